@@ -1,0 +1,98 @@
+"""The oracle (oracle/model_ref.py) against the fixtures produced by executing the reference source.
+
+Tolerances: the fixtures are fp32 runs of the reference op sequence; the oracle restates the same
+sequence in torch, so agreement is at fp32 summation-order level.  The *_f64 fixtures (same graph in
+double precision) bound how far either fp32 run sits from the exact answer.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as R
+
+CONV_CASES = ["c1_raw", "c1_coarsened", "rand_5_7", "rand_32_64", "rand_128_64", "rand_nomask"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_backward_matches_reference(golden_dir, case):
+    z = _load(golden_dir, "conv_%s.npz" % case)
+    x = torch.tensor(z["x"], requires_grad=True)
+    adj = torch.tensor(z["adj"])
+    cin = x.shape[2]
+    params = [p.requires_grad_(True) for p in R.conv_params(cin, int(z["cout"]), int(z["seed"]))]
+    y = R.custom_conv2d(x, adj, params, biasMask=(case != "rand_nomask"))
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=0, atol=2e-6)
+    (y * torch.tensor(z["dy"])).sum().backward()
+    for key, p in zip(["dW0", "db", "du", "dc", "dv"], params):
+        ref = z[key]
+        tol = 2e-6 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=0, atol=tol, err_msg=key)
+    np.testing.assert_allclose(x.grad.numpy(), z["dx"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fp32_error_budget_vs_float64(golden_dir, case):
+    """How far the fp32 reference run is from the float64 run of the same graph (documents the tolerance)."""
+    z32 = _load(golden_dir, "conv_%s.npz" % case)
+    z64 = _load(golden_dir, "conv_%s_f64.npz" % case)
+    assert np.array_equal(z32["x"], z64["x"])
+    err = np.abs(z32["y"].astype(np.float64) - z64["y"]).max()
+    assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("name,ms", [("net_ico3", False), ("net_ico3_ms", True), ("net_torus640", False)])
+def test_net_loss_and_gradients_match_reference(golden_dir, name, ms):
+    z = _load(golden_dir, name + ".npz")
+    prep = _load(golden_dir, "prep_ico3.npz" if "ico3" in name else "prep_torus640.npz")
+    x = torch.tensor(prep["x"].astype(np.float32))
+    gt = torch.tensor(prep["gt"].astype(np.float32))
+    adjs = [torch.tensor(prep["adj%d" % l].astype(np.int32)) for l in range(3)]
+    params = [p.requires_grad_(True) for p in R.init_params(int(z["seed"]), multi_scale=ms)]
+    assert len(params) == int(z["n_vars"])
+    Rm = torch.tensor(z["R"].astype(np.float32))
+    x_r, gt_r = R.rotate_inputs(x, gt, Rm)
+    np.testing.assert_allclose(x_r.numpy(), z["fn_rot"], atol=1e-6)
+    np.testing.assert_allclose(gt_r.numpy(), z["tfn_rot"], atol=1e-6)
+    out = R.get_model_reg_multi_scale(x_r, adjs, params, multiScale=ms)
+    ys = out if ms else (out,)
+    for i, y in enumerate(ys):
+        ref = z["y%d" % i]
+        np.testing.assert_allclose(y.detach().numpy(), ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
+    n_conv = R.normalizeTensor(ys[0])
+    np.testing.assert_allclose(n_conv.detach().numpy(), z["n_conv"], rtol=0, atol=2e-5)
+    idx = torch.tensor(z["sample_ind"])
+    loss = R.faceNormalsLoss(n_conv[:, idx], gt_r[:, idx])
+    assert abs(loss.item() - float(z["loss"])) < 2e-3 * max(1.0, float(z["loss"])) * 1e-1
+    loss.backward()
+    for i, p in enumerate(params):
+        ref = z["g%02d" % i]
+        g = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        scale = max(np.abs(ref).max(), 1e-3)
+        np.testing.assert_allclose(g, ref, rtol=0, atol=2e-3 * scale, err_msg="grad %d" % i)
+
+
+def test_infer_epilogue_matches_reference(golden_dir):
+    z = _load(golden_dir, "infer_ico3.npz")
+    prep = _load(golden_dir, "prep_ico3.npz")
+    x = torch.tensor(prep["x"].astype(np.float32))
+    adjs = [torch.tensor(prep["adj%d" % l].astype(np.int32)) for l in range(3)]
+    params = R.init_params(0)
+    n_conv = R.normalizeTensor(R.get_model_reg_multi_scale(x, adjs, params))
+    np.testing.assert_allclose(n_conv.numpy(), z["n_conv"], atol=2e-5)
+    pred = R.infer_epilogue(n_conv, prep["permutations"], int(prep["num_faces"]))
+    np.testing.assert_allclose(pred.numpy(), z["predicted_normals"], atol=2e-5)
+    assert pred.shape == (1280, 3)
+
+
+def test_parameter_count_matches_reference():
+    """474 199 params in 44 variables; multi-scale adds 204 806 in 8."""
+    n = sum(int(np.prod(s)) for _, s in R.param_spec(False))
+    assert (len(R.param_spec(False)), n) == (44, 474199)
+    nms = sum(int(np.prod(s)) for _, s in R.param_spec(True))
+    assert (len(R.param_spec(True)), nms - n) == (52, 204806)
