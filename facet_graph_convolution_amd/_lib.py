@@ -1,0 +1,124 @@
+"""ctypes binding of libfgc.so (the C ABI declared in include/fgc.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, a
+RuntimeError is raised.  torch is imported first so that libfgc resolves the HIP runtime
+torch already loaded (same SONAME libamdhip64.so.7), i.e. both share streams and pointers.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfgc.so")
+
+FGC_M = 9
+AG_LD = 24
+DL_LD = 12
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("nnz", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p),
+        ("x0", C.c_void_p), ("x1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32), ("shift", C.c_int32), ("cout", C.c_int32),
+        ("W0", C.c_void_p), ("b", C.c_void_p), ("u", C.c_void_p), ("c", C.c_void_p), ("v", C.c_void_p),
+        ("bias_mask", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
+class ConvBwdIO(C.Structure):
+    _fields_ = [
+        ("trowptr", C.c_void_p), ("tcol", C.c_void_p), ("tedge", C.c_void_p),
+        ("ag", C.c_void_p), ("y", C.c_void_p), ("dy", C.c_void_p),
+        ("ds", C.c_void_p), ("dl", C.c_void_p), ("dag", C.c_void_p), ("r", C.c_void_p),
+        ("dx0", C.c_void_p), ("dx1", C.c_void_p),
+        ("accumulate0", C.c_int32), ("accumulate1", C.c_int32),
+        ("dW0", C.c_void_p), ("db", C.c_void_p), ("du", C.c_void_p), ("dc", C.c_void_p), ("dv", C.c_void_p),
+    ]
+
+
+_SIGS = {
+    "fgc_last_error": (C.c_char_p, []),
+    "fgc_version": (C.c_int, []),
+    "fgc_csr_from_klist": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_klist_from_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "fgc_csr_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "fgc_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_void_p]),
+    "fgc_conv_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fgc_mlp_num_partials": (C.c_int32, [C.c_int32]),
+    "fgc_mlp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "fgc_mlp_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                              C.c_void_p]),
+    "fgc_mlp_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fgc_lrelu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "fgc_lrelu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "fgc_pool4_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "fgc_pool4_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_void_p]),
+    "fgc_upsample4_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "fgc_upsample4_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "fgc_norm_num_partials": (C.c_int32, [C.c_int32]),
+    "fgc_normalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "fgc_normalize_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_angular_loss_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_angular_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_float, C.c_void_p, C.c_void_p]),
+    "fgc_rotate_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "fgc_infer_epilogue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_scatter_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libfgc.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C facet_graph_convolution_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            if os.environ.get("FGC_DEV_PARTIAL") and not hasattr(L, name):
+                continue  # developer-only: library under construction
+            fn = getattr(L, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what="libfgc"):
+    if rc != 0:
+        msg = lib().fgc_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) address of a tensor; None -> NULL."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())

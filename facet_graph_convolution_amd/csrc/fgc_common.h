@@ -1,0 +1,74 @@
+// Shared helpers for libfgc (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/fgc.h"
+
+namespace fgc {
+
+void set_error(const char* fmt, ...);
+
+#define FGC_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            fgc::set_error(__VA_ARGS__);  \
+            return FGC_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define FGC_CHECK_LAUNCH(what)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            fgc::set_error("%s: launch failed: %s", what, hipGetErrorString(e__));    \
+            return FGC_EHIP;                                                          \
+        }                                                                             \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- geometry of the fused "edge-aggregate + MFMA" kernels ------------------------------
+// A node's input row is processed KC = 4*LPN channels per pass by LPN lanes (float4 each).
+struct ConvGeom {
+    int cin, cout;
+    int lpn;        // lanes per node: 2,4,8
+    int kc;         // channels per pass = 4*lpn
+    int passes;     // ceil(cin / kc)
+    int kpass;      // M*kc rounded up to a multiple of 16 (MFMA k-group)
+    int zstride;    // LDS row stride (floats), == 8 mod 16, >= kpass
+    int npad;       // output columns padded to a multiple of 16
+    int T;          // nodes per workgroup tile
+};
+
+static inline int lds_stride_for(int kpass) {
+    // smallest s >= kpass with s % 16 == 8: the ds_read_b128 A-fragment pattern
+    // (lane l -> row l&15, float offset 4*(l>>4)) is then bank-conflict free (brute-forced
+    // against the gfx950 b128 lane groups for every such stride < 2000).
+    int s = (kpass / 16) * 16 + 8;
+    while (s < kpass) s += 16;
+    return s;
+}
+
+static inline ConvGeom conv_geom(int cin, int cout) {
+    ConvGeom g;
+    g.cin = cin;
+    g.cout = cout;
+    int lpn = 2;
+    while (lpn < 8 && lpn * 4 < cin) lpn *= 2;
+    g.lpn = lpn;
+    g.kc = 4 * lpn;
+    g.passes = (cin + g.kc - 1) / g.kc;
+    g.kpass = (FGC_M * g.kc + 15) / 16 * 16;
+    g.zstride = lds_stride_for(g.kpass);
+    g.npad = (cout + 15) / 16 * 16;
+    g.T = 32;
+    return g;
+}
+
+}  // namespace fgc

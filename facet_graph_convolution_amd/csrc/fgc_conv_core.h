@@ -1,0 +1,306 @@
+// Fused "edge softmax -> neighbour aggregate -> f32 MFMA" core shared by the forward
+// graph convolution and by its data-gradient (which is a convolution of the same shape
+// over the transposed graph).  gfx950 only: wave64, v_mfma_f32_16x16x4_f32, 160 KB LDS.
+//
+// Work decomposition (one 256-thread workgroup = 4 waves = one tile of T = 32 nodes):
+//   phase S  (once)      thread (node = tid/8, kl = tid%8) computes the M = 9 assignment
+//                        softmax of edges kl, kl+8, kl+16 of its node -> LDS qbuf
+//   per pass p over KC = 4*LPN gathered channels:
+//     phase A            thread (node, cl) streams its node's neighbour rows (float4 per
+//                        lane, 128 B contiguous per node for LPN = 8) and accumulates
+//                        z[m][4] += q[m] * x_j[4]      (36 fp32 accumulators / lane)
+//                        -> LDS ztile[node][m*KC + cl*4 ..]
+//     phase G            MFMA: acc[T x npad] += ztile[T x kpass] * Wp[kpass x npad]
+//                        A fragments by ds_read_b128 (row stride == 8 mod 64 floats: conflict
+//                        free), B fragments by one global dwordx4 per 4 MFMAs from the
+//                        k-interleaved packed weights (L2 resident, shared by all tiles)
+//   epilogue             accumulators -> LDS (k-split partials summed in fixed order)
+//                        -> op-specific epilogue (bias/act/pool, or dx assembly)
+#pragma once
+#include "fgc_common.h"
+
+namespace fgc {
+
+constexpr int TILE = 32;        // nodes per workgroup
+constexpr int KMAX = 24;        // >= K_faces (23) edge slots per node kept in LDS
+constexpr int QLD = 12;         // floats per edge in qbuf: q[0..8], [9] = source row of the neighbour (int bits)
+constexpr int NTHREADS = 256;
+constexpr int MAX_NPAD = 128;   // GEMM N limit (cout / cin of the transposed op)
+
+struct CoreParams {
+    int n;                   // nodes
+    const int* rowptr;       // CSR used for gathering (forward: out-edges, bwd-data: in-edges)
+    const int* col;
+    const int* eid;          // bwd-data only: forward edge id of each in-edge (else NULL)
+    const float* src0;       // gathered rows, source 0: [(n>>shift), c0]
+    const float* src1;       // source 1 or NULL
+    int c0, c1, shift;       // gathered width cg = c0 + c1
+    int cg;                  // gathered channels
+    int nout;                // GEMM N (real), npad = roundup16
+    int npad;
+    int passes, kc, kpass, zstride;
+    const float* ag;         // logits table [(n>>shift_ag), 24]
+    int ag_shift;            // row = node >> ag_shift
+    int ctr_off, nbr_off;    // 0 (a) / 12 (g): which half the centre / the neighbour contributes
+    const float* Wp;         // packed B operand [passes*kpass/4][npad] float4
+};
+
+// ---- LDS carve ---------------------------------------------------------------------------
+struct Smem {
+    float* ztile;   // [TILE][zstride]
+    float* qbuf;    // [TILE][KMAX][QLD]  (slot 9 of each row: neighbour source row, already >> shift)
+    int* deg;       // [TILE] + 4 scratch ints (no static __shared__: keeps the dynamic base 16-B aligned)
+    float* extra;   // op specific
+};
+
+__device__ __forceinline__ Smem carve(char* base, int zstride) {
+    Smem s;
+    s.ztile = reinterpret_cast<float*>(base);
+    size_t off = (size_t)TILE * zstride * 4;
+    s.qbuf = reinterpret_cast<float*>(base + off);
+    off += (size_t)TILE * KMAX * QLD * 4;
+    s.deg = reinterpret_cast<int*>(base + off);
+    off += (TILE + 4) * 4;
+    s.extra = reinterpret_cast<float*>(base + off);
+    return s;
+}
+static inline size_t smem_core_bytes(int zstride) {
+    return (size_t)TILE * zstride * 4 + (size_t)TILE * KMAX * QLD * 4 + (TILE + 4) * 4;
+}
+
+// ---- phase S: per-edge soft assignment ------------------------------------------------------
+// q_ikm = softmax_m(ctr[m] + nbr[m])  (model.py:79-94; c is already folded into the a half)
+// Edges [kbase, kbase+KMAX) of every node of the tile are processed per call (one call covers
+// every node whose degree is <= KMAX = 24, i.e. every reference K-list; longer in-edge lists of
+// asymmetric graphs take several chunks).  Returns this thread's node degree.
+template <bool WITH_DL>
+__device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s, int tile0, int kbase,
+                                             const float* dl, float* dgsum /* [9] += sum of dl over my edges */) {
+    const int tid = threadIdx.x;
+    const int node = tid >> 3, kl = tid & 7;
+    const int i = tile0 + node;
+    int d = 0, e0 = 0;
+    float ctr[FGC_M];
+    if (i < p.n) {
+        e0 = p.rowptr[i];
+        d = p.rowptr[i + 1] - e0;
+        const float* ar = p.ag + (size_t)(i >> p.ag_shift) * FGC_AG_LD + p.ctr_off;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+        ctr[0] = a0[0]; ctr[1] = a0[1]; ctr[2] = a0[2]; ctr[3] = a0[3];
+        ctr[4] = a1[0]; ctr[5] = a1[1]; ctr[6] = a1[2]; ctr[7] = a1[3];
+        ctr[8] = ar[8];
+    }
+    if (kl == 0) s.deg[node] = d;
+    const int kend = min(d, kbase + KMAX);
+    for (int kk = kbase + kl; kk < kend; kk += 8) {
+        const int e = e0 + kk;
+        const int k = kk - kbase;
+        const int j = p.col[e];
+        const float* gr = p.ag + (size_t)(j >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gr + 4);
+        float l[FGC_M];
+        l[0] = ctr[0] + g0[0]; l[1] = ctr[1] + g0[1]; l[2] = ctr[2] + g0[2]; l[3] = ctr[3] + g0[3];
+        l[4] = ctr[4] + g1[0]; l[5] = ctr[5] + g1[1]; l[6] = ctr[6] + g1[2]; l[7] = ctr[7] + g1[3];
+        l[8] = ctr[8] + gr[8];
+        float mx = l[0];
+#pragma unroll
+        for (int m = 1; m < FGC_M; ++m) mx = fmaxf(mx, l[m]);
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) {
+            l[m] = expf(l[m] - mx);
+            sum += l[m];
+        }
+        const float inv = 1.0f / sum;
+        float* q = s.qbuf + ((size_t)node * KMAX + k) * QLD;
+        *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
+        *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
+        q[8] = l[8] * inv;
+        q[9] = __int_as_float(j >> p.shift);
+        if (WITH_DL) {
+            const float* dr = dl + (size_t)p.eid[e] * FGC_DL_LD;
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dr);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dr + 4);
+            dgsum[0] += d0[0]; dgsum[1] += d0[1]; dgsum[2] += d0[2]; dgsum[3] += d0[3];
+            dgsum[4] += d1[0]; dgsum[5] += d1[1]; dgsum[6] += d1[2]; dgsum[7] += d1[3];
+            dgsum[8] += dr[8];
+        }
+    }
+    return d;
+}
+
+// number of KMAX-edge chunks the tile needs (max over the block); also the barrier that
+// publishes qbuf/deg written by softmax_phase.
+__device__ __forceinline__ int edge_chunks(const Smem& s, int my_degree) {
+    const int any_long = __syncthreads_or(my_degree > KMAX);
+    if (!any_long) return 1;
+    int* maxd = s.deg + TILE;
+    if (threadIdx.x == 0) *maxd = 0;
+    __syncthreads();
+    atomicMax(maxd, my_degree);
+    __syncthreads();
+    return (*maxd + KMAX - 1) / KMAX;
+}
+
+// ---- gathered row chunk load ----------------------------------------------------------------
+// channels [cbase, cbase+4) of the concatenated source row `row`
+template <bool VEC4>
+__device__ __forceinline__ f32x4 load_chunk(const CoreParams& p, int row, int cbase) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (VEC4) {
+        if (cbase < p.c0) {
+            v = *reinterpret_cast<const f32x4*>(p.src0 + (size_t)row * p.c0 + cbase);
+        } else if (cbase < p.cg) {
+            v = *reinterpret_cast<const f32x4*>(p.src1 + (size_t)row * p.c1 + (cbase - p.c0));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = cbase + t;
+            if (c < p.c0) v[t] = p.src0[(size_t)row * p.c0 + c];
+            else if (c < p.cg) v[t] = p.src1[(size_t)row * p.c1 + (c - p.c0)];
+        }
+    }
+    return v;
+}
+
+// ---- phase A: z[m][4] = sum_k q[k][m] * x_j(k)[4] ---------------------------------------------
+// thread (node, cl): node = tid / LPN (only the first TILE*LPN threads work), cl = tid % LPN
+// accumulates into z (caller zeroes it); covers the edge chunk currently held in qbuf
+template <int LPN, bool VEC4>
+__device__ __forceinline__ void aggregate_pass(const CoreParams& p, const Smem& s, int pass, int kbase,
+                                               f32x4 (&z)[FGC_M]) {
+    const int tid = threadIdx.x;
+    const int node = tid / LPN, cl = tid % LPN;
+    if (node >= TILE) return;
+    const int d = min(max(s.deg[node] - kbase, 0), KMAX);
+    const int cbase = pass * p.kc + cl * 4;
+    const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
+    int k = 0;
+    for (; k + 4 <= d; k += 4) {
+        f32x4 xv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xv[t] = load_chunk<VEC4>(p, __float_as_int(qb[(k + t) * QLD + 9]), cbase);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float* q = qb + (k + t) * QLD;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
+            const float q8 = q[8];
+            z[0] += q0[0] * xv[t]; z[1] += q0[1] * xv[t]; z[2] += q0[2] * xv[t]; z[3] += q0[3] * xv[t];
+            z[4] += q1[0] * xv[t]; z[5] += q1[1] * xv[t]; z[6] += q1[2] * xv[t]; z[7] += q1[3] * xv[t];
+            z[8] += q8 * xv[t];
+        }
+    }
+    for (; k < d; ++k) {
+        const f32x4 xv = load_chunk<VEC4>(p, __float_as_int(qb[k * QLD + 9]), cbase);
+        const float* q = qb + k * QLD;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
+        const float q8 = q[8];
+        z[0] += q0[0] * xv; z[1] += q0[1] * xv; z[2] += q0[2] * xv; z[3] += q0[3] * xv;
+        z[4] += q1[0] * xv; z[5] += q1[1] * xv; z[6] += q1[2] * xv; z[7] += q1[3] * xv;
+        z[8] += q8 * xv;
+    }
+}
+
+template <int LPN>
+__device__ __forceinline__ void store_ztile(const CoreParams& p, const Smem& s, const f32x4 (&z)[FGC_M]) {
+    const int tid = threadIdx.x;
+    const int node = tid / LPN, cl = tid % LPN;
+    if (node >= TILE) return;
+    float* zr = s.ztile + (size_t)node * p.zstride + cl * 4;
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x4*>(zr + m * p.kc) = z[m];
+}
+
+// zero the k padding columns [M*kc, kpass) of the z tile (only LPN = 2 has any)
+__device__ __forceinline__ void zero_zpad(const CoreParams& p, const Smem& s) {
+    const int padw = p.kpass - FGC_M * p.kc;
+    if (padw <= 0) return;
+    for (int t = threadIdx.x; t < TILE * padw; t += NTHREADS) {
+        const int r = t / padw, c = t % padw;
+        s.ztile[(size_t)r * p.zstride + FGC_M * p.kc + c] = 0.f;
+    }
+}
+
+// ---- phase G: MFMA over one pass ------------------------------------------------------------
+// Wave w owns column tiles ct = ct0, ct0+ctstep, ... (< nct) and the k-groups [kg0, kg1).
+struct WaveTiling {
+    int ct0, ctstep, kparts, kpart;
+};
+__device__ __forceinline__ WaveTiling wave_tiling(int npad) {
+    const int w = threadIdx.x >> 6;
+    const int nct = npad >> 4;
+    WaveTiling t;
+    t.kparts = nct >= 3 ? 1 : (nct == 2 ? 2 : 4);
+    const int wpk = 4 / t.kparts;  // waves per k-part
+    t.kpart = w / wpk;
+    t.ct0 = w % wpk;
+    t.ctstep = wpk;
+    return t;
+}
+
+constexpr int CTW = 2;  // column tiles per wave (npad <= 128)
+constexpr int RT = TILE / 16;
+
+__device__ __forceinline__ void gemm_pass(const CoreParams& p, const Smem& s, int pass, const WaveTiling& wt,
+                                          f32x4 (&acc)[RT][CTW]) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nct = p.npad >> 4;
+    const int kg_total = p.kpass >> 4;
+    const int kg0 = kg_total * wt.kpart / wt.kparts;
+    const int kg1 = kg_total * (wt.kpart + 1) / wt.kparts;
+    const f32x4* Wp4 = reinterpret_cast<const f32x4*>(p.Wp);
+    const size_t wrow0 = (size_t)pass * (p.kpass >> 2);
+    bool ctv[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) ctv[c] = (wt.ct0 + c * wt.ctstep) < nct;
+    if (!ctv[0]) return;
+    for (int g = kg0; g < kg1; ++g) {
+        f32x4 a[RT], b[CTW];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + g * 16 + lq * 4);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ctv[c]) b[c] = Wp4[(wrow0 + g * 4 + lq) * p.npad + (wt.ct0 + c * wt.ctstep) * 16 + lr];
+        }
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            if (!ctv[c]) continue;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// accumulators -> LDS out tile [kparts][TILE][oldd]; caller must have synchronised so that
+// the region (aliasing ztile) is free.
+__device__ __forceinline__ void store_acc(float* otile, int oldd, const WaveTiling& wt, int npad,
+                                          const f32x4 (&acc)[RT][CTW]) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nct = npad >> 4;
+    float* base = otile + (size_t)wt.kpart * TILE * oldd;
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int ct = wt.ct0 + c * wt.ctstep;
+        if (ct >= nct) continue;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) base[(size_t)(r * 16 + lq * 4 + t) * oldd + ct * 16 + lr] = acc[r][c][t];
+        }
+    }
+}
+
+}  // namespace fgc

@@ -1,0 +1,202 @@
+/*
+ * fgc.h - C ABI of libfgc.so, the MI355X (gfx950) facet-graph-convolution kernels.
+ *
+ * The reference (Elensil/Facet_Graph_Convolution) has no FFI: its "operator API" is the
+ * set of Python functions in Code/model.py that build TensorFlow graph nodes.  This
+ * header is the boundary a maintainer would bind instead (ctypes stub: INTEGRATION.md);
+ * each entry point names the reference symbol (file:line) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _h (host);
+ *   - the caller owns every buffer; the library allocates nothing and never synchronises;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); 0 = default stream;
+ *   - return 0 on success, a negative FGC_E* code otherwise; fgc_last_error() gives the
+ *     text for the calling thread;
+ *   - float tensors are fp32 row-major with channels innermost ([n, C]); index tensors int32;
+ *   - M (number of soft-assignment weight matrices) is fixed to FGC_M = 9 (model.py:855).
+ *
+ * Adjacency: the reference K-list (int32 [n, K], one-indexed, 0 = empty slot, slot 0 =
+ * self; utils.py:243-295, utils.py:1799-1827) is converted once to CSR that PRESERVES
+ * slot order and duplicates: col[rowptr[i] .. rowptr[i+1]) = adj[i, k] - 1 over the
+ * non-zero slots k in increasing k.  deg(i) = rowptr[i+1] - rowptr[i] = count_nonzero
+ * (model.py:436).
+ */
+#ifndef FGC_H
+#define FGC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGC_M 9            /* soft-assignment matrices per conv (model.py:855,868,880) */
+#define FGC_AG_LD 24       /* row stride of the assignment-logit table: a[0..8] pad, g[12..20] pad */
+#define FGC_DL_LD 12       /* row stride of the per-edge dlogit buffer */
+
+#define FGC_OK 0
+#define FGC_EINVAL (-22)
+#define FGC_ENOMEM (-12)
+#define FGC_EHIP (-5)
+
+const char* fgc_last_error(void);
+int fgc_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side graph conversion (CPU; pointers are HOST pointers)
+ * ---------------------------------------------------------------------------------- */
+
+/* K-list -> CSR.  rowptr_h [n+1]; col_h may be NULL to query nnz only.
+ * replaces: the K-padded adjacency fed to get_slices/get_patches (model.py:380-405). */
+int fgc_csr_from_klist(const int32_t* adj_h, int32_t n, int32_t K, int32_t* rowptr_h, int32_t* col_h,
+                       int64_t* nnz_out);
+/* CSR -> K-list (zero padded).  Bit-identical round trip for rows whose zeros are trailing. */
+int fgc_klist_from_csr(const int32_t* rowptr_h, const int32_t* col_h, int32_t n, int32_t K, int32_t* adj_h);
+/* Transposed CSR for the backward pass: for every node j the list of (i, e) such that forward
+ * edge e = (i -> j); in-edges ordered by e.  trowptr_h [n+1], tcol_h [nnz] (= i), tedge_h [nnz] (= e). */
+int fgc_csr_transpose(const int32_t* rowptr_h, const int32_t* col_h, int32_t n, int32_t* trowptr_h,
+                      int32_t* tcol_h, int32_t* tedge_h);
+
+/* ------------------------------------------------------------------------------------
+ * Graph convolution  (replaces custom_conv2d, model.py:427-504, invariance-off branch,
+ * with get_weight_assigments model.py:74-95 and get_patches model.py:380-405 fused in)
+ *
+ *   a_i = u x_i + c,  g_j = v x_j,  q_ik = softmax_m(a_i + g_j(i,k))
+ *   y_i = (1/deg_i) sum_k sum_m q_ikm W0[m] x_j(i,k) + b [deg_i > 0]
+ *
+ * The input of node j is the channel concatenation [x0 | x1] of row (j >> shift) of each
+ * source (shift = 2 reads a 4x-upsampled coarse tensor, model.py:817-825, without
+ * materialising it; x1 = NULL for a single source; concat replaces tf.concat model.py:909,929).
+ * act: 0 = none, 1 = leaky ReLU with `alpha` (model.py:828-830) applied to y.
+ * y_pool (optional, may be NULL): max over each 4 consecutive rows of y (model.py:779-788).
+ * ---------------------------------------------------------------------------------- */
+typedef struct fgc_conv_desc {
+    int32_t n;              /* nodes of this level */
+    int32_t nnz;            /* edges */
+    const int32_t* rowptr;  /* [n+1] */
+    const int32_t* col;     /* [nnz] */
+    const float* x0;        /* [(n >> shift), c0] */
+    const float* x1;        /* [(n >> shift), c1] or NULL */
+    int32_t c0, c1;         /* cin = c0 + c1 */
+    int32_t shift;          /* 0 or 2 */
+    int32_t cout;
+    const float* W0;        /* [M, cout, cin]  (model.py:430) */
+    const float* b;         /* [cout]          (model.py:431) */
+    const float* u;         /* [M, cin]        (model.py:432) */
+    const float* c;         /* [M]             (model.py:433) */
+    const float* v;         /* [M, cin]        (model.py:447) */
+    int32_t bias_mask;      /* model.py:496-500 */
+    int32_t act;
+    float alpha;
+} fgc_conv_desc;
+
+/* bytes of scratch the conv entry points need for this descriptor (packed weights) */
+size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d);
+
+/* forward.  ag [(n >> shift), FGC_AG_LD] receives the assignment logits (kept for backward).
+ * y [n, cout]; y_pool [n/4, cout] or NULL. */
+int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* y_pool, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* backward.  Transposed CSR required.  dy is the gradient w.r.t. the POST-activation output y
+ * (y itself is passed to recover the leaky-ReLU mask).  Scratch the caller provides:
+ *   ds   [n, cout]           dy * lrelu'(y) / deg
+ *   dl   [nnz, FGC_DL_LD]    per-edge d(logit)
+ *   dag  [(n >> shift), FGC_AG_LD]   d a | d g per source row
+ *   r    [n, M*cout]         backward-side aggregate (feeds the dW reduction)
+ * Outputs: dW0,db,du,dc,dv (overwritten); dx0/dx1 [(n >> shift), c0/c1] either overwritten
+ * (accumulate = 0) or added to (accumulate = 1); dx pointers may be NULL (conv1: no input grad). */
+typedef struct fgc_conv_bwd_io {
+    const int32_t* trowptr; /* [n+1] */
+    const int32_t* tcol;    /* [nnz] */
+    const int32_t* tedge;   /* [nnz] */
+    const float* ag;        /* saved by forward */
+    const float* y;         /* forward output (post activation) */
+    const float* dy;        /* [n, cout] */
+    float* ds;
+    float* dl;
+    float* dag;
+    float* r;
+    float* dx0;
+    float* dx1;
+    int32_t accumulate0, accumulate1;
+    float* dW0;
+    float* db;
+    float* du;
+    float* dc;
+    float* dv;
+} fgc_conv_bwd_io;
+
+size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
+int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-facet MLP  cin -> hidden -> cout with leaky ReLU in between
+ * (replaces lrelu(custom_lin(x,1024)) -> custom_lin(.,3), model.py:763-769,937-941; the
+ * [n, hidden] tensor never leaves the CU).  W1 [cin, hidden], b1 [hidden], W2 [hidden, cout], b2 [cout].
+ * abs_partial (optional): per-workgroup partial sums of |y| for normalizeTensor's global mean;
+ * needs fgc_mlp_num_partials(n) floats.
+ * ---------------------------------------------------------------------------------- */
+int32_t fgc_mlp_num_partials(int32_t n);
+size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout);
+int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
+                const float* b1, const float* W2, const float* b2, float alpha, float* y, float* abs_partial,
+                void* workspace, size_t workspace_bytes, void* stream);
+/* dW1,db1,dW2,db2 overwritten; dx [n, cin] overwritten. */
+int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
+                const float* W1, const float* b1, const float* W2, float alpha, float* dx, float* dW1,
+                float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Element-wise / reduction ops
+ * ---------------------------------------------------------------------------------- */
+/* leaky ReLU (model.py:828-830), forward and backward from the OUTPUT y */
+int fgc_lrelu_fwd(const float* x, float* y, int64_t count, float alpha, void* stream);
+int fgc_lrelu_bwd(const float* y, const float* dy, float* dx, int64_t count, float alpha, void* stream);
+/* 4:1 max pooling over consecutive rows (model.py:779-788, steps = 2) */
+int fgc_pool4_fwd(const float* x, float* y, int32_t n_out, int32_t c, void* stream);
+/* gradient of max pooling, split evenly over ties (tf.reduce_max semantics).  accumulate: dx += */
+int fgc_pool4_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t n_out, int32_t c,
+                  int32_t accumulate, void* stream);
+/* 1:4 upsampling by repetition (model.py:817-825) and its gradient (sum of 4 rows) */
+int fgc_upsample4_fwd(const float* x, float* y, int32_t n_in, int32_t c, void* stream);
+int fgc_upsample4_bwd(const float* dy, float* dx, int32_t n_in, int32_t c, int32_t accumulate, void* stream);
+
+/* normalizeTensor (utils.py:1700-1715).  scratch: 2 + fgc_norm_num_partials(n) floats.
+ * If abs_partial/num_partials come from fgc_mlp_fwd they are used for the global mean,
+ * otherwise pass NULL/0 and the op reduces |x| itself. */
+int32_t fgc_norm_num_partials(int32_t n);
+int fgc_normalize_fwd(const float* x, int32_t n, const float* abs_partial, int32_t num_partials, float* y,
+                      float* scratch, void* stream);
+int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, float* dx, float* scratch, void* stream);
+
+/* angular loss on sampled rows (train.py:509-517 gather + faceNormalsLoss train.py:1272-1294).
+ * fn, gt [n,3]; sample_ind int32 [ns]; loss_out [2] = {loss in degrees, number of real rows}.
+ * bwd: dfn [n,3] is zero-filled then receives d loss / d fn (scaled by dloss). */
+int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns, float* loss_out,
+                         void* stream);
+int fgc_angular_loss_bwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns, int32_t n,
+                         const float* loss_out, float dloss, float* dfn, void* stream);
+
+/* random-rotation augmentation (train.py:439-451): every 3-vector of every row times R^T.
+ * R_h: HOST pointer to 9 floats (row major). vecs = channels / 3. */
+int fgc_rotate_rows(const float* x, float* y, int32_t n, int32_t vecs, const float* R_h, void* stream);
+
+/* TensorFlow-1 Adam over one flat parameter buffer (train.py:520, tf.train.AdamOptimizer defaults:
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)).  t is 1-based. */
+int fgc_adam_step(float* p, const float* g, float* m, float* v, int64_t count, int32_t t, float lr, float b1,
+                  float b2, float eps, void* stream);
+
+/* inference epilogue (train.py:115-121,136; utils.py:26-35): out[f] = normalize^2(n_conv[perm[f]]), f < num_faces */
+int fgc_infer_epilogue(const float* n_conv, const int32_t* perm, int32_t num_faces, float* out, void* stream);
+
+/* halo pack / unpack for facet sharding: dst[i] = src[idx[i]] rows of width c */
+int fgc_gather_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst, void* stream);
+int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGC_H */
