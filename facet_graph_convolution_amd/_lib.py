@@ -55,6 +55,7 @@ _SIGS = {
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_mlp_num_partials": (C.c_int32, [C.c_int32]),
     "fgc_mlp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "fgc_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "fgc_mlp_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),

@@ -1,0 +1,686 @@
+// Backward of the graph convolution (gradient of custom_conv2d, /root/reference/Code/model.py:427-504;
+// the reference gets it from tf.gradients over ~25 materialised ops, train.py:520).
+//
+// With s_i = dy_i * lrelu'(y_i) / deg_i  (the gradient w.r.t. the per-node sum), a_i/g_j/q_ik as in forward:
+//   K1  logits kernel (node i centred, forward CSR)
+//         dz_i   = W^T s_i                        f32 MFMA  [T,cout] x [cout, 9*cin]   -> LDS
+//         dq_ikm = <dz_i[m,:], x_j>               per edge, 8 lanes x float4, butterfly reduce
+//         dl_ikm = q_ikm (dq_ikm - sum_m' q dq)   -> dl[e, 12]   (softmax backward)
+//         da_i   = sum_k dl_ik                    -> dag[i, 0..8];   dc partial per workgroup
+//   K2  data kernel (node j centred, TRANSPOSED CSR): the same fused core as forward
+//         r_j[m,:] = sum_{i->j} q_ijm s_i         -> r[j, 9*cout]  (also the dW reduction's A operand)
+//         dg_j     = sum_{i->j} dl_(i->j)         -> dag[j, 12..20]
+//         dx_j     = r_j W  (f32 MFMA) + da_j u + dg_j v ; 4:1 row sum when the input was upsampled
+//   K3  reductions over nodes (f32 MFMA, K = nodes):  dW0 = r^T x,  [du; dv] = dag^T x ; db, dc column sums
+// No float atomics anywhere: every sum has a fixed order, results are bitwise reproducible.
+#include "fgc_conv_core.h"
+
+namespace fgc {
+
+int validate_conv_desc(const fgc_conv_desc* d, const char* who);
+bool conv_vec4_ok(const fgc_conv_desc* d);
+void fill_core_params(CoreParams& p, const ConvGeom& g, int n, const int* rowptr, const int* col, const int* eid,
+                      const float* s0, const float* s1, int c0, int c1, int shift, int nout, const float* ag,
+                      int ag_shift, int ctr_off, int nbr_off, const float* Wp);
+size_t conv_smem_bytes(const ConvGeom& g, size_t extra);
+__global__ void pack_weight_kernel(const float* __restrict__ W0, float* __restrict__ Wp, int cin, int cout, int kdim,
+                                   int ncols, int npad, int kc, int kpass, int passes, int transposed);
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nslabs, size_t count, int in_ld, int out_ld,
+                                    float* __restrict__ out);
+
+__device__ __forceinline__ float slope_from_y(float y, float alpha) { return y > 0.f ? 1.f : (y < 0.f ? alpha : 0.f); }
+
+// ---------------------------------------------------------------------------------------------
+// s = dy * lrelu'(y) / deg ; db partial column sums of dy * lrelu'(y) over rows that got the bias
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void ds_db_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                    const int* __restrict__ rowptr, int n, int cout, int act,
+                                                    float alpha, int bias_mask, int rows_per_block,
+                                                    float* __restrict__ ds, float* __restrict__ db_part) {
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    for (int col = threadIdx.x; col < cout; col += blockDim.x) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const int d = rowptr[r + 1] - rowptr[r];
+            float g = dy[(size_t)r * cout + col];
+            if (act) g *= slope_from_y(y[(size_t)r * cout + col], alpha);
+            if (!bias_mask || d > 0) acc += g;
+            ds[(size_t)r * cout + col] = d > 0 ? g / (float)d : 0.f;
+        }
+        db_part[(size_t)blockIdx.x * cout + col] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 operand: Wq[pass][o/4][kk][o%4] = W0[m][o][pass*kc+cl], kk = m*kc+cl  (K = cout, N = kpass)
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_logit_weight_kernel(const float* __restrict__ W0, float* __restrict__ Wq, int cin, int cout,
+                                         int opad, int kc, int kpass, int passes) {
+    const size_t total = (size_t)passes * opad * kpass;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        const size_t v4 = idx >> 2;
+        const int kk = v4 % kpass;
+        const size_t rest = v4 / kpass;
+        const int o4 = rest % (opad >> 2);
+        const int pass = (int)(rest / (opad >> 2));
+        const int o = o4 * 4 + e;
+        const int m = kk / kc, cl = kk % kc;
+        const int c = pass * kc + cl;
+        Wq[idx] = (m < FGC_M && o < cout && c < cin) ? W0[((size_t)m * cout + o) * cin + c] : 0.f;
+    }
+}
+
+struct LogitParams {
+    const float* ds;     // [n, cout]
+    int cout, opad, ostride;  // opad = roundup16(cout); LDS stride of the ds tile (== 8 mod 16)
+    const float* Wq;
+    float* dl;           // [nnz, 12]
+    float* dag;          // [n, 24]  (writes 0..8)
+    float* dc_part;      // [grid, 12]
+};
+
+constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> ceil(18/4)
+
+template <int LPN, bool VEC4>
+__global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p, LogitParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw, p.zstride);
+    float* dst = s.extra;                       // ds tile [TILE][ostride]
+    float* red = dst + TILE * lp.ostride;       // [4][12] block reduction scratch
+    const int tile0 = blockIdx.x * TILE;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    constexpr int SLOTS = KMAX / LPN;           // edges owned per lane: k = slot*LPN + cl
+
+    // ds tile -> LDS (zero padded)
+    for (int t = tid; t < TILE * lp.opad; t += NTHREADS) {
+        const int r = t / lp.opad, o = t % lp.opad;
+        const int i = tile0 + r;
+        dst[r * lp.ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
+    }
+    const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
+    const int nchunks = edge_chunks(s, dmine);
+
+    const int node = tid / LPN, cl = tid % LPN;
+    const bool worker = node < TILE;
+    float dcacc[FGC_M];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) dcacc[m] = 0.f;
+    float daacc[FGC_M];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) daacc[m] = 0.f;
+
+    const int nct = p.kpass >> 4;
+    const int okg = lp.opad >> 4;
+    const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int kbase = ch * KMAX;
+        if (ch > 0) {
+            __syncthreads();
+            softmax_phase<false>(p, s, tile0, kbase, nullptr, nullptr);
+            __syncthreads();
+        }
+        float dq[SLOTS][FGC_M];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) dq[sl][m] = 0.f;
+
+        for (int pass = 0; pass < p.passes; ++pass) {
+            // ---- dz tile = ds tile x Wq[pass]  (MFMA), C layout -> ztile
+            f32x4 acc[RT][K1_CTW];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < okg; ++g) {
+                f32x4 a[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * lp.ostride + g * 16 + lq * 4);
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c) {
+                    const int ct = wave + c * 4;
+                    if (ct >= nct) continue;
+                    const f32x4 b = Wq4[((size_t)pass * (lp.opad >> 2) + g * 4 + lq) * p.kpass + ct * 16 + lr];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r][c], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // previous pass' readers of ztile are done
+#pragma unroll
+            for (int c = 0; c < K1_CTW; ++c) {
+                const int ct = wave + c * 4;
+                if (ct >= nct) continue;
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        s.ztile[(size_t)(r * 16 + lq * 4 + t) * p.zstride + ct * 16 + lr] = acc[r][c][t];
+            }
+            __syncthreads();
+            // ---- per edge: dq[m] += <dz_i[m, chunk], x_j[chunk]>
+            if (worker) {
+                f32x4 dz[FGC_M];
+                const float* zr = s.ztile + (size_t)node * p.zstride + cl * 4;
+#pragma unroll
+                for (int m = 0; m < FGC_M; ++m) dz[m] = *reinterpret_cast<const f32x4*>(zr + m * p.kc);
+                const int d = min(max(s.deg[node] - kbase, 0), KMAX);
+                const int cbase = pass * p.kc + cl * 4;
+                const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    for (int kk = 0; kk < LPN; ++kk) {
+                        const int k = sl * LPN + kk;
+                        if (k >= d) break;
+                        const f32x4 xv = load_chunk<VEC4>(p, __float_as_int(qb[k * QLD + 9]), cbase);
+                        float part[FGC_M];
+#pragma unroll
+                        for (int m = 0; m < FGC_M; ++m) {
+                            float v = dz[m][0] * xv[0];
+                            v = fmaf(dz[m][1], xv[1], v);
+                            v = fmaf(dz[m][2], xv[2], v);
+                            v = fmaf(dz[m][3], xv[3], v);
+#pragma unroll
+                            for (int off = 1; off < LPN; off <<= 1) v += __shfl_xor(v, off);
+                            part[m] = v;
+                        }
+                        if (kk == cl) {
+#pragma unroll
+                            for (int m = 0; m < FGC_M; ++m) dq[sl][m] += part[m];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- softmax backward for the edges this lane owns
+        if (worker) {
+            const int i = tile0 + node;
+            const int d = min(max(s.deg[node] - kbase, 0), KMAX);
+            const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
+            const int e0 = i < p.n ? p.rowptr[i] + kbase : 0;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int k = sl * LPN + cl;
+                if (k < d) {
+                    float q[FGC_M];
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + k * QLD);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(qb + k * QLD + 4);
+                    q[0] = q0[0]; q[1] = q0[1]; q[2] = q0[2]; q[3] = q0[3];
+                    q[4] = q1[0]; q[5] = q1[1]; q[6] = q1[2]; q[7] = q1[3];
+                    q[8] = qb[k * QLD + 8];
+                    float dot = 0.f;
+#pragma unroll
+                    for (int m = 0; m < FGC_M; ++m) dot = fmaf(q[m], dq[sl][m], dot);
+                    float dlv[FGC_M];
+#pragma unroll
+                    for (int m = 0; m < FGC_M; ++m) {
+                        dlv[m] = q[m] * (dq[sl][m] - dot);
+                        daacc[m] += dlv[m];
+                        dcacc[m] += dlv[m];
+                    }
+                    float* o = lp.dl + (size_t)(e0 + k) * FGC_DL_LD;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{dlv[0], dlv[1], dlv[2], dlv[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{dlv[4], dlv[5], dlv[6], dlv[7]};
+                    *reinterpret_cast<f32x4*>(o + 8) = f32x4{dlv[8], 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+    // da_i: sum over the node's LPN lanes
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) {
+        float v = daacc[m];
+#pragma unroll
+        for (int off = 1; off < LPN; off <<= 1) v += __shfl_xor(v, off);
+        daacc[m] = v;
+    }
+    if (worker && cl == 0 && tile0 + node < p.n) {
+        float* o = lp.dag + (size_t)(tile0 + node) * FGC_AG_LD;
+        *reinterpret_cast<f32x4*>(o) = f32x4{daacc[0], daacc[1], daacc[2], daacc[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{daacc[4], daacc[5], daacc[6], daacc[7]};
+        *reinterpret_cast<f32x4*>(o + 8) = f32x4{daacc[8], 0.f, 0.f, 0.f};
+    }
+    // dc partial of this workgroup (fixed order: wave butterfly, then 4 waves)
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) {
+        float v = dcacc[m];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        dcacc[m] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) red[wave * 12 + m] = dcacc[m];
+    }
+    __syncthreads();
+    if (tid < 12) {
+        const float v = tid < FGC_M ? (red[tid] + red[12 + tid]) + (red[24 + tid] + red[36 + tid]) : 0.f;
+        lp.dc_part[(size_t)blockIdx.x * 12 + tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: data gradient = forward core over the transposed graph
+// ---------------------------------------------------------------------------------------------
+struct DataEpilogue {
+    const float* dl;      // [nnz, 12]
+    float* dag;           // reads 0..8 (da), writes 12..20 (dg)
+    float* r;             // [n, 9*cout]
+    int rld;              // 9*cout
+    const float* u;       // [9, cin]
+    const float* v;       // [9, cin]
+    int cin, c0f, c1f;    // forward input split
+    int shiftf;           // forward input shift (0 / 2)
+    float* dx0;
+    float* dx1;
+    int acc0, acc1;
+};
+
+template <int LPN, bool VEC4>
+__global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, DataEpilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw, p.zstride);
+    float* dagt = s.extra;  // [TILE][24]: da | dg of the tile's nodes
+    const int tile0 = blockIdx.x * TILE;
+    const int tid = threadIdx.x;
+    const WaveTiling wt = wave_tiling(p.npad);
+
+    float dgsum[FGC_M];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) dgsum[m] = 0.f;
+    const int dmine = softmax_phase<true>(p, s, tile0, 0, ep.dl, dgsum);
+    zero_zpad(p, s);
+    const int nchunks = edge_chunks(s, dmine);
+
+    f32x4 acc[RT][CTW];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool want_dx = ep.dx0 != nullptr;
+    for (int pass = 0; pass < p.passes; ++pass) {
+        f32x4 z[FGC_M];
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) z[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        aggregate_pass<LPN, VEC4>(p, s, pass, 0, z);
+        for (int ch = 1; ch < nchunks; ++ch) {
+            __syncthreads();
+            float dummy[FGC_M];
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) dummy[m] = 0.f;
+            if (pass == 0) softmax_phase<true>(p, s, tile0, ch * KMAX, ep.dl, dgsum);
+            else softmax_phase<false>(p, s, tile0, ch * KMAX, nullptr, dummy);
+            __syncthreads();
+            aggregate_pass<LPN, VEC4>(p, s, pass, ch * KMAX, z);
+        }
+        if (nchunks > 1 && pass + 1 < p.passes) {
+            __syncthreads();
+            softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
+            __syncthreads();
+        }
+        // r[j, m*cout + channel] straight from the accumulators
+        {
+            const int node = tid / LPN, cl = tid % LPN;
+            const int j = tile0 + node;
+            const int ch0 = pass * p.kc + cl * 4;
+            if (node < TILE && j < p.n && ch0 < p.cg) {
+                float* rr = ep.r + (size_t)j * ep.rld + ch0;
+                if (VEC4) {
+#pragma unroll
+                    for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x4*>(rr + m * p.cg) = z[m];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < FGC_M; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (ch0 + t < p.cg) rr[m * p.cg + t] = z[m][t];
+                }
+            }
+        }
+        if (!want_dx) continue;
+        if (pass > 0) __syncthreads();
+        store_ztile<LPN>(p, s, z);
+        __syncthreads();
+        gemm_pass(p, s, pass, wt, acc);
+    }
+    // dg_j = sum over in-edges of dl: reduce the 8 softmax lanes of each node
+    {
+        const int node = tid >> 3, kl = tid & 7;
+        const int j = tile0 + node;
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) {
+            float v = dgsum[m];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            dgsum[m] = v;
+        }
+        if (kl == 0) {
+            float* t = dagt + node * 24;
+            if (j < p.n) {
+                const float* da = ep.dag + (size_t)j * FGC_AG_LD;
+#pragma unroll
+                for (int m = 0; m < FGC_M; ++m) {
+                    t[m] = da[m];
+                    t[12 + m] = dgsum[m];
+                }
+                float* o = ep.dag + (size_t)j * FGC_AG_LD + 12;
+                *reinterpret_cast<f32x4*>(o) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
+                *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int m = 0; m < 24; ++m) t[m] = 0.f;
+            }
+        }
+    }
+    if (!want_dx) return;
+    __syncthreads();
+    const int oldd = p.npad + 4;
+    float* otile = s.ztile;
+    store_acc(otile, oldd, wt, p.npad, acc);
+    __syncthreads();
+
+    // dx rows: GEMM part + da.u + dg.v ; optional 4:1 row sum (input was an upsampled coarse tensor)
+    const int kparts = wt.kparts;
+    const int group = 1 << ep.shiftf;  // 1 or 4 tile rows per source row
+    const int nsrc = TILE / group;
+    for (int t = tid; t < nsrc * ep.cin; t += NTHREADS) {
+        const int sr = t / ep.cin, c = t % ep.cin;
+        float val = 0.f;
+        bool any = false;
+        for (int q = 0; q < group; ++q) {
+            const int row = sr * group + q;
+            if (tile0 + row >= p.n) continue;
+            any = true;
+            float g = 0.f;
+            for (int kp = 0; kp < kparts; ++kp) g += otile[((size_t)kp * TILE + row) * oldd + c];
+            const float* dg = dagt + row * 24;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                g = fmaf(dg[m], ep.u[m * ep.cin + c], g);
+                g = fmaf(dg[12 + m], ep.v[m * ep.cin + c], g);
+            }
+            val += g;
+        }
+        if (!any) continue;
+        const size_t srow = (size_t)((tile0 >> ep.shiftf) + sr);
+        if (c < ep.c0f) {
+            float* o = ep.dx0 + srow * ep.c0f + c;
+            *o = ep.acc0 ? *o + val : val;
+        } else if (ep.dx1) {
+            float* o = ep.dx1 + srow * ep.c1f + (c - ep.c0f);
+            *o = ep.acc1 ? *o + val : val;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: C[P,Q] = sum_rows A[row,P] * X[row >> shift, Q]   (X = [x0 | x1]); f32 MFMA with K = rows.
+// grid (P/64, nsplit): each workgroup owns 64 columns of A, all Q, and a contiguous row range; its
+// partial goes to slab[split][P][Q]; a fixed-order pass sums the slabs.
+// ---------------------------------------------------------------------------------------------
+constexpr int TN_QT = 8;  // Q <= 128
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, int P,
+                                                      const float* __restrict__ x0, const float* __restrict__ x1,
+                                                      int c0, int c1, int shift, int rows, int rows_per_split,
+                                                      float* __restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) float As[16][64];
+    __shared__ __attribute__((aligned(16))) float Bs[16][128];
+    const int Q = c0 + c1;
+    const int qpad = (Q + 15) & ~15;
+    const int nqt = qpad >> 4;
+    const int p0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_end = min(rows, r_begin + rows_per_split);
+    f32x4 acc[TN_QT];
+#pragma unroll
+    for (int q = 0; q < TN_QT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int rb = r_begin; rb < r_end; rb += 16) {
+        __syncthreads();
+        for (int t = tid; t < 16 * 64; t += 256) {
+            const int rr = t >> 6, pp = t & 63;
+            const int row = rb + rr;
+            As[rr][pp] = (row < r_end && p0 + pp < P) ? A[(size_t)row * lda + p0 + pp] : 0.f;
+        }
+        for (int t = tid; t < 16 * qpad; t += 256) {
+            const int rr = t / qpad, qq = t % qpad;
+            const int row = rb + rr;
+            float v = 0.f;
+            if (row < r_end && qq < Q) {
+                const size_t sr = (size_t)(row >> shift);
+                v = qq < c0 ? x0[sr * c0 + qq] : x1[sr * c1 + (qq - c0)];
+            }
+            Bs[rr][qq] = v;
+        }
+        __syncthreads();
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = As[lq * 4 + t][wave * 16 + lr];
+#pragma unroll
+        for (int q = 0; q < TN_QT; ++q) {
+            if (q >= nqt) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Bs[lq * 4 + t][q * 16 + lr], acc[q], 0, 0, 0);
+        }
+    }
+    float* out = slab + (size_t)blockIdx.y * P * Q;
+#pragma unroll
+    for (int q = 0; q < TN_QT; ++q) {
+        if (q >= nqt) break;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pp = p0 + wave * 16 + lq * 4 + t;
+            const int qq = q * 16 + lr;
+            if (pp < P && qq < Q) out[(size_t)pp * Q + qq] = acc[q][t];
+        }
+    }
+}
+
+static int tn_splits(int P, int rows) {
+    const int pb = cdiv(P, 64);
+    int s = 1024 / pb;
+    const int maxs = cdiv(rows, 64);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return s;
+}
+
+struct BwdWorkspace {
+    float* Wq;        // logits operand
+    float* Wpt;       // data-gradient operand
+    float* db_part;   // [nb][cout]
+    float* dc_part;   // [tiles][12]
+    float* slab;      // gemm_tn partials
+    float* duv;       // [24, cin]
+    size_t bytes;
+    int nb_db, rows_per_db;
+    int splitW, splitUV;
+};
+
+static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
+    BwdWorkspace w;
+    const int cin = d->c0 + d->c1;
+    const ConvGeom g1 = conv_geom(cin, d->cout);
+    const ConvGeom g2 = conv_geom(d->cout, cin);
+    const int opad = (d->cout + 15) / 16 * 16;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* ptr = base ? (float*)(base + off) : nullptr;
+        off += align_up(nfloats * 4, 256);
+        return ptr;
+    };
+    w.Wq = take((size_t)g1.passes * opad * g1.kpass);
+    w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
+    w.rows_per_db = 256;
+    w.nb_db = cdiv(d->n, w.rows_per_db);
+    w.db_part = take((size_t)w.nb_db * d->cout);
+    w.dc_part = take((size_t)cdiv(d->n, TILE) * 12);
+    w.splitW = tn_splits(FGC_M * d->cout, d->n);
+    w.splitUV = tn_splits(24, d->n);
+    const size_t s1 = (size_t)w.splitW * FGC_M * d->cout * cin;
+    const size_t s2 = (size_t)w.splitUV * 24 * cin;
+    w.slab = take(s1 > s2 ? s1 : s2);
+    w.duv = take((size_t)24 * cin);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace fgc
+
+using namespace fgc;
+
+extern "C" size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d) {
+    if (!d) return 0;
+    return plan_bwd(d, nullptr).bytes;
+}
+
+template <int LPN>
+static int launch_logits(const CoreParams& p, const LogitParams& lp, bool vec4, size_t smem, hipStream_t st) {
+    const int grid = cdiv(p.n, TILE);
+    if (vec4) {
+        hipFuncSetAttribute((const void*)conv_bwd_logits_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+        hipLaunchKernelGGL((conv_bwd_logits_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, st, p, lp);
+    } else {
+        hipFuncSetAttribute((const void*)conv_bwd_logits_kernel<LPN, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+        hipLaunchKernelGGL((conv_bwd_logits_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, st, p, lp);
+    }
+    FGC_CHECK_LAUNCH("fgc_conv_bwd/logits");
+    return FGC_OK;
+}
+
+template <int LPN>
+static int launch_data(const CoreParams& p, const DataEpilogue& ep, bool vec4, size_t smem, hipStream_t st) {
+    const int grid = cdiv(p.n, TILE);
+    if (vec4) {
+        hipFuncSetAttribute((const void*)conv_bwd_data_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+        hipLaunchKernelGGL((conv_bwd_data_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, st, p, ep);
+    } else {
+        hipFuncSetAttribute((const void*)conv_bwd_data_kernel<LPN, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+        hipLaunchKernelGGL((conv_bwd_data_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, st, p, ep);
+    }
+    FGC_CHECK_LAUNCH("fgc_conv_bwd/data");
+    return FGC_OK;
+}
+
+extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    int rc = validate_conv_desc(d, "fgc_conv_bwd");
+    if (rc) return rc;
+    FGC_CHECK_ARG(io != nullptr, "fgc_conv_bwd: null io");
+    FGC_CHECK_ARG(io->trowptr && io->tcol && io->tedge, "fgc_conv_bwd: transposed CSR missing");
+    FGC_CHECK_ARG(io->ag && io->dy && io->ds && io->dl && io->dag && io->r, "fgc_conv_bwd: null buffer");
+    FGC_CHECK_ARG(!d->act || io->y, "fgc_conv_bwd: y required when an activation was applied");
+    FGC_CHECK_ARG(io->dW0 && io->db && io->du && io->dc && io->dv, "fgc_conv_bwd: null parameter-gradient pointer");
+    FGC_CHECK_ARG(io->dx0 != nullptr || io->dx1 == nullptr, "fgc_conv_bwd: dx1 without dx0");
+    FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_conv_bwd_workspace_bytes(d) && (uintptr_t)workspace % 16 == 0,
+                  "fgc_conv_bwd: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
+                  fgc_conv_bwd_workspace_bytes(d));
+    hipStream_t st = (hipStream_t)stream;
+    const int cin = d->c0 + d->c1;
+    const int cout = d->cout;
+    const BwdWorkspace w = plan_bwd(d, (char*)workspace);
+    const ConvGeom g1 = conv_geom(cin, cout);   // gathers x (cin wide)
+    const ConvGeom g2 = conv_geom(cout, cin);   // gathers s (cout wide), GEMM N = cin
+    const int opad = (cout + 15) / 16 * 16;
+    const int ostride = opad + 8;
+
+    // s = dy*lrelu'(y)/deg, db partials
+    hipLaunchKernelGGL(ds_db_kernel, dim3(w.nb_db), dim3(128), 0, st, io->dy, io->y, d->rowptr, d->n, cout, d->act,
+                       d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(128), 0, st, w.db_part, w.nb_db, (size_t)cout, cout, cout,
+                       io->db);
+    FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");
+    // operand packing
+    {
+        const size_t tot = (size_t)g1.passes * opad * g1.kpass;
+        hipLaunchKernelGGL(pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, st, d->W0, w.Wq, cin, cout,
+                           opad, g1.kc, g1.kpass, g1.passes);
+        const size_t tot2 = (size_t)g2.passes * g2.kpass * g2.npad;
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv((int)tot2, 1024)), dim3(256), 0, st, d->W0, w.Wpt, cin, cout, cout,
+                           cin, g2.npad, g2.kc, g2.kpass, g2.passes, 1);
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
+    }
+    // K1
+    {
+        CoreParams p;
+        fill_core_params(p, g1, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, cout, io->ag,
+                         d->shift, 0, 12, nullptr);
+        LogitParams lp{io->ds, cout, opad, ostride, w.Wq, io->dl, io->dag, w.dc_part};
+        const size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
+        const bool vec4 = conv_vec4_ok(d);
+        switch (g1.lpn) {
+            case 2: rc = launch_logits<2>(p, lp, vec4, smem, st); break;
+            case 4: rc = launch_logits<4>(p, lp, vec4, smem, st); break;
+            default: rc = launch_logits<8>(p, lp, vec4, smem, st); break;
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(64), 0, st, w.dc_part, cdiv(d->n, TILE), (size_t)12, 12,
+                           FGC_M, io->dc);
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/dc");
+    }
+    // K2
+    {
+        CoreParams p;
+        fill_core_params(p, g2, d->n, io->trowptr, io->tcol, io->tedge, io->ds, nullptr, cout, 0, 0, cin, io->ag,
+                         d->shift, 12, 0, w.Wpt);
+        DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout, d->u, d->v, cin, d->c0, d->c1, d->shift,
+                        io->dx0, io->dx1, io->accumulate0, io->accumulate1};
+        const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
+        const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
+        switch (g2.lpn) {
+            case 2: rc = launch_data<2>(p, ep, vec4, smem, st); break;
+            case 4: rc = launch_data<4>(p, ep, vec4, smem, st); break;
+            default: rc = launch_data<8>(p, ep, vec4, smem, st); break;
+        }
+        if (rc) return rc;
+    }
+    // K3: dW0 = r^T x
+    {
+        const int P = FGC_M * cout;
+        const int rps = cdiv(cdiv(d->n, w.splitW), 16) * 16;
+        const int ns = cdiv(d->n, rps);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(P, 64), ns), dim3(256), 0, st, io->r, P, P, d->x0, d->x1, d->c0,
+                           d->c1, d->shift, d->n, rps, w.slab);
+        const size_t cnt = (size_t)P * cin;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, w.slab, ns, cnt, cin, cin,
+                           io->dW0);
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
+    }
+    // [du; dv] = dag^T x
+    {
+        const int rps = cdiv(cdiv(d->n, w.splitUV), 16) * 16;
+        const int ns = cdiv(d->n, rps);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(1, ns), dim3(256), 0, st, io->dag, FGC_AG_LD, 24, d->x0, d->x1, d->c0,
+                           d->c1, d->shift, d->n, rps, w.slab);
+        const size_t cnt = (size_t)24 * cin;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, w.slab, ns, cnt, cin, cin,
+                           w.duv);
+        if (hipMemcpyAsync(io->du, w.duv, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(io->dv, w.duv + (size_t)12 * cin, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) !=
+                hipSuccess) {
+            fgc::set_error("fgc_conv_bwd: copy of du/dv failed");
+            return FGC_EHIP;
+        }
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/duv");
+    }
+    return FGC_OK;
+}

@@ -1,0 +1,440 @@
+// Element-wise and reduction ops of the denoising path.  All are HBM-bound streaming kernels:
+// float4 accesses where the layout allows, grid capped at 2048 blocks with grid-stride loops,
+// reductions in two deterministic stages (no float atomics, bitwise reproducible).
+#include <math.h>
+
+#include "fgc_common.h"
+
+namespace fgc {
+
+constexpr int EW_THREADS = 256;
+static inline int ew_grid(int64_t count) {
+    int64_t b = (count + EW_THREADS - 1) / EW_THREADS;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+__device__ __forceinline__ float lrelu_f(float v, float alpha) { return fmaxf(v, 0.f) - alpha * fmaxf(-v, 0.f); }
+// derivative expressed through the OUTPUT y (alpha > 0 keeps the sign): 1, alpha, or 0 at exactly 0
+// (tf.nn.relu's gradient is 0 at 0 for both relu terms of model.py:830)
+__device__ __forceinline__ float lrelu_slope(float y, float alpha) { return y > 0.f ? 1.f : (y < 0.f ? alpha : 0.f); }
+
+__global__ void lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = lrelu_f(x[i], alpha);
+}
+__global__ void lrelu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                 int64_t count, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * lrelu_slope(y[i], alpha);
+}
+
+__global__ void pool4_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count, int c) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const int col = (int)(i % c);
+        const float* p = x + (r * 4) * c + col;
+        y[i] = fmaxf(fmaxf(p[0], p[c]), fmaxf(p[2 * c], p[3 * c]));
+    }
+}
+// tf.reduce_max gradient: dy split evenly over the entries equal to the max
+__global__ void pool4_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                 const float* __restrict__ dy, float* __restrict__ dx, int64_t count, int c,
+                                 int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const int col = (int)(i % c);
+        const float m = y[i];
+        const float* p = x + (r * 4) * c + col;
+        float* q = dx + (r * 4) * c + col;
+        const float e0 = p[0] == m ? 1.f : 0.f, e1 = p[c] == m ? 1.f : 0.f, e2 = p[2 * c] == m ? 1.f : 0.f,
+                    e3 = p[3 * c] == m ? 1.f : 0.f;
+        const float g = dy[i] / (e0 + e1 + e2 + e3);
+        if (accumulate) {
+            q[0] += e0 * g; q[c] += e1 * g; q[2 * c] += e2 * g; q[3 * c] += e3 * g;
+        } else {
+            q[0] = e0 * g; q[c] = e1 * g; q[2 * c] = e2 * g; q[3 * c] = e3 * g;
+        }
+    }
+}
+__global__ void upsample4_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count_out, int c) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count_out;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        y[i] = x[(r >> 2) * c + i % c];
+    }
+}
+__global__ void upsample4_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t count_in, int c,
+                                     int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count_in;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const int col = (int)(i % c);
+        const float* p = dy + (r * 4) * c + col;
+        const float v = (p[0] + p[c]) + (p[2 * c] + p[3 * c]);
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+// ---- block reduction helper (deterministic) ---------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats LDS */) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    return t;
+}
+
+// ---- normalizeTensor (utils.py:1700-1715) ---------------------------------------------------
+constexpr int NORM_ROWS_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void abs_partial_kernel(const float* __restrict__ x, int64_t count,
+                                                          float* __restrict__ part) {
+    __shared__ float red[4];
+    const int64_t i0 = (int64_t)blockIdx.x * NORM_ROWS_PER_BLOCK * 3;
+    const int64_t i1 = min(count, i0 + (int64_t)NORM_ROWS_PER_BLOCK * 3);
+    float v = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) v += fabsf(x[i]);
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+// scratch[0] = mean|x| + eps  (single block, fixed order)
+__global__ __launch_bounds__(256) void finish_mean_kernel(const float* __restrict__ part, int nparts, float count,
+                                                          float* __restrict__ scratch) {
+    __shared__ float red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) scratch[0] = v / count + 1e-5f;
+}
+__global__ void normalize_fwd_kernel(const float* __restrict__ x, int n, const float* __restrict__ scratch,
+                                     float* __restrict__ y) {
+    const float eps = 1e-5f;
+    const float s = scratch[0];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const float a = x[3 * r] / s, b = x[3 * r + 1] / s, c = x[3 * r + 2] / s;
+        const float norm = sqrtf(eps + (a * a + b * b + c * c));
+        const float inv = norm > eps ? 1.0f / (norm + eps) : 0.f;
+        y[3 * r] = a * inv;
+        y[3 * r + 1] = b * inv;
+        y[3 * r + 2] = c * inv;
+    }
+}
+// backward.  xs = x/s, out = xs*inv(norm).  d xs = dy*inv - xs * (dy.xs) * inv^2 / norm   (norm > eps)
+// d s = -sum(d xs . x)/s^2 ;  d x = d xs / s + sign(x) * d s / (3n)
+__global__ __launch_bounds__(256) void normalize_bwd_stage1(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            int n, const float* __restrict__ scratch,
+                                                            float* __restrict__ dxs /* reuse dx buffer */,
+                                                            float* __restrict__ part) {
+    __shared__ float red[4];
+    const float eps = 1e-5f;
+    const float s = scratch[0];
+    const int r0 = blockIdx.x * NORM_ROWS_PER_BLOCK;
+    const int r1 = min(n, r0 + NORM_ROWS_PER_BLOCK);
+    float acc = 0.f;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float x0 = x[3 * r], x1 = x[3 * r + 1], x2 = x[3 * r + 2];
+        const float a = x0 / s, b = x1 / s, c = x2 / s;
+        const float norm = sqrtf(eps + (a * a + b * b + c * c));
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (norm > eps) {
+            const float inv = 1.0f / (norm + eps);
+            const float d0 = dy[3 * r], d1 = dy[3 * r + 1], d2 = dy[3 * r + 2];
+            const float dot = d0 * a + d1 * b + d2 * c;
+            const float k = dot * inv * inv / norm;
+            g0 = d0 * inv - a * k;
+            g1 = d1 * inv - b * k;
+            g2 = d2 * inv - c * k;
+        }
+        dxs[3 * r] = g0;
+        dxs[3 * r + 1] = g1;
+        dxs[3 * r + 2] = g2;
+        acc += g0 * x0 + g1 * x1 + g2 * x2;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void normalize_bwd_finish(const float* __restrict__ part, int nparts,
+                                                            float* __restrict__ scratch) {
+    __shared__ float red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) {
+        const float s = scratch[0];
+        scratch[1] = -v / (s * s);  // d s
+    }
+}
+__global__ void normalize_bwd_stage2(const float* __restrict__ x, int64_t count, const float* __restrict__ scratch,
+                                     float inv_count, float* __restrict__ dx) {
+    const float s = scratch[0];
+    const float ds = scratch[1] * inv_count;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float xv = x[i];
+        const float sg = xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f);
+        dx[i] = dx[i] / s + sg * ds;
+    }
+}
+
+// ---- angular loss on sampled rows (train.py:509-517, 1272-1294) ---------------------------------
+__global__ __launch_bounds__(256) void angular_loss_fwd_kernel(const float* __restrict__ fn,
+                                                               const float* __restrict__ gt,
+                                                               const int* __restrict__ idx, int ns,
+                                                               float* __restrict__ out) {
+    __shared__ float red[4];
+    const float close = 0.9999999f;
+    float lsum = 0.f, rsum = 0.f;
+    for (int s = threadIdx.x; s < ns; s += 256) {
+        const int r = idx[s];
+        const float g0 = gt[3 * r], g1 = gt[3 * r + 1], g2 = gt[3 * r + 2];
+        const float f0 = fn[3 * r], f1 = fn[3 * r + 1], f2 = fn[3 * r + 2];
+        const bool fake = (fabsf(g0) + fabsf(g1) + fabsf(g2)) <= 10e-4f;
+        if (!fake) {
+            const float dt = f0 * g0 + f1 * g1 + f2 * g2;
+            lsum += 180.f * acosf(fminf(fmaxf(dt, -close), close)) / 3.14159265358979323846f;
+            rsum += 1.f;
+        }
+    }
+    lsum = block_sum(lsum, red);
+    rsum = block_sum(rsum, red);
+    if (threadIdx.x == 0) {
+        out[0] = lsum / rsum;
+        out[1] = rsum;
+    }
+}
+// d loss / d fn[r] = -(180/pi) / sqrt(1-c^2) * gt[r] / nreal   when |dot| < close (clip gradient is 0 outside)
+__global__ void angular_loss_bwd_kernel(const float* __restrict__ fn, const float* __restrict__ gt,
+                                        const int* __restrict__ idx, int ns, const float* __restrict__ loss_out,
+                                        float dloss, float* __restrict__ dfn) {
+    const float close = 0.9999999f;
+    const float nreal = loss_out[1];
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+        const int r = idx[s];
+        const float g0 = gt[3 * r], g1 = gt[3 * r + 1], g2 = gt[3 * r + 2];
+        const bool fake = (fabsf(g0) + fabsf(g1) + fabsf(g2)) <= 10e-4f;
+        if (fake) continue;
+        const float dt = fn[3 * r] * g0 + fn[3 * r + 1] * g1 + fn[3 * r + 2] * g2;
+        // tf.minimum/maximum pass the gradient to the un-clipped input only while it is strictly inside
+        // (ties: tf gives the gradient to the first argument when equal -> still n_dt for maximum(n_dt,-c)
+        //  at equality; measure-zero, ignored)
+        if (dt > close || dt < -close) continue;
+        const float k = -(180.f / 3.14159265358979323846f) / sqrtf(1.f - dt * dt) * dloss / nreal;
+        // duplicates in sample_ind add identical values: order-independent, so atomics stay deterministic
+        atomicAdd(&dfn[3 * r], k * g0);
+        atomicAdd(&dfn[3 * r + 1], k * g1);
+        atomicAdd(&dfn[3 * r + 2], k * g2);
+    }
+}
+
+// ---- rotation augmentation (train.py:439-451) ---------------------------------------------------
+struct Rot {
+    float r[9];
+};
+__global__ void rotate_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t nvec, Rot R) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+        y[3 * i] = R.r[0] * a + R.r[1] * b + R.r[2] * c;
+        y[3 * i + 1] = R.r[3] * a + R.r[4] * b + R.r[5] * c;
+        y[3 * i + 2] = R.r[6] * a + R.r[7] * b + R.r[8] * c;
+    }
+}
+
+// ---- TF1 Adam ------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t count, float lr_t, float b1, float b2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---- inference epilogue (train.py:115-121,136) -------------------------------------------------
+__global__ void infer_epilogue_kernel(const float* __restrict__ nc, const int* __restrict__ perm, int nf,
+                                      float* __restrict__ out) {
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
+        const int r = perm[f];
+        float a = nc[3 * r], b = nc[3 * r + 1], c = nc[3 * r + 2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {  // utils.normalize = normalizeOnce twice (utils.py:26-35)
+            const float k = 1.0f / (sqrtf(a * a + b * b + c * c) + 0.00000001f);
+            a *= k;
+            b *= k;
+            c *= k;
+        }
+        out[3 * f] = a;
+        out[3 * f + 1] = b;
+        out[3 * f + 2] = c;
+    }
+}
+
+// ---- halo pack / unpack -------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int64_t count, int c,
+                                   float* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        dst[i] = src[(int64_t)idx[r] * c + i % c];
+    }
+}
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int64_t count,
+                                        int c, float* __restrict__ dst) {
+    // idx must be duplicate-free (each halo row has one owner): plain read-modify-write, deterministic
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        dst[(int64_t)idx[r] * c + i % c] += src[i];
+    }
+}
+
+}  // namespace fgc
+
+using namespace fgc;
+#define ST ((hipStream_t)stream)
+
+extern "C" int fgc_lrelu_fwd(const float* x, float* y, int64_t count, float alpha, void* stream) {
+    FGC_CHECK_ARG(x && y && count >= 0, "fgc_lrelu_fwd: bad arguments");
+    if (!count) return FGC_OK;
+    hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, ST, x, y, count, alpha);
+    FGC_CHECK_LAUNCH("fgc_lrelu_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_lrelu_bwd(const float* y, const float* dy, float* dx, int64_t count, float alpha, void* stream) {
+    FGC_CHECK_ARG(y && dy && dx && count >= 0, "fgc_lrelu_bwd: bad arguments");
+    if (!count) return FGC_OK;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, ST, y, dy, dx, count, alpha);
+    FGC_CHECK_LAUNCH("fgc_lrelu_bwd");
+    return FGC_OK;
+}
+extern "C" int fgc_pool4_fwd(const float* x, float* y, int32_t n_out, int32_t c, void* stream) {
+    FGC_CHECK_ARG(x && y && n_out > 0 && c > 0, "fgc_pool4_fwd: bad arguments");
+    const int64_t cnt = (int64_t)n_out * c;
+    hipLaunchKernelGGL(pool4_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, x, y, cnt, c);
+    FGC_CHECK_LAUNCH("fgc_pool4_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_pool4_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t n_out, int32_t c,
+                             int32_t accumulate, void* stream) {
+    FGC_CHECK_ARG(x && y && dy && dx && n_out > 0 && c > 0, "fgc_pool4_bwd: bad arguments");
+    const int64_t cnt = (int64_t)n_out * c;
+    hipLaunchKernelGGL(pool4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, x, y, dy, dx, cnt, c, accumulate);
+    FGC_CHECK_LAUNCH("fgc_pool4_bwd");
+    return FGC_OK;
+}
+extern "C" int fgc_upsample4_fwd(const float* x, float* y, int32_t n_in, int32_t c, void* stream) {
+    FGC_CHECK_ARG(x && y && n_in > 0 && c > 0, "fgc_upsample4_fwd: bad arguments");
+    const int64_t cnt = (int64_t)n_in * 4 * c;
+    hipLaunchKernelGGL(upsample4_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, x, y, cnt, c);
+    FGC_CHECK_LAUNCH("fgc_upsample4_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_upsample4_bwd(const float* dy, float* dx, int32_t n_in, int32_t c, int32_t accumulate,
+                                 void* stream) {
+    FGC_CHECK_ARG(dy && dx && n_in > 0 && c > 0, "fgc_upsample4_bwd: bad arguments");
+    const int64_t cnt = (int64_t)n_in * c;
+    hipLaunchKernelGGL(upsample4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, dy, dx, cnt, c, accumulate);
+    FGC_CHECK_LAUNCH("fgc_upsample4_bwd");
+    return FGC_OK;
+}
+
+extern "C" int32_t fgc_norm_num_partials(int32_t n) { return cdiv(n, NORM_ROWS_PER_BLOCK); }
+
+extern "C" int fgc_normalize_fwd(const float* x, int32_t n, const float* abs_partial, int32_t num_partials, float* y,
+                                 float* scratch, void* stream) {
+    FGC_CHECK_ARG(x && y && scratch && n > 0, "fgc_normalize_fwd: bad arguments");
+    const float inv_count = 3.0f * (float)n;  // element count (the kernel divides)
+    if (abs_partial && num_partials > 0) {
+        hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, ST, abs_partial, num_partials, inv_count, scratch);
+    } else {
+        const int np = fgc_norm_num_partials(n);
+        hipLaunchKernelGGL(abs_partial_kernel, dim3(np), dim3(256), 0, ST, x, (int64_t)n * 3, scratch + 2);
+        hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, ST, scratch + 2, np, inv_count, scratch);
+    }
+    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, ST, x, n, scratch, y);
+    FGC_CHECK_LAUNCH("fgc_normalize_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, float* dx, float* scratch,
+                                 void* stream) {
+    FGC_CHECK_ARG(x && dy && dx && scratch && n > 0, "fgc_normalize_bwd: bad arguments");
+    // scratch[0] (= mean|x| + eps) is the value left by fgc_normalize_fwd on the same x
+    const int np = fgc_norm_num_partials(n);
+    hipLaunchKernelGGL(normalize_bwd_stage1, dim3(np), dim3(256), 0, ST, x, dy, n, scratch, dx, scratch + 2);
+    hipLaunchKernelGGL(normalize_bwd_finish, dim3(1), dim3(256), 0, ST, scratch + 2, np, scratch);
+    hipLaunchKernelGGL(normalize_bwd_stage2, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, ST, x, (int64_t)n * 3,
+                       scratch, 1.0f / (3.0f * (float)n), dx);
+    FGC_CHECK_LAUNCH("fgc_normalize_bwd");
+    return FGC_OK;
+}
+
+extern "C" int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns,
+                                    float* loss_out, void* stream) {
+    FGC_CHECK_ARG(fn && gt && sample_ind && loss_out && ns > 0, "fgc_angular_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(angular_loss_fwd_kernel, dim3(1), dim3(256), 0, ST, fn, gt, sample_ind, ns, loss_out);
+    FGC_CHECK_LAUNCH("fgc_angular_loss_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_angular_loss_bwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns, int32_t n,
+                                    const float* loss_out, float dloss, float* dfn, void* stream) {
+    FGC_CHECK_ARG(fn && gt && sample_ind && loss_out && dfn && ns > 0 && n > 0, "fgc_angular_loss_bwd: bad arguments");
+    if (hipMemsetAsync(dfn, 0, (size_t)n * 3 * sizeof(float), ST) != hipSuccess) {
+        fgc::set_error("fgc_angular_loss_bwd: memset failed");
+        return FGC_EHIP;
+    }
+    hipLaunchKernelGGL(angular_loss_bwd_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ST, fn, gt, sample_ind, ns, loss_out,
+                       dloss, dfn);
+    FGC_CHECK_LAUNCH("fgc_angular_loss_bwd");
+    return FGC_OK;
+}
+
+extern "C" int fgc_rotate_rows(const float* x, float* y, int32_t n, int32_t vecs, const float* R_h, void* stream) {
+    FGC_CHECK_ARG(x && y && R_h && n > 0 && vecs > 0, "fgc_rotate_rows: bad arguments");
+    Rot R;
+    for (int i = 0; i < 9; ++i) R.r[i] = R_h[i];
+    const int64_t nvec = (int64_t)n * vecs;
+    hipLaunchKernelGGL(rotate_rows_kernel, dim3(ew_grid(nvec)), dim3(EW_THREADS), 0, ST, x, y, nvec, R);
+    FGC_CHECK_LAUNCH("fgc_rotate_rows");
+    return FGC_OK;
+}
+
+extern "C" int fgc_adam_step(float* p, const float* g, float* m, float* v, int64_t count, int32_t t, float lr,
+                             float b1, float b2, float eps, void* stream) {
+    FGC_CHECK_ARG(p && g && m && v && count > 0 && t >= 1, "fgc_adam_step: bad arguments");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, ST, p, g, m, v, count, (float)lr_t, b1, b2,
+                       eps);
+    FGC_CHECK_LAUNCH("fgc_adam_step");
+    return FGC_OK;
+}
+
+extern "C" int fgc_infer_epilogue(const float* n_conv, const int32_t* perm, int32_t num_faces, float* out,
+                                  void* stream) {
+    FGC_CHECK_ARG(n_conv && perm && out && num_faces > 0, "fgc_infer_epilogue: bad arguments");
+    hipLaunchKernelGGL(infer_epilogue_kernel, dim3(ew_grid(num_faces)), dim3(EW_THREADS), 0, ST, n_conv, perm, num_faces,
+                       out);
+    FGC_CHECK_LAUNCH("fgc_infer_epilogue");
+    return FGC_OK;
+}
+
+extern "C" int fgc_gather_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst,
+                               void* stream) {
+    FGC_CHECK_ARG(src && idx && dst && count >= 0 && c > 0, "fgc_gather_rows: bad arguments");
+    if (!count) return FGC_OK;
+    const int64_t cnt = (int64_t)count * c;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, src, idx, cnt, c, dst);
+    FGC_CHECK_LAUNCH("fgc_gather_rows");
+    return FGC_OK;
+}
+extern "C" int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst,
+                                    void* stream) {
+    FGC_CHECK_ARG(src && idx && dst && count >= 0 && c > 0, "fgc_scatter_add_rows: bad arguments");
+    if (!count) return FGC_OK;
+    const int64_t cnt = (int64_t)count * c;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, src, idx, cnt, c, dst);
+    FGC_CHECK_LAUNCH("fgc_scatter_add_rows");
+    return FGC_OK;
+}

@@ -1,0 +1,449 @@
+// Per-facet MLP cin -> hidden -> cout (replaces lrelu(custom_lin(x,1024)) -> custom_lin(.,3),
+// /root/reference/Code/model.py:763-769,937-941).  The [n, hidden] activation never leaves the CU:
+// each wave produces 16-column slabs of it with f32 MFMA, applies bias + leaky ReLU in the
+// accumulator layout and folds them straight into the tiny second layer on the VALU.
+#include "fgc_common.h"
+
+namespace fgc {
+
+constexpr int MLP_T = 64;          // rows per tile
+constexpr int MLP_RT = MLP_T / 16;
+constexpr int MLP_COUT_MAX = 4;
+constexpr int MLP_THREADS = 256;
+
+// W1 [cin, hidden] -> Wp1[k/4][hidden][k%4], k padded to a multiple of 16 with zeros
+__global__ void mlp_pack_kernel(const float* __restrict__ W1, float* __restrict__ Wp, int cin, int kpad, int hidden) {
+    const size_t total = (size_t)kpad * hidden;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        const size_t v4 = idx >> 2;
+        const int col = v4 % hidden;
+        const int k = (int)(v4 / hidden) * 4 + e;
+        Wp[idx] = k < cin ? W1[(size_t)k * hidden + col] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int n, int cin, int kpad, int xs, int row0,
+                                            float* xt) {
+    // xt [MLP_T][xs]; zero padded rows / channels
+    for (int t = threadIdx.x; t < MLP_T * kpad; t += MLP_THREADS) {
+        const int r = t / kpad, c = t % kpad;
+        const int row = row0 + r;
+        xt[r * xs + c] = (row < n && c < cin) ? x[(size_t)row * cin + c] : 0.f;
+    }
+}
+
+// hidden pre-activation slab for column tile ct: h[rt] (C layout: col = lane&15, row = rt*16 + (lane>>4)*4 + reg)
+__device__ __forceinline__ void hidden_slab(const float* xt, int xs, int kg, const f32x4* __restrict__ Wp4, int hidden,
+                                            int ct, f32x4 (&h)[MLP_RT]) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < MLP_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < kg; ++g) {
+        const f32x4 b = Wp4[(size_t)(g * 4 + lq) * hidden + ct * 16 + lr];
+#pragma unroll
+        for (int r = 0; r < MLP_RT; ++r) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xt + (r * 16 + lr) * xs + g * 16 + lq * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], h[r], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __restrict__ x, int n, int cin, int kpad,
+                                                              int hidden, int cout, const float* __restrict__ Wp,
+                                                              const float* __restrict__ b1,
+                                                              const float* __restrict__ W2,
+                                                              const float* __restrict__ b2, float alpha,
+                                                              float* __restrict__ y, float* __restrict__ abs_partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int xs = kpad + 8;  // == 8 mod 16
+    float* xt = reinterpret_cast<float*>(smem_raw);
+    float* ypart = xt + MLP_T * xs;  // [4 waves][MLP_T][4]
+    float* red = ypart + 4 * MLP_T * 4;  // [4]
+    const int row0 = blockIdx.x * MLP_T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    load_x_tile(x, n, cin, kpad, xs, row0, xt);
+    __syncthreads();
+
+    const int kg = kpad >> 4;
+    const int nct = hidden >> 4;
+    const f32x4* Wp4 = reinterpret_cast<const f32x4*>(Wp);
+    float yp[MLP_RT][4][MLP_COUT_MAX];
+#pragma unroll
+    for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < MLP_COUT_MAX; ++o) yp[r][t][o] = 0.f;
+
+    for (int ct = wave; ct < nct; ct += 4) {
+        f32x4 h[MLP_RT];
+        hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
+        const int col = ct * 16 + lr;
+        const float bb = b1[col];
+        float w2[MLP_COUT_MAX];
+#pragma unroll
+        for (int o = 0; o < MLP_COUT_MAX; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
+#pragma unroll
+        for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = h[r][t] + bb;
+                v = fmaxf(v, 0.f) - alpha * fmaxf(-v, 0.f);
+#pragma unroll
+                for (int o = 0; o < MLP_COUT_MAX; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
+            }
+    }
+    // reduce over the 16 column lanes
+#pragma unroll
+    for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < MLP_COUT_MAX; ++o) {
+                float v = yp[r][t][o];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                yp[r][t][o] = v;
+            }
+    if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int o = 0; o < MLP_COUT_MAX; ++o)
+                    ypart[(wave * MLP_T + r * 16 + lq * 4 + t) * 4 + o] = yp[r][t][o];
+    }
+    __syncthreads();
+    float asum = 0.f;
+    for (int t = threadIdx.x; t < MLP_T * cout; t += MLP_THREADS) {
+        const int r = t / cout, o = t % cout;
+        const int row = row0 + r;
+        if (row < n) {
+            float v = b2[o];
+            v += ypart[(0 * MLP_T + r) * 4 + o];
+            v += ypart[(1 * MLP_T + r) * 4 + o];
+            v += ypart[(2 * MLP_T + r) * 4 + o];
+            v += ypart[(3 * MLP_T + r) * 4 + o];
+            y[(size_t)row * cout + o] = v;
+            asum += fabsf(v);
+        }
+    }
+    if (abs_partial) {
+        // deterministic block reduction: wave shuffle then 4 partials in fixed order
+        for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off);
+        if (lane == 0) red[wave] = asum;
+        __syncthreads();
+        if (threadIdx.x == 0) abs_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: persistent workgroups; hidden is recomputed, never stored.
+//   dhid = (dy W2^T) * lrelu'(h);  dW2 = hact^T dy;  db1 = sum dhid;  dW1 = x^T dhid;  dx = dhid W1^T
+// Each workgroup owns the hidden-column range [hc0, hc0+hcw) (blockIdx.y) and walks row tiles
+// blockIdx.x, +gridDim.x, ...; parameter-gradient partials stay in registers over the walk and are
+// written once per workgroup as slabs (reduced in fixed order by reduce_slabs_kernel).
+// ---------------------------------------------------------------------------------------------
+constexpr int MLP_BWD_CTW = 4;   // column tiles per wave per workgroup (hcw = 4 waves * 4 * 16 = 256 columns)
+constexpr int MLP_BWD_MT = 2;    // cin tiles of 16 (cin <= 32)
+
+__global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, int n, int cin, int kpad, int hidden, int cout,
+    const float* __restrict__ Wp, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, float alpha, float* __restrict__ dx_slab /* [gridDim.y][n][cin] */,
+    float* __restrict__ dW1_slab /* [gridDim.x][cin][hidden] */, float* __restrict__ db1_slab /* [gridDim.x][hidden] */,
+    float* __restrict__ dW2_slab /* [gridDim.x][hidden][4] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int xs = kpad + 8;
+    float* xt = reinterpret_cast<float*>(smem_raw);                // [MLP_T][xs]
+    float* dyt = xt + MLP_T * xs;                                   // [MLP_T][4]
+    float* dht = dyt + MLP_T * 4;                                   // [4 waves][MLP_T][24]  (stride 24 == 8 mod 16)
+    float* dxp = dht + 4 * MLP_T * 24;                              // [4 waves][MLP_T][kpad+1]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int kg = kpad >> 4;
+    const f32x4* Wp4 = reinterpret_cast<const f32x4*>(Wp);
+    const int hc0 = blockIdx.y * (4 * MLP_BWD_CTW * 16);
+    const int ntiles = (n + MLP_T - 1) / MLP_T;
+
+    f32x4 dW1acc[MLP_BWD_CTW][MLP_BWD_MT];
+    float dW2acc[MLP_BWD_CTW][MLP_COUT_MAX];
+    float db1acc[MLP_BWD_CTW];
+#pragma unroll
+    for (int c = 0; c < MLP_BWD_CTW; ++c) {
+        db1acc[c] = 0.f;
+#pragma unroll
+        for (int o = 0; o < MLP_COUT_MAX; ++o) dW2acc[c][o] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MLP_BWD_MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * MLP_T;
+        __syncthreads();
+        load_x_tile(x, n, cin, kpad, xs, row0, xt);
+        for (int t = threadIdx.x; t < MLP_T * 4; t += MLP_THREADS) {
+            const int r = t >> 2, o = t & 3;
+            dyt[t] = (row0 + r < n && o < cout) ? dy[(size_t)(row0 + r) * cout + o] : 0.f;
+        }
+        __syncthreads();
+        f32x4 dxacc[MLP_RT][MLP_BWD_MT];
+#pragma unroll
+        for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+            for (int m = 0; m < MLP_BWD_MT; ++m) dxacc[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int c = 0; c < MLP_BWD_CTW; ++c) {
+            const int ct = (hc0 >> 4) + wave * MLP_BWD_CTW + c;
+            const int col = ct * 16 + lr;
+            f32x4 h[MLP_RT];
+            hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
+            const float bb = b1[col];
+            float w2[MLP_COUT_MAX];
+#pragma unroll
+            for (int o = 0; o < MLP_COUT_MAX; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
+            f32x4 dh[MLP_RT];
+#pragma unroll
+            for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = r * 16 + lq * 4 + t;
+                    const f32x4 dyr = *reinterpret_cast<const f32x4*>(dyt + rr * 4);
+                    const float pre = h[r][t] + bb;
+                    const float hact = fmaxf(pre, 0.f) - alpha * fmaxf(-pre, 0.f);
+                    // d lrelu: relu'(pre) + alpha*relu'(-pre), both 0 at pre == 0 (TF relu gradient)
+                    const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
+                    float g = 0.f;
+#pragma unroll
+                    for (int o = 0; o < MLP_COUT_MAX; ++o) {
+                        g = fmaf(dyr[o], w2[o], g);
+                        dW2acc[c][o] = fmaf(hact, dyr[o], dW2acc[c][o]);
+                    }
+                    g *= slope;
+                    dh[r][t] = g;
+                    db1acc[c] += g;
+                }
+            // dW1[cin tile m][col] += sum_rows x[row][cm] * dh[row][col]  (K = rows; dh regs are the B fragment)
+#pragma unroll
+            for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = r * 16 + lq * 4 + t;
+#pragma unroll
+                    for (int m = 0; m < MLP_BWD_MT; ++m) {
+                        const float a = xt[rr * xs + m * 16 + lr];
+                        dW1acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dh[r][t], dW1acc[c][m], 0, 0, 0);
+                    }
+                }
+            // dx += dh[T x 16] * W1^T[16 x cin]: transpose dh through LDS into the A-fragment layout
+            float* dhw = dht + wave * MLP_T * 24;
+#pragma unroll
+            for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dhw[(r * 16 + lq * 4 + t) * 24 + lr] = dh[r][t];
+            // same wave wrote and reads: LDS ops of one wave are ordered; the compiler inserts the lgkmcnt wait
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int m = 0; m < MLP_BWD_MT; ++m) {
+                const int cc = m * 16 + lr;
+                f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cc < cin) b = *reinterpret_cast<const f32x4*>(W1 + (size_t)cc * hidden + ct * 16 + lq * 4);
+#pragma unroll
+                for (int r = 0; r < MLP_RT; ++r) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(dhw + (r * 16 + lr) * 24 + lq * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        dxacc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], dxacc[r][m], 0, 0, 0);
+                }
+            }
+        }
+        // reduce dx over the 4 waves (fixed order) and write this hidden-range's slab
+        const int dxs = kpad + 1;
+        float* dxw = dxp + wave * MLP_T * dxs;
+#pragma unroll
+        for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+            for (int m = 0; m < MLP_BWD_MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dxw[(r * 16 + lq * 4 + t) * dxs + m * 16 + lr] = dxacc[r][m][t];
+        __syncthreads();
+        for (int t = threadIdx.x; t < MLP_T * cin; t += MLP_THREADS) {
+            const int r = t / cin, c = t % cin;
+            if (row0 + r < n) {
+                const float v = (dxp[(0 * MLP_T + r) * dxs + c] + dxp[(1 * MLP_T + r) * dxs + c]) +
+                                (dxp[(2 * MLP_T + r) * dxs + c] + dxp[(3 * MLP_T + r) * dxs + c]);
+                dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = v;
+            }
+        }
+    }
+    // parameter-gradient slabs of this workgroup
+#pragma unroll
+    for (int c = 0; c < MLP_BWD_CTW; ++c) {
+        const int ct = (hc0 >> 4) + wave * MLP_BWD_CTW + c;
+        const int col = ct * 16 + lr;
+        // dW1acc C layout: column = lane&15 (hidden col), row = lq*4 + t (cin index within tile m)
+#pragma unroll
+        for (int m = 0; m < MLP_BWD_MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cc = m * 16 + lq * 4 + t;
+                if (cc < cin) dW1_slab[((size_t)blockIdx.x * cin + cc) * hidden + col] = dW1acc[c][m][t];
+            }
+        // dW2 / db1: rows were split over the 4 lane quarters
+        float v = db1acc[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) db1_slab[(size_t)blockIdx.x * hidden + col] = v;
+#pragma unroll
+        for (int o = 0; o < MLP_COUT_MAX; ++o) {
+            float w = dW2acc[c][o];
+            w += __shfl_xor(w, 16);
+            w += __shfl_xor(w, 32);
+            if (lq == 0) dW2_slab[((size_t)blockIdx.x * hidden + col) * 4 + o] = w;
+        }
+    }
+}
+
+// out[j] = sum_s slab[s][j] (fixed order), optional column remap: out index j -> (j / in_ld) * out_ld + j % in_ld for
+// j % in_ld < out_ld
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nslabs, size_t count, int in_ld, int out_ld,
+                                    float* __restrict__ out) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(j % in_ld);
+        if (c >= out_ld) continue;
+        float v = 0.f;
+        for (int s = 0; s < nslabs; ++s) v += slab[(size_t)s * count + j];
+        out[(j / in_ld) * out_ld + c] = v;
+    }
+}
+
+// column sums of a [rows, c] matrix in two deterministic stages
+__global__ void colsum_stage1_kernel(const float* __restrict__ a, int rows, int c, int rows_per_block,
+                                     float* __restrict__ part /* [gridDim.x][c] */) {
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    for (int col = threadIdx.x; col < c; col += blockDim.x) {
+        float v = 0.f;
+        for (int r = r0; r < r1; ++r) v += a[(size_t)r * c + col];
+        part[(size_t)blockIdx.x * c + col] = v;
+    }
+}
+
+}  // namespace fgc
+
+using namespace fgc;
+
+static int mlp_kpad(int cin) { return (cin + 15) / 16 * 16; }
+static int mlp_bwd_gx(int n) {
+    const int ntiles = cdiv(n, MLP_T);
+    return ntiles < 128 ? ntiles : 128;
+}
+
+extern "C" int32_t fgc_mlp_num_partials(int32_t n) { return cdiv(n, MLP_T); }
+
+extern "C" size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout) {
+    // packed W1 + backward slabs (sized for the worst case n-independent parts; dx slabs are sized by the caller's n
+    // through fgc_mlp_bwd_workspace_bytes below)
+    (void)cout;
+    return align_up((size_t)mlp_kpad(cin) * hidden * sizeof(float), 256);
+}
+
+extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout) {
+    (void)cout;
+    const size_t gx = mlp_bwd_gx(n), gy = hidden / 256;
+    size_t b = align_up((size_t)mlp_kpad(cin) * hidden * 4, 256);
+    b += align_up(gy * (size_t)n * cin * 4, 256);          // dx slabs
+    b += align_up(gx * (size_t)cin * hidden * 4, 256);     // dW1 slabs
+    b += align_up(gx * (size_t)hidden * 4, 256);           // db1 slabs
+    b += align_up(gx * (size_t)hidden * 4 * 4, 256);       // dW2 slabs
+    b += align_up((size_t)1024 * 4 * 4, 256);              // db2 partials
+    return b;
+}
+
+extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
+                           const float* b1, const float* W2, const float* b2, float alpha, float* y,
+                           float* abs_partial, void* workspace, size_t workspace_bytes, void* stream) {
+    FGC_CHECK_ARG(x && W1 && b1 && W2 && b2 && y, "fgc_mlp_fwd: null pointer");
+    FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 128, "fgc_mlp_fwd: n=%d cin=%d (cin must be in [1,128])", n, cin);
+    FGC_CHECK_ARG(hidden > 0 && hidden % 64 == 0, "fgc_mlp_fwd: hidden=%d must be a multiple of 64", hidden);
+    FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_fwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
+    FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_workspace_bytes(cin, hidden, cout),
+                  "fgc_mlp_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int kpad = mlp_kpad(cin);
+    float* Wp = (float*)workspace;
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, st, W1, Wp, cin, kpad, hidden);
+    FGC_CHECK_LAUNCH("fgc_mlp_fwd/pack");
+    const size_t smem = (size_t)(MLP_T * (kpad + 8) + 4 * MLP_T * 4 + 4) * 4;
+    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, st, x, n, cin, kpad, hidden, cout,
+                       Wp, b1, W2, b2, alpha, y, abs_partial);
+    FGC_CHECK_LAUNCH("fgc_mlp_fwd");
+    return FGC_OK;
+}
+
+extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
+                           const float* W1, const float* b1, const float* W2, float alpha, float* dx, float* dW1,
+                           float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    FGC_CHECK_ARG(x && dy && W1 && b1 && W2 && dx && dW1 && db1 && dW2 && db2, "fgc_mlp_bwd: null pointer");
+    FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 16 * MLP_BWD_MT, "fgc_mlp_bwd: cin=%d must be in [1,%d]", cin,
+                  16 * MLP_BWD_MT);
+    FGC_CHECK_ARG(hidden > 0 && hidden % 256 == 0, "fgc_mlp_bwd: hidden=%d must be a multiple of 256", hidden);
+    FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_bwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
+    FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout),
+                  "fgc_mlp_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+                  fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));
+    hipStream_t st = (hipStream_t)stream;
+    const int kpad = mlp_kpad(cin);
+    const int gx = mlp_bwd_gx(n), gy = hidden / 256;
+    char* w = (char*)workspace;
+    float* Wp = (float*)w;
+    w += align_up((size_t)kpad * hidden * 4, 256);
+    float* dx_slab = (float*)w;
+    w += align_up((size_t)gy * n * cin * 4, 256);
+    float* dW1_slab = (float*)w;
+    w += align_up((size_t)gx * cin * hidden * 4, 256);
+    float* db1_slab = (float*)w;
+    w += align_up((size_t)gx * hidden * 4, 256);
+    float* dW2_slab = (float*)w;
+    w += align_up((size_t)gx * hidden * 4 * 4, 256);
+    float* db2_part = (float*)w;
+
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, st, W1, Wp, cin, kpad, hidden);
+    FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
+    const size_t smem = (size_t)(MLP_T * (kpad + 8) + MLP_T * 4 + 4 * MLP_T * 24 + 4 * MLP_T * (kpad + 1)) * 4;
+    hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(gx, gy), dim3(MLP_THREADS), smem, st, x, dy, n, cin, kpad, hidden, cout, Wp,
+                       W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);
+    FGC_CHECK_LAUNCH("fgc_mlp_bwd");
+    // fixed-order reductions
+    {
+        const size_t cnt = (size_t)n * cin;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, dx_slab, gy, cnt, cin, cin,
+                           dx);
+    }
+    {
+        const size_t cnt = (size_t)cin * hidden;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, dW1_slab, gx, cnt, hidden,
+                           hidden, dW1);
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(hidden, 256)), dim3(256), 0, st, db1_slab, gx, (size_t)hidden,
+                       hidden, hidden, db1);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(hidden * 4, 256)), dim3(256), 0, st, dW2_slab, gx,
+                       (size_t)hidden * 4, 4, cout, dW2);
+    // db2 = column sums of dy
+    {
+        const int nb = n < 1024 * 64 ? cdiv(n, 64) : 1024;
+        const int rpb = cdiv(n, nb);
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nb), dim3(64), 0, st, dy, n, cout, rpb, db2_part);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(64), 0, st, db2_part, nb, (size_t)cout, cout, cout, db2);
+    }
+    FGC_CHECK_LAUNCH("fgc_mlp_bwd/reduce");
+    return FGC_OK;
+}

@@ -78,3 +78,208 @@ def conv_fwd(graph, x0, x1, shift, params, bias_mask=True, act=0, alpha=0.1, wan
     yp = torch.empty(graph.n // 4, d.cout, dtype=torch.float32, device=dev) if want_pool else None
     check(L.fgc_conv_fwd(C.byref(d), ptr(ag), ptr(y), ptr(yp), ptr(ws), ws.numel(), stream_ptr()), "fgc_conv_fwd")
     return y, yp, ag
+
+
+def conv_bwd(graph, x0, x1, shift, params, ag, y, dy, bias_mask=True, act=0, alpha=0.1, need_dx=True,
+             dx0=None, dx1=None, acc0=False, acc1=False):
+    """Gradient of conv_fwd.  Returns (dx0, dx1, [dW0, db, du, dc, dv]).
+
+    dx0/dx1 may be passed in (with acc flags) so that a tensor consumed by two layers
+    accumulates both contributions in a fixed order; otherwise they are allocated.
+    """
+    _req_cuda(x0, x1, dy, *params)
+    x0, x1, dy = _f32c(x0), _f32c(x1), _f32c(dy)
+    y = _f32c(y)
+    params = [_f32c(p) for p in params]
+    d = make_conv_desc(graph, x0, x1, shift, params, bias_mask, act, alpha)
+    L = _lib.lib()
+    dev = x0.device
+    n, cout = graph.n, d.cout
+    trow, tcol, tedge = graph.transposed()
+    f32 = dict(dtype=torch.float32, device=dev)
+    ds = torch.empty(n, cout, **f32)
+    dl = torch.empty(max(graph.nnz, 1), DL_LD, **f32)
+    dag = torch.empty(n, AG_LD, **f32)
+    r = torch.empty(n, FGC_M * cout, **f32)
+    grads = [torch.empty_like(p) for p in params]
+    if need_dx:
+        if dx0 is None:
+            dx0 = torch.empty_like(x0)
+            acc0 = False
+        if x1 is not None and dx1 is None:
+            dx1 = torch.empty_like(x1)
+            acc1 = False
+    else:
+        dx0 = dx1 = None
+    io = ConvBwdIO()
+    io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
+    io.ag, io.y, io.dy = ag.data_ptr(), (y.data_ptr() if y is not None else None), dy.data_ptr()
+    io.ds, io.dl, io.dag, io.r = ds.data_ptr(), dl.data_ptr(), dag.data_ptr(), r.data_ptr()
+    io.dx0 = dx0.data_ptr() if dx0 is not None else None
+    io.dx1 = dx1.data_ptr() if dx1 is not None else None
+    io.accumulate0, io.accumulate1 = int(bool(acc0)), int(bool(acc1))
+    io.dW0, io.db, io.du, io.dc, io.dv = [g.data_ptr() for g in grads]
+    ws_bytes = L.fgc_conv_bwd_workspace_bytes(C.byref(d))
+    ws = _workspace(ws_bytes, dev, "bwd")
+    check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "fgc_conv_bwd")
+    return dx0, dx1, grads
+
+
+def mlp_fwd(x, W1, b1, W2, b2, alpha=0.1, want_abs_partial=False):
+    _req_cuda(x, W1, b1, W2, b2)
+    x, W1, b1, W2, b2 = map(_f32c, (x, W1, b1, W2, b2))
+    n, cin = x.shape
+    hidden, cout = W2.shape
+    L = _lib.lib()
+    ws = _workspace(L.fgc_mlp_workspace_bytes(cin, hidden, cout), x.device)
+    y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
+    part = torch.empty(L.fgc_mlp_num_partials(n), dtype=torch.float32, device=x.device) if want_abs_partial else None
+    check(L.fgc_mlp_fwd(ptr(x), n, cin, hidden, cout, ptr(W1), ptr(b1), ptr(W2), ptr(b2), alpha, ptr(y), ptr(part),
+                        ptr(ws), ws.numel(), stream_ptr()), "fgc_mlp_fwd")
+    return (y, part) if want_abs_partial else y
+
+
+def mlp_bwd(x, dy, W1, b1, W2, alpha=0.1):
+    _req_cuda(x, dy, W1, b1, W2)
+    x, dy, W1, b1, W2 = map(_f32c, (x, dy, W1, b1, W2))
+    n, cin = x.shape
+    hidden, cout = W2.shape
+    L = _lib.lib()
+    ws = _workspace(L.fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout), x.device, "bwd")
+    dx = torch.empty_like(x)
+    dW1, db1, dW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
+    db2 = torch.empty(cout, dtype=torch.float32, device=x.device)
+    check(L.fgc_mlp_bwd(ptr(x), ptr(dy), n, cin, hidden, cout, ptr(W1), ptr(b1), ptr(W2), alpha, ptr(dx), ptr(dW1),
+                        ptr(db1), ptr(dW2), ptr(db2), ptr(ws), ws.numel(), stream_ptr()), "fgc_mlp_bwd")
+    return dx, dW1, db1, dW2, db2
+
+
+def lrelu_fwd(x, alpha):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().fgc_lrelu_fwd(ptr(x), ptr(y), x.numel(), alpha, stream_ptr()), "fgc_lrelu_fwd")
+    return y
+
+
+def lrelu_bwd(y, dy, alpha):
+    y, dy = _f32c(y), _f32c(dy)
+    dx = torch.empty_like(y)
+    check(_lib.lib().fgc_lrelu_bwd(ptr(y), ptr(dy), ptr(dx), y.numel(), alpha, stream_ptr()), "fgc_lrelu_bwd")
+    return dx
+
+
+def pool4_fwd(x):
+    x = _f32c(x)
+    n, c = x.shape
+    if n % 4:
+        raise ValueError("pooling needs a multiple of 4 rows, got %d" % n)
+    y = torch.empty(n // 4, c, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_pool4_fwd(ptr(x), ptr(y), n // 4, c, stream_ptr()), "fgc_pool4_fwd")
+    return y
+
+
+def pool4_bwd(x, y, dy, dx=None, accumulate=False):
+    x, y, dy = _f32c(x), _f32c(y), _f32c(dy)
+    if dx is None:
+        dx = torch.empty_like(x)
+        accumulate = False
+    check(_lib.lib().fgc_pool4_bwd(ptr(x), ptr(y), ptr(dy), ptr(dx), y.shape[0], y.shape[1], int(accumulate),
+                                   stream_ptr()), "fgc_pool4_bwd")
+    return dx
+
+
+def upsample4_fwd(x):
+    x = _f32c(x)
+    n, c = x.shape
+    y = torch.empty(n * 4, c, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_upsample4_fwd(ptr(x), ptr(y), n, c, stream_ptr()), "fgc_upsample4_fwd")
+    return y
+
+
+def upsample4_bwd(dy, dx=None, accumulate=False):
+    dy = _f32c(dy)
+    n4, c = dy.shape
+    if dx is None:
+        dx = torch.empty(n4 // 4, c, dtype=torch.float32, device=dy.device)
+        accumulate = False
+    check(_lib.lib().fgc_upsample4_bwd(ptr(dy), ptr(dx), n4 // 4, c, int(accumulate), stream_ptr()),
+          "fgc_upsample4_bwd")
+    return dx
+
+
+def normalize_fwd(x, abs_partial=None):
+    """normalizeTensor on [n,3]; returns (y, scratch) - scratch feeds normalize_bwd."""
+    x = _f32c(x)
+    n = x.shape[0]
+    L = _lib.lib()
+    scratch = torch.empty(2 + L.fgc_norm_num_partials(n), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    npart = abs_partial.numel() if abs_partial is not None else 0
+    check(L.fgc_normalize_fwd(ptr(x), n, ptr(abs_partial), npart, ptr(y), ptr(scratch), stream_ptr()),
+          "fgc_normalize_fwd")
+    return y, scratch
+
+
+def normalize_bwd(x, dy, scratch):
+    x, dy = _f32c(x), _f32c(dy)
+    dx = torch.empty_like(x)
+    check(_lib.lib().fgc_normalize_bwd(ptr(x), ptr(dy), x.shape[0], ptr(dx), ptr(scratch), stream_ptr()),
+          "fgc_normalize_bwd")
+    return dx
+
+
+def angular_loss_fwd(fn, gt, sample_ind):
+    fn, gt = _f32c(fn), _f32c(gt)
+    out = torch.empty(2, dtype=torch.float32, device=fn.device)
+    check(_lib.lib().fgc_angular_loss_fwd(ptr(fn), ptr(gt), ptr(sample_ind), sample_ind.numel(), ptr(out),
+                                          stream_ptr()), "fgc_angular_loss_fwd")
+    return out
+
+
+def angular_loss_bwd(fn, gt, sample_ind, loss_out, dloss=1.0):
+    fn, gt = _f32c(fn), _f32c(gt)
+    dfn = torch.empty_like(fn)
+    check(_lib.lib().fgc_angular_loss_bwd(ptr(fn), ptr(gt), ptr(sample_ind), sample_ind.numel(), fn.shape[0],
+                                          ptr(loss_out), float(dloss), ptr(dfn), stream_ptr()),
+          "fgc_angular_loss_bwd")
+    return dfn
+
+
+def rotate_rows(x, R):
+    """Every 3-vector of every row times R^T (train.py:439-451).  R: 3x3 array-like on the host."""
+    x = _f32c(x)
+    n, c = x.shape
+    if c % 3:
+        raise ValueError("channels must be a multiple of 3")
+    Rh = np.ascontiguousarray(np.asarray(R, dtype=np.float32).reshape(9))
+    y = torch.empty_like(x)
+    check(_lib.lib().fgc_rotate_rows(ptr(x), ptr(y), n, c // 3, Rh.ctypes.data, stream_ptr()), "fgc_rotate_rows")
+    return y
+
+
+def adam_step(p, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    check(_lib.lib().fgc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), int(t), lr, b1, b2, eps,
+                                   stream_ptr()), "fgc_adam_step")
+
+
+def infer_epilogue(n_conv, perm, num_faces):
+    n_conv = _f32c(n_conv)
+    out = torch.empty(num_faces, 3, dtype=torch.float32, device=n_conv.device)
+    check(_lib.lib().fgc_infer_epilogue(ptr(n_conv), ptr(perm), num_faces, ptr(out), stream_ptr()),
+          "fgc_infer_epilogue")
+    return out
+
+
+def gather_rows(src, idx):
+    src = _f32c(src)
+    dst = torch.empty(idx.numel(), src.shape[1], dtype=torch.float32, device=src.device)
+    check(_lib.lib().fgc_gather_rows(ptr(src), ptr(idx), idx.numel(), src.shape[1], ptr(dst), stream_ptr()),
+          "fgc_gather_rows")
+    return dst
+
+
+def scatter_add_rows(src, idx, dst):
+    src = _f32c(src)
+    check(_lib.lib().fgc_scatter_add_rows(ptr(src), ptr(idx), idx.numel(), src.shape[1], ptr(dst), stream_ptr()),
+          "fgc_scatter_add_rows")
+    return dst

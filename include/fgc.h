@@ -103,7 +103,7 @@ int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* y_pool, voi
  * (y itself is passed to recover the leaky-ReLU mask).  Scratch the caller provides:
  *   ds   [n, cout]           dy * lrelu'(y) / deg
  *   dl   [nnz, FGC_DL_LD]    per-edge d(logit)
- *   dag  [(n >> shift), FGC_AG_LD]   d a | d g per source row
+ *   dag  [n, FGC_AG_LD]      d a (0..8) | d g (12..20) per node of this level
  *   r    [n, M*cout]         backward-side aggregate (feeds the dW reduction)
  * Outputs: dW0,db,du,dc,dv (overwritten); dx0/dx1 [(n >> shift), c0/c1] either overwritten
  * (accumulate = 0) or added to (accumulate = 1); dx pointers may be NULL (conv1: no input grad). */
@@ -141,6 +141,7 @@ int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* worksp
  * ---------------------------------------------------------------------------------- */
 int32_t fgc_mlp_num_partials(int32_t n);
 size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout);
+size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout);
 int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
                 const float* b1, const float* W2, const float* b2, float alpha, float* y, float* abs_partial,
                 void* workspace, size_t workspace_bytes, void* stream);

@@ -34,3 +34,114 @@ def test_conv_forward_matches_golden(golden_dir, case):
     print("%s: |gpu-f64| %.3e  |ref32-f64| %.3e  |gpu-ref32| %.3e" % (case, err_gpu, err_ref, np.abs(got - ref32).max()))
     # fp32 tolerance: both fp32 evaluations must sit within 2e-6 of the float64 result
     assert err_gpu < 2e-6
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward_matches_golden(golden_dir, case):
+    """All six gradients of custom_conv2d against autograd through the reference source."""
+    from facet_graph_convolution_amd import ops
+    from facet_graph_convolution_amd.graph import FacetGraph
+    z = np.load(os.path.join(golden_dir, "conv_%s.npz" % case))
+    z64 = np.load(os.path.join(golden_dir, "conv_%s_f64.npz" % case))
+    dev = torch.device("cuda:0")
+    x = torch.tensor(z["x"][0], device=dev)
+    g = FacetGraph(z["adj"], dev)
+    params = _params(x.shape[1], int(z["cout"]), int(z["seed"]), dev)
+    mask = case != "rand_nomask"
+    y, _, ag = ops.conv_fwd(g, x, None, 0, params, bias_mask=mask)
+    dy = torch.tensor(z["dy"][0], device=dev)
+    dx, _, grads = ops.conv_bwd(g, x, None, 0, params, ag, y, dy, bias_mask=mask)
+    torch.cuda.synchronize()
+    for key, got in zip(["dW0", "db", "du", "dc", "dv", "dx"], grads + [dx]):
+        got = got.cpu().numpy()
+        ref32 = z[key].reshape(got.shape)
+        ref64 = z64[key].reshape(got.shape)
+        scale = max(1.0, np.abs(ref64).max())
+        e_gpu = np.abs(got - ref64).max() / scale
+        e_ref = np.abs(ref32 - ref64).max() / scale
+        print("%s %-3s |gpu-f64| %.2e |ref32-f64| %.2e (scale %.1f)" % (case, key, e_gpu, e_ref, scale))
+        # gradients: relative to the tensor's max magnitude, within 5e-6 of the float64 gradient
+        assert e_gpu < 5e-6, key
+
+
+def test_conv_concat_upsample_and_pool_match_oracle():
+    """The fused addressing modes (two-source concat, 4x upsampled input, fused activation + pooling) against
+    the oracle's materialised tf.concat / custom_upsampling / lrelu / custom_binary_tree_pooling."""
+    from facet_graph_convolution_amd import ops
+    from facet_graph_convolution_amd.graph import FacetGraph
+    from oracle import model_ref as R
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(5)
+    n = 96
+    adj = np.zeros((n, 23), dtype=np.int32)
+    for i in range(n):
+        d = rs.randint(1, 14)
+        adj[i, 0] = i + 1
+        adj[i, 1:1 + d] = rs.randint(1, n + 1, size=d)
+    g = FacetGraph(adj, dev)
+    xa = torch.tensor(rs.normal(size=(n, 32)).astype(np.float32))
+    xb = torch.tensor(rs.normal(size=(n, 32)).astype(np.float32))
+    xc = torch.tensor(rs.normal(size=(n // 4, 64)).astype(np.float32))
+    adj_t = torch.tensor(adj[None])
+    # concat
+    p = R.conv_params(64, 32, 3)
+    ref = R.lrelu(R.custom_conv2d(torch.cat([xa, xb], 1)[None], adj_t, p))
+    ref_pool = R.custom_binary_tree_pooling(ref, 2)
+    y, yp, _ = ops.conv_fwd(g, xa.to(dev), xb.to(dev), 0, [t.to(dev) for t in p], act=1, alpha=0.1, want_pool=True)
+    np.testing.assert_allclose(y.cpu().numpy(), ref[0].numpy(), atol=2e-6)
+    np.testing.assert_allclose(yp.cpu().numpy(), ref_pool[0].numpy(), atol=2e-6)
+    # upsampled single source
+    p = R.conv_params(64, 32, 4)
+    ref = R.custom_conv2d(R.custom_upsampling(xc[None], 2), adj_t, p)
+    y, _, _ = ops.conv_fwd(g, xc.to(dev), None, 2, [t.to(dev) for t in p])
+    np.testing.assert_allclose(y.cpu().numpy(), ref[0].numpy(), atol=2e-6)
+
+
+def _oracle_conv_grads(x_list, shift, adj, params, dy, act):
+    from oracle import model_ref as R
+    xs = [t.clone().requires_grad_(True) for t in x_list]
+    ps = [t.clone().requires_grad_(True) for t in params]
+    xin = torch.cat(xs, 1)[None]
+    if shift:
+        xin = R.custom_upsampling(xin, 2)
+    y = R.custom_conv2d(xin, torch.tensor(adj[None]), ps)
+    if act:
+        y = R.lrelu(y)
+    (y[0] * dy).sum().backward()
+    return [t.grad for t in xs], [t.grad for t in ps]
+
+
+@pytest.mark.parametrize("mode", ["concat", "upsample"])
+def test_conv_backward_fused_addressing_matches_oracle(mode):
+    from facet_graph_convolution_amd import ops
+    from facet_graph_convolution_amd.graph import FacetGraph
+    from oracle import model_ref as R
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(9)
+    n = 128
+    adj = np.zeros((n, 23), dtype=np.int32)
+    for i in range(n):
+        d = rs.randint(0, 12)
+        adj[i, 0] = i + 1
+        adj[i, 1:1 + d] = rs.randint(1, n + 1, size=d)
+    g = FacetGraph(adj, dev)
+    if mode == "concat":
+        xs = [torch.tensor(rs.normal(size=(n, 64)).astype(np.float32)) for _ in range(2)]
+        shift, cin, cout = 0, 128, 64
+    else:
+        xs = [torch.tensor(rs.normal(size=(n // 4, 128)).astype(np.float32))]
+        shift, cin, cout = 2, 128, 64
+    p = R.conv_params(cin, cout, 21)
+    dy = torch.tensor(rs.normal(size=(n, cout)).astype(np.float32))
+    gx_ref, gp_ref = _oracle_conv_grads(xs, shift, adj, p, dy, act=True)
+    xd = [t.to(dev) for t in xs]
+    pd = [t.to(dev) for t in p]
+    y, _, ag = ops.conv_fwd(g, xd[0], xd[1] if len(xd) > 1 else None, shift, pd, act=1, alpha=0.1)
+    dx0, dx1, grads = ops.conv_bwd(g, xd[0], xd[1] if len(xd) > 1 else None, shift, pd, ag, y, dy.to(dev), act=1,
+                                   alpha=0.1)
+    got_x = [dx0] + ([dx1] if dx1 is not None else [])
+    for a, b in zip(got_x, gx_ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=5e-6 * max(1.0, b.abs().max().item()))
+    for a, b, name in zip(grads, gp_ref, ["dW0", "db", "du", "dc", "dv"]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=5e-6 * max(1.0, b.abs().max().item()),
+                                   err_msg=name)

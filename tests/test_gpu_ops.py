@@ -1,0 +1,137 @@
+"""GPU parity of the MLP and the element-wise / reduction ops against the oracle (torch fp32/fp64 on CPU)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.tensor(np.asarray(a, dtype=np.float32))
+
+
+@pytest.mark.parametrize("n,cin", [(1000, 32), (77, 32), (300, 64), (130, 128)])
+def test_mlp_forward(n, cin):
+    from facet_graph_convolution_amd import ops
+    from oracle import model_ref as R
+    rs = np.random.RandomState(n)
+    x = _t(rs.normal(size=(n, cin)))
+    W1, b1 = _t(rs.normal(0, 0.05, (cin, 1024))), _t(rs.normal(0, 0.01, 1024))
+    W2, b2 = _t(rs.normal(0, 0.05, (1024, 3))), _t(rs.normal(0, 0.01, 3))
+    ref = R.custom_lin(R.lrelu(R.custom_lin(x.double(), W1.double(), b1.double())), W2.double(), b2.double())
+    y, part = ops.mlp_fwd(x.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), 0.1, want_abs_partial=True)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=3e-6)
+    assert abs(part.sum().item() - ref.abs().sum().item()) < 1e-4 * ref.abs().sum().item()
+
+
+@pytest.mark.parametrize("n", [1000, 77, 5000])
+def test_mlp_backward(n):
+    from facet_graph_convolution_amd import ops
+    from oracle import model_ref as R
+    rs = np.random.RandomState(n + 1)
+    cin = 32
+    x = _t(rs.normal(size=(n, cin))).double().requires_grad_(True)
+    ps = [_t(rs.normal(0, 0.05, (cin, 1024))), _t(rs.normal(0, 0.01, 1024)), _t(rs.normal(0, 0.05, (1024, 3))),
+          _t(rs.normal(0, 0.01, 3))]
+    pd = [p.double().requires_grad_(True) for p in ps]
+    dy = _t(rs.normal(size=(n, 3)))
+    y = R.custom_lin(R.lrelu(R.custom_lin(x, pd[0], pd[1])), pd[2], pd[3])
+    (y * dy.double()).sum().backward()
+    dx, dW1, db1, dW2, db2 = ops.mlp_bwd(x.detach().float().to(DEV), dy.to(DEV), ps[0].to(DEV), ps[1].to(DEV),
+                                         ps[2].to(DEV), 0.1)
+    for got, ref, name in [(dx, x.grad, "dx"), (dW1, pd[0].grad, "dW1"), (db1, pd[1].grad, "db1"),
+                           (dW2, pd[2].grad, "dW2"), (db2, pd[3].grad, "db2")]:
+        scale = max(1.0, ref.abs().max().item())
+        err = (got.cpu().double() - ref).abs().max().item() / scale
+        assert err < 5e-6, (name, err)
+
+
+def test_elementwise_ops():
+    from facet_graph_convolution_amd import ops
+    from oracle import model_ref as R
+    rs = np.random.RandomState(0)
+    x = _t(rs.normal(size=(64, 48)))
+    x[3, 5] = 0.0
+    xd = x.to(DEV)
+    y = ops.lrelu_fwd(xd, 0.1)
+    assert torch.equal(y.cpu(), R.lrelu(x, 0.1))
+    dy = _t(rs.normal(size=(64, 48)))
+    xr = x.clone().requires_grad_(True)
+    (R.lrelu(xr, 0.1) * dy).sum().backward()
+    assert torch.equal(ops.lrelu_bwd(y, dy.to(DEV), 0.1).cpu(), xr.grad)
+    # pooling with ties (fake rows produce identical values)
+    x[8:12] = x[8]
+    x[16:18] = x[16]
+    xd = x.to(DEV)
+    p = ops.pool4_fwd(xd)
+    assert torch.equal(p.cpu(), R.custom_binary_tree_pooling(x[None], 2)[0])
+    xr = x.clone().requires_grad_(True)
+    dp = _t(rs.normal(size=(16, 48)))
+    (R.custom_binary_tree_pooling(xr[None], 2)[0] * dp).sum().backward()
+    np.testing.assert_allclose(ops.pool4_bwd(xd, p, dp.to(DEV)).cpu().numpy(), xr.grad.numpy(), atol=1e-7)
+    u = ops.upsample4_fwd(p)
+    assert torch.equal(u.cpu(), R.custom_upsampling(p.cpu()[None], 2)[0])
+    du = _t(rs.normal(size=(64, 48)))
+    np.testing.assert_allclose(ops.upsample4_bwd(du.to(DEV)).cpu().numpy(),
+                               du.reshape(16, 4, 48).sum(1).numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [100, 5000])
+def test_normalize_and_loss(n):
+    from facet_graph_convolution_amd import ops
+    from oracle import model_ref as R
+    rs = np.random.RandomState(n)
+    x = _t(rs.normal(size=(n, 3)) * 0.3)
+    x[7] = 0.0  # zero row -> inv = 0 branch
+    gt = _t(rs.normal(size=(n, 3)))
+    gt = gt / gt.norm(dim=1, keepdim=True)
+    gt[5] = 0.0  # fake row
+    idx = torch.tensor(rs.randint(n, size=4000).astype(np.int32))
+    xr = x.double().requires_grad_(True)
+    nref = R.normalizeTensor(xr[None])
+    loss_ref = R.faceNormalsLoss(nref[:, idx.long()], gt.double()[None][:, idx.long()])
+    loss_ref.backward()
+    xd, gtd, idxd = x.to(DEV), gt.to(DEV), idx.to(DEV)
+    y, scratch = ops.normalize_fwd(xd)
+    np.testing.assert_allclose(y.cpu().numpy(), nref[0].detach().numpy(), atol=2e-6)
+    out = ops.angular_loss_fwd(y, gtd, idxd)
+    assert abs(out[0].item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+    dfn = ops.angular_loss_bwd(y, gtd, idxd, out, 1.0)
+    dx = ops.normalize_bwd(xd, dfn, scratch)
+    ref = xr.grad.numpy()
+    np.testing.assert_allclose(dx.cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max())
+
+
+def test_rotate_adam_epilogue_gather():
+    from facet_graph_convolution_amd import ops
+    from oracle import model_ref as R
+    rs = np.random.RandomState(3)
+    x = _t(rs.normal(size=(50, 6)))
+    Rm = _t(np.linalg.qr(rs.normal(size=(3, 3)))[0])
+    xr, _ = R.rotate_inputs(x[None], None, Rm)
+    np.testing.assert_allclose(ops.rotate_rows(x.to(DEV), Rm.numpy()).cpu().numpy(), xr[0].numpy(), atol=1e-6)
+    # Adam, three steps
+    p = _t(rs.normal(size=1000))
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    pr, mr, vr = [p.clone().double()], [m.clone().double()], [v.clone().double()]
+    for t in range(1, 4):
+        g = _t(rs.normal(size=1000))
+        ops.adam_step(pd, g.to(DEV), md, vd, t)
+        R.adam_step_tf1(pr, [g.double()], mr, vr, t)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr[0].numpy(), atol=1e-6)
+    # inference epilogue
+    nc = _t(rs.normal(size=(40, 3)))
+    perm = rs.permutation(40).astype(np.int32)
+    ref = R.infer_epilogue(nc[None], perm, 30)
+    got = ops.infer_epilogue(nc.to(DEV), torch.tensor(perm).to(DEV), 30)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-6)
+    # halo pack/unpack
+    src = _t(rs.normal(size=(40, 8))).to(DEV)
+    idx = torch.tensor(rs.permutation(40)[:10].astype(np.int32)).to(DEV)
+    gathered = ops.gather_rows(src, idx)
+    assert torch.equal(gathered, src[idx.long()])
+    dst = torch.zeros(40, 8, device=DEV)
+    ops.scatter_add_rows(gathered, idx, dst)
+    assert torch.equal(dst[idx.long()], gathered)
