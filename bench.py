@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the facet-graph-convolution hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of the reference's loop body (train.py:558-575,619) on one
+synthetic mesh: random rotation of inputs and ground truth, full 3-level graph U-Net + MLP forward,
+normalisation, angular loss on 4000 sampled rows, full backward, TF1-Adam update.  fp32 throughout.
+
+Workload (BASELINE.json configs[1]): torus 250 x 200 quads = 100 000 facets,
+preprocessed natively (adjacency + 4 pairing levels + binary-tree order) before the timed region;
+everything is resident in HBM when the clock starts.
+
+N > 1: one process per GPU (torchrun), each rank trains on its own 100k-facet mesh (different noise
+seed) and the flat fp32 gradient (1.9 MB) is averaged with ONE RCCL all-reduce per step ("weak" scaling).
+The single-mesh facet-sharded path with per-layer halo exchange is not built yet.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel's achieved TFLOP/s from hipEvent timings taken live in this process
+  cpu_baseline  the oracle (reference-shaped torch CPU restatement) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def build_mesh(nu, nv, seed):
+    from facet_graph_convolution_amd.meshgen import torus, add_noise
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    V, F = torus(nu, nv)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F, 0.2, seed=1 + seed), F, V, seed=seed)
+    return ds, F.shape[0]
+
+
+def kernel_flops(kind, n, nnz, cin, cout, M=9):
+    """Algorithmic FLOPs of one launch: the dense contraction 2*n*M*cin*cout plus the per-edge
+    aggregation 2*nnz*M*C (C = gathered width)."""
+    gemm = 2.0 * n * M * cin * cout
+    if kind == "fwd":          # gathers cin-wide rows
+        return gemm + 2.0 * nnz * M * cin
+    if kind == "bwd_logits":   # dz GEMM + per-edge dots over cin
+        return gemm + 2.0 * nnz * M * cin
+    if kind == "bwd_data":     # gathers cout-wide rows of s
+        return gemm + 2.0 * nnz * M * cout
+    if kind == "bwd_weight":   # r^T x
+        return gemm
+    raise ValueError(kind)
+
+
+def algorithmic_bytes_fwd_bwd(net):
+    """SURVEY.md §8d convention: each tensor crossing a layer boundary written once, read once per consumer;
+    CSR read once per conv; weights and fused ops free.  Backward moves the same tensors as gradients plus
+    the saved activations again (x2.45 of forward in the survey's accounting: 3879/1584)."""
+    dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net.layer_dims()}
+    n0, n1, n2 = dims["conv1"][0], dims["conv2"][0], dims["conv3"][0]
+    d0, d1, d2 = (dims[k][1] / dims[k][0] for k in ("conv1", "conv2", "conv3"))
+    fwd = 4 * (n0 * (6 + 32 + 1 + d0) + n1 * (32 + 64 + 1 + d1) + n2 * (64 + 128 + 1 + d2) +
+               n2 * (128 + 128 + 1 + d2) + n1 * (32 + 64 + 1 + d1) + n1 * (128 + 64 + 1 + d1) +
+               n0 * (16 + 32 + 1 + d0) + n0 * (64 + 32 + 1 + d0) + n0 * (32 + 3) + n1 * 32 + n2 * 64)
+    return fwd, fwd * 3879.0 / 1584.0
+
+
+def cpu_baseline(sample_faces=(100, 100)):
+    """The oracle timed on this host: one forward+backward of the reference-shaped torch-CPU restatement on a
+    20 000-facet torus (the reference's own patch size, settings.py:20), all host threads."""
+    import torch
+    from oracle import model_ref as R
+    ds, F = build_mesh(sample_faces[0], sample_faces[1], seed=7)
+    x = torch.tensor(ds.in_list[0].astype(np.float32))
+    gt = torch.tensor(ds.gt_list[0].astype(np.float32))
+    adjs = [torch.tensor(a.astype(np.int32)) for a in ds.adj_list[0]]
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    params = [p.requires_grad_(True) for p in R.init_params(0)]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = torch.eye(3)
+    t0 = time.time()
+    loss, _ = R.train_loss(x, adjs, gt, params, samp, Rm)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": F / dt, "unit": "facets/s", "cores": threads, "kind": "port",
+            "sample": "oracle/model_ref.py (reference-shaped K-padded torch CPU fp32), 1 forward+backward of the "
+                      "full net on a torus 100x100 = %d facets (N0=%d), %.1f s" % (F, x.shape[1], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nu", type=int, default=250)
+    ap.add_argument("--nv", type=int, default=200)
+    ap.add_argument("--graph", type=int, default=1, help="replay the forward+backward enqueue as one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
+                         (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+
+    ds, F = build_mesh(args.nu, args.nv, seed=rank)
+    net = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+    n0 = ds.in_list[0].shape[1]
+    rs = np.random.RandomState(100 + rank)
+
+    def step():
+        net.set_samples(rs.randint(n0, size=4000))
+        net.set_rotation(rand_rotation_matrix(randnums=rs.uniform(size=3)))
+        net.forward_backward(rotate=True, capture=bool(args.graph))
+        if world > 1:
+            dist.all_reduce(net.params.grad, op=dist.ReduceOp.AVG)
+        net.adam_step()
+
+    def sync_barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = net.buffers["loss"][0].item()
+
+    # forward-only rate (BASELINE config 2 wording), untimed extra
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(max(3, args.steps // 2)):
+        net.forward(rotate=False)
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3
+
+    roofline = None
+    kernels = {}
+    if not args.no_roofline:
+        # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
+        # `steps` eager steps of the same work as the timed region
+        net.profile_start()
+        for _ in range(args.steps):
+            net.set_samples(rs.randint(n0, size=4000))
+            net.forward_backward(rotate=True, capture=False)
+            net.adam_step()
+        prof = net.profile_stop()
+        dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net.layer_dims()}
+        total_ms = sum(ms for _, ms in prof.values())
+        rows = []
+        for key, (cnt, ms) in prof.items():
+            tag, kern = key.split("/", 1)
+            phase, layer = (tag.split(":") + [""])[:2]
+            kind = None
+            if layer in dims:
+                if "conv_fwd_kernel" in kern:
+                    kind = "fwd"
+                elif "conv_bwd_logits_kernel" in kern:
+                    kind = "bwd_logits"
+                elif "conv_bwd_data_kernel" in kern:
+                    kind = "bwd_data"
+                elif "gemm_tn_kernel" in kern and cnt == args.steps * 2:
+                    kind = None  # two launches share this name (dW0 and du/dv); flops attributed below per step
+            avg_us = ms / cnt * 1e3
+            fl = kernel_flops(kind, *dims[layer]) if kind else None
+            rows.append((ms, key, cnt, avg_us, fl))
+        rows.sort(reverse=True)
+        for ms, key, cnt, avg_us, fl in rows[:12]:
+            kernels[key] = {"launches": cnt, "avg_us": round(avg_us, 2), "share": round(ms / total_ms, 4),
+                            "tflops": round(fl / (avg_us * 1e-6) / 1e12, 2) if fl else None}
+        dom = next((r for r in rows if r[4]), None)
+        if dom:
+            ms, key, cnt, avg_us, fl = dom
+            ach = fl / (avg_us * 1e-6) / 1e12
+            roofline = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_kernel_us": round(avg_us, 2), "launch_flops": fl,
+                        "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3)}
+
+    fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        out = {
+            "metric": "facets/sec (fwd+bwd) on 100k-facet mesh",
+            "value": world * F * args.steps / dt,
+            "unit": "facets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "torus %dx%d quads = %d facets per GPU (N0=%d padded nodes), full graph U-Net + MLP: "
+                                   "rotate + forward + angular loss + backward + Adam, fp32%s" %
+                                   (args.nu, args.nv, F, n0, ", hipGraph replay" if args.graph else ""),
+                       "parallelism": "1 mesh per GPU, flat-gradient all-reduce" if world > 1 else "single GPU"},
+            "loss_deg": loss,
+            "forward_only_ms": fwd_ms,
+            "forward_only_facets_per_s": F / (fwd_ms * 1e-3),
+            "hbm_roofline_frac_whole_step": fb_b / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),
+            "algorithmic_bytes_fwd_bwd": fb_b,
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

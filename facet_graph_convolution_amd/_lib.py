@@ -45,9 +45,24 @@ class ConvBwdIO(C.Structure):
 _SIGS = {
     "fgc_last_error": (C.c_char_p, []),
     "fgc_version": (C.c_int, []),
+    "fgc_profile_enable": (C.c_int, [C.c_int]),
+    "fgc_profile_tag": (C.c_int, [C.c_char_p]),
+    "fgc_profile_collect": (C.c_int, [C.c_char_p, C.c_int32]),
     "fgc_csr_from_klist": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgc_klist_from_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "fgc_csr_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_face_features": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_faces_large_adj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_metis_one_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_hierarchy_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_hierarchy_free": (None, [C.c_void_p]),
+    "fgc_hierarchy_size": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "fgc_hierarchy_real_size": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "fgc_hierarchy_new_to_old": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "fgc_hierarchy_parents": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "fgc_hierarchy_klist": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "fgc_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "fgc_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_void_p]),

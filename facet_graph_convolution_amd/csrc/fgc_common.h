@@ -28,6 +28,27 @@ void set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// ---- optional per-kernel timing (fgc_profile_*): hipEvents around every launch, off by default ----
+bool prof_enabled();
+void prof_begin(const char* name, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfScope(const char* name, hipStream_t s) : st(s), on(prof_enabled()) {
+        if (on) prof_begin(name, st);
+    }
+    ~ProfScope() {
+        if (on) prof_end(st);
+    }
+};
+// launch with timing scope: FGC_LAUNCH("name", stream, kernel, grid, block, smem, args...)
+#define FGC_LAUNCH(name, st, kernel, grid, block, smem, ...)                      \
+    do {                                                                          \
+        fgc::ProfScope prof__(name, st);                                          \
+        hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);           \
+    } while (0)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

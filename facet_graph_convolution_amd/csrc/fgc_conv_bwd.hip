@@ -555,11 +555,11 @@ static int launch_logits(const CoreParams& p, const LogitParams& lp, bool vec4, 
     if (vec4) {
         hipFuncSetAttribute((const void*)conv_bwd_logits_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-        hipLaunchKernelGGL((conv_bwd_logits_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, st, p, lp);
+        FGC_LAUNCH("conv_bwd_logits_kernel<LPN, true>", st, (conv_bwd_logits_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, p, lp);
     } else {
         hipFuncSetAttribute((const void*)conv_bwd_logits_kernel<LPN, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-        hipLaunchKernelGGL((conv_bwd_logits_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, st, p, lp);
+        FGC_LAUNCH("conv_bwd_logits_kernel<LPN, false>", st, (conv_bwd_logits_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, p, lp);
     }
     FGC_CHECK_LAUNCH("fgc_conv_bwd/logits");
     return FGC_OK;
@@ -571,11 +571,11 @@ static int launch_data(const CoreParams& p, const DataEpilogue& ep, bool vec4, s
     if (vec4) {
         hipFuncSetAttribute((const void*)conv_bwd_data_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-        hipLaunchKernelGGL((conv_bwd_data_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, st, p, ep);
+        FGC_LAUNCH("conv_bwd_data_kernel<LPN, true>", st, (conv_bwd_data_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, p, ep);
     } else {
         hipFuncSetAttribute((const void*)conv_bwd_data_kernel<LPN, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-        hipLaunchKernelGGL((conv_bwd_data_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, st, p, ep);
+        FGC_LAUNCH("conv_bwd_data_kernel<LPN, false>", st, (conv_bwd_data_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, p, ep);
     }
     FGC_CHECK_LAUNCH("fgc_conv_bwd/data");
     return FGC_OK;
@@ -604,18 +604,18 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const int ostride = opad + 8;
 
     // s = dy*lrelu'(y)/deg, db partials
-    hipLaunchKernelGGL(ds_db_kernel, dim3(w.nb_db), dim3(128), 0, st, io->dy, io->y, d->rowptr, d->n, cout, d->act,
+    FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(128), 0, io->dy, io->y, d->rowptr, d->n, cout, d->act,
                        d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(128), 0, st, w.db_part, w.nb_db, (size_t)cout, cout, cout,
+    FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(1), dim3(128), 0, w.db_part, w.nb_db, (size_t)cout, cout, cout,
                        io->db);
     FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");
     // operand packing
     {
         const size_t tot = (size_t)g1.passes * opad * g1.kpass;
-        hipLaunchKernelGGL(pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, st, d->W0, w.Wq, cin, cout,
+        FGC_LAUNCH("pack_logit_weight_kernel", st, pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, d->W0, w.Wq, cin, cout,
                            opad, g1.kc, g1.kpass, g1.passes);
         const size_t tot2 = (size_t)g2.passes * g2.kpass * g2.npad;
-        hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv((int)tot2, 1024)), dim3(256), 0, st, d->W0, w.Wpt, cin, cout, cout,
+        FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot2, 1024)), dim3(256), 0, d->W0, w.Wpt, cin, cout, cout,
                            cin, g2.npad, g2.kc, g2.kpass, g2.passes, 1);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
     }
@@ -633,7 +633,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             default: rc = launch_logits<8>(p, lp, vec4, smem, st); break;
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(64), 0, st, w.dc_part, cdiv(d->n, TILE), (size_t)12, 12,
+        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(1), dim3(64), 0, w.dc_part, cdiv(d->n, TILE), (size_t)12, 12,
                            FGC_M, io->dc);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/dc");
     }
@@ -658,10 +658,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const int P = FGC_M * cout;
         const int rps = cdiv(cdiv(d->n, w.splitW), 16) * 16;
         const int ns = cdiv(d->n, rps);
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(P, 64), ns), dim3(256), 0, st, io->r, P, P, d->x0, d->x1, d->c0,
+        FGC_LAUNCH("gemm_tn_kernel", st, gemm_tn_kernel, dim3(cdiv(P, 64), ns), dim3(256), 0, io->r, P, P, d->x0, d->x1, d->c0,
                            d->c1, d->shift, d->n, rps, w.slab);
         const size_t cnt = (size_t)P * cin;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, w.slab, ns, cnt, cin, cin,
+        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, w.slab, ns, cnt, cin, cin,
                            io->dW0);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
     }
@@ -669,10 +669,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     {
         const int rps = cdiv(cdiv(d->n, w.splitUV), 16) * 16;
         const int ns = cdiv(d->n, rps);
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(1, ns), dim3(256), 0, st, io->dag, FGC_AG_LD, 24, d->x0, d->x1, d->c0,
+        FGC_LAUNCH("gemm_tn_kernel", st, gemm_tn_kernel, dim3(1, ns), dim3(256), 0, io->dag, FGC_AG_LD, 24, d->x0, d->x1, d->c0,
                            d->c1, d->shift, d->n, rps, w.slab);
         const size_t cnt = (size_t)24 * cin;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, w.slab, ns, cnt, cin, cin,
+        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, w.slab, ns, cnt, cin, cin,
                            w.duv);
         if (hipMemcpyAsync(io->du, w.duv, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
             hipMemcpyAsync(io->dv, w.duv + (size_t)12 * cin, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) !=

@@ -248,11 +248,11 @@ static int launch_fwd(const CoreParams& p, const FwdEpilogue& ep, bool vec4, siz
     if (vec4) {
         hipFuncSetAttribute((const void*)conv_fwd_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-        hipLaunchKernelGGL((conv_fwd_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, st, p, ep);
+        FGC_LAUNCH("conv_fwd_kernel<LPN, true>", st, (conv_fwd_kernel<LPN, true>), dim3(grid), dim3(NTHREADS), smem, p, ep);
     } else {
         hipFuncSetAttribute((const void*)conv_fwd_kernel<LPN, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
-        hipLaunchKernelGGL((conv_fwd_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, st, p, ep);
+        FGC_LAUNCH("conv_fwd_kernel<LPN, false>", st, (conv_fwd_kernel<LPN, false>), dim3(grid), dim3(NTHREADS), smem, p, ep);
     }
     FGC_CHECK_LAUNCH("fgc_conv_fwd");
     return FGC_OK;
@@ -273,11 +273,11 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     float* Wp = (float*)workspace;
 
     const size_t tot = packed_floats(g);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, st, d->W0, Wp, cin, d->cout,
+    FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, d->W0, Wp, cin, d->cout,
                        cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
     FGC_CHECK_LAUNCH("fgc_conv_fwd/pack");
     const int rows = d->n >> d->shift;
-    hipLaunchKernelGGL(proj_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, d->x0, d->x1, d->c0, d->c1, rows, d->u,
+    FGC_LAUNCH("proj_kernel", st, proj_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, d->x0, d->x1, d->c0, d->c1, rows, d->u,
                        d->c, d->v, ag);
     FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
 

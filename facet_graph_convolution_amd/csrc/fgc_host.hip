@@ -1,6 +1,7 @@
 // Host-side pieces of libfgc: error text, K-list <-> CSR, transposed CSR.
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "fgc_common.h"
@@ -14,6 +15,82 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 }  // namespace fgc
+
+// ---- per-kernel timing -------------------------------------------------------------------
+namespace fgc {
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+static char g_tag[48] = "";
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static hipEvent_t g_cur_start;
+static const char* g_cur_name;
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(const char* name, hipStream_t st) {
+    hipEventCreate(&g_cur_start);
+    hipEventRecord(g_cur_start, st);
+    g_cur_name = name;
+}
+void prof_end(hipStream_t st) {
+    ProfRec r;
+    r.name = std::string(g_tag) + "/" + g_cur_name;
+    r.a = g_cur_start;
+    hipEventCreate(&r.b);
+    hipEventRecord(r.b, st);
+    g_prof.push_back(r);
+}
+}  // namespace fgc
+
+// label prepended to the kernel names recorded from now on (e.g. the layer being run)
+extern "C" int fgc_profile_tag(const char* tag) {
+    snprintf(fgc::g_tag, sizeof(fgc::g_tag), "%s", tag ? tag : "");
+    return FGC_OK;
+}
+extern "C" int fgc_profile_enable(int on) {
+    fgc::g_prof_on = on != 0;
+    return FGC_OK;
+}
+// Synchronises, then writes "name count total_ms\n" lines (aggregated per kernel name) into buf and clears the
+// recorded events.  Returns the number of bytes written (excluding the terminator), or a negative error.
+extern "C" int fgc_profile_collect(char* buf, int32_t buf_bytes) {
+    FGC_CHECK_ARG(buf && buf_bytes > 0, "fgc_profile_collect: bad buffer");
+    struct Agg {
+        std::string name;
+        int count;
+        double ms;
+    };
+    std::vector<Agg> agg;
+    for (auto& r : fgc::g_prof) {
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+        bool found = false;
+        for (auto& a : agg)
+            if (a.name == r.name) {
+                a.count++;
+                a.ms += ms;
+                found = true;
+                break;
+            }
+        if (!found) agg.push_back({r.name, 1, (double)ms});
+    }
+    fgc::g_prof.clear();
+    int off = 0;
+    buf[0] = 0;
+    for (auto& a : agg) {
+        std::string nm = a.name;
+        for (auto& ch : nm)
+            if (ch == ' ') ch = '_';
+        const int w = snprintf(buf + off, buf_bytes - off, "%s %d %.6f\n", nm.c_str(), a.count, a.ms);
+        if (w < 0 || w >= buf_bytes - off) break;
+        off += w;
+    }
+    return off;
+}
 
 extern "C" const char* fgc_last_error(void) { return fgc::g_err; }
 extern "C" int fgc_version(void) { return 100; }

@@ -230,15 +230,16 @@ __global__ void angular_loss_bwd_kernel(const float* __restrict__ fn, const floa
 }
 
 // ---- rotation augmentation (train.py:439-451) ---------------------------------------------------
-struct Rot {
+__global__ void rotate_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t nvec,
+                                   const float* __restrict__ Rd) {
     float r[9];
-};
-__global__ void rotate_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t nvec, Rot R) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = Rd[i];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
-        y[3 * i] = R.r[0] * a + R.r[1] * b + R.r[2] * c;
-        y[3 * i + 1] = R.r[3] * a + R.r[4] * b + R.r[5] * c;
-        y[3 * i + 2] = R.r[6] * a + R.r[7] * b + R.r[8] * c;
+        y[3 * i] = r[0] * a + r[1] * b + r[2] * c;
+        y[3 * i + 1] = r[3] * a + r[4] * b + r[5] * c;
+        y[3 * i + 2] = r[6] * a + r[7] * b + r[8] * c;
     }
 }
 
@@ -299,21 +300,21 @@ using namespace fgc;
 extern "C" int fgc_lrelu_fwd(const float* x, float* y, int64_t count, float alpha, void* stream) {
     FGC_CHECK_ARG(x && y && count >= 0, "fgc_lrelu_fwd: bad arguments");
     if (!count) return FGC_OK;
-    hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, ST, x, y, count, alpha);
+    FGC_LAUNCH("lrelu_fwd_kernel", ST, lrelu_fwd_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, x, y, count, alpha);
     FGC_CHECK_LAUNCH("fgc_lrelu_fwd");
     return FGC_OK;
 }
 extern "C" int fgc_lrelu_bwd(const float* y, const float* dy, float* dx, int64_t count, float alpha, void* stream) {
     FGC_CHECK_ARG(y && dy && dx && count >= 0, "fgc_lrelu_bwd: bad arguments");
     if (!count) return FGC_OK;
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, ST, y, dy, dx, count, alpha);
+    FGC_LAUNCH("lrelu_bwd_kernel", ST, lrelu_bwd_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, y, dy, dx, count, alpha);
     FGC_CHECK_LAUNCH("fgc_lrelu_bwd");
     return FGC_OK;
 }
 extern "C" int fgc_pool4_fwd(const float* x, float* y, int32_t n_out, int32_t c, void* stream) {
     FGC_CHECK_ARG(x && y && n_out > 0 && c > 0, "fgc_pool4_fwd: bad arguments");
     const int64_t cnt = (int64_t)n_out * c;
-    hipLaunchKernelGGL(pool4_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, x, y, cnt, c);
+    FGC_LAUNCH("pool4_fwd_kernel", ST, pool4_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, cnt, c);
     FGC_CHECK_LAUNCH("fgc_pool4_fwd");
     return FGC_OK;
 }
@@ -321,14 +322,14 @@ extern "C" int fgc_pool4_bwd(const float* x, const float* y, const float* dy, fl
                              int32_t accumulate, void* stream) {
     FGC_CHECK_ARG(x && y && dy && dx && n_out > 0 && c > 0, "fgc_pool4_bwd: bad arguments");
     const int64_t cnt = (int64_t)n_out * c;
-    hipLaunchKernelGGL(pool4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, x, y, dy, dx, cnt, c, accumulate);
+    FGC_LAUNCH("pool4_bwd_kernel", ST, pool4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, dy, dx, cnt, c, accumulate);
     FGC_CHECK_LAUNCH("fgc_pool4_bwd");
     return FGC_OK;
 }
 extern "C" int fgc_upsample4_fwd(const float* x, float* y, int32_t n_in, int32_t c, void* stream) {
     FGC_CHECK_ARG(x && y && n_in > 0 && c > 0, "fgc_upsample4_fwd: bad arguments");
     const int64_t cnt = (int64_t)n_in * 4 * c;
-    hipLaunchKernelGGL(upsample4_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, x, y, cnt, c);
+    FGC_LAUNCH("upsample4_fwd_kernel", ST, upsample4_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, cnt, c);
     FGC_CHECK_LAUNCH("fgc_upsample4_fwd");
     return FGC_OK;
 }
@@ -336,7 +337,7 @@ extern "C" int fgc_upsample4_bwd(const float* dy, float* dx, int32_t n_in, int32
                                  void* stream) {
     FGC_CHECK_ARG(dy && dx && n_in > 0 && c > 0, "fgc_upsample4_bwd: bad arguments");
     const int64_t cnt = (int64_t)n_in * c;
-    hipLaunchKernelGGL(upsample4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, dy, dx, cnt, c, accumulate);
+    FGC_LAUNCH("upsample4_bwd_kernel", ST, upsample4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, dy, dx, cnt, c, accumulate);
     FGC_CHECK_LAUNCH("fgc_upsample4_bwd");
     return FGC_OK;
 }
@@ -348,13 +349,13 @@ extern "C" int fgc_normalize_fwd(const float* x, int32_t n, const float* abs_par
     FGC_CHECK_ARG(x && y && scratch && n > 0, "fgc_normalize_fwd: bad arguments");
     const float inv_count = 3.0f * (float)n;  // element count (the kernel divides)
     if (abs_partial && num_partials > 0) {
-        hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, ST, abs_partial, num_partials, inv_count, scratch);
+        FGC_LAUNCH("finish_mean_kernel", ST, finish_mean_kernel, dim3(1), dim3(256), 0, abs_partial, num_partials, inv_count, scratch);
     } else {
         const int np = fgc_norm_num_partials(n);
-        hipLaunchKernelGGL(abs_partial_kernel, dim3(np), dim3(256), 0, ST, x, (int64_t)n * 3, scratch + 2);
-        hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, ST, scratch + 2, np, inv_count, scratch);
+        FGC_LAUNCH("abs_partial_kernel", ST, abs_partial_kernel, dim3(np), dim3(256), 0, x, (int64_t)n * 3, scratch + 2);
+        FGC_LAUNCH("finish_mean_kernel", ST, finish_mean_kernel, dim3(1), dim3(256), 0, scratch + 2, np, inv_count, scratch);
     }
-    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, ST, x, n, scratch, y);
+    FGC_LAUNCH("normalize_fwd_kernel", ST, normalize_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, x, n, scratch, y);
     FGC_CHECK_LAUNCH("fgc_normalize_fwd");
     return FGC_OK;
 }
@@ -363,9 +364,9 @@ extern "C" int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, flo
     FGC_CHECK_ARG(x && dy && dx && scratch && n > 0, "fgc_normalize_bwd: bad arguments");
     // scratch[0] (= mean|x| + eps) is the value left by fgc_normalize_fwd on the same x
     const int np = fgc_norm_num_partials(n);
-    hipLaunchKernelGGL(normalize_bwd_stage1, dim3(np), dim3(256), 0, ST, x, dy, n, scratch, dx, scratch + 2);
-    hipLaunchKernelGGL(normalize_bwd_finish, dim3(1), dim3(256), 0, ST, scratch + 2, np, scratch);
-    hipLaunchKernelGGL(normalize_bwd_stage2, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, ST, x, (int64_t)n * 3,
+    FGC_LAUNCH("normalize_bwd_stage1", ST, normalize_bwd_stage1, dim3(np), dim3(256), 0, x, dy, n, scratch, dx, scratch + 2);
+    FGC_LAUNCH("normalize_bwd_finish", ST, normalize_bwd_finish, dim3(1), dim3(256), 0, scratch + 2, np, scratch);
+    FGC_LAUNCH("normalize_bwd_stage2", ST, normalize_bwd_stage2, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, x, (int64_t)n * 3,
                        scratch, 1.0f / (3.0f * (float)n), dx);
     FGC_CHECK_LAUNCH("fgc_normalize_bwd");
     return FGC_OK;
@@ -374,7 +375,7 @@ extern "C" int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, flo
 extern "C" int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns,
                                     float* loss_out, void* stream) {
     FGC_CHECK_ARG(fn && gt && sample_ind && loss_out && ns > 0, "fgc_angular_loss_fwd: bad arguments");
-    hipLaunchKernelGGL(angular_loss_fwd_kernel, dim3(1), dim3(256), 0, ST, fn, gt, sample_ind, ns, loss_out);
+    FGC_LAUNCH("angular_loss_fwd_kernel", ST, angular_loss_fwd_kernel, dim3(1), dim3(256), 0, fn, gt, sample_ind, ns, loss_out);
     FGC_CHECK_LAUNCH("fgc_angular_loss_fwd");
     return FGC_OK;
 }
@@ -385,18 +386,16 @@ extern "C" int fgc_angular_loss_bwd(const float* fn, const float* gt, const int3
         fgc::set_error("fgc_angular_loss_bwd: memset failed");
         return FGC_EHIP;
     }
-    hipLaunchKernelGGL(angular_loss_bwd_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, ST, fn, gt, sample_ind, ns, loss_out,
+    FGC_LAUNCH("angular_loss_bwd_kernel", ST, angular_loss_bwd_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, fn, gt, sample_ind, ns, loss_out,
                        dloss, dfn);
     FGC_CHECK_LAUNCH("fgc_angular_loss_bwd");
     return FGC_OK;
 }
 
-extern "C" int fgc_rotate_rows(const float* x, float* y, int32_t n, int32_t vecs, const float* R_h, void* stream) {
-    FGC_CHECK_ARG(x && y && R_h && n > 0 && vecs > 0, "fgc_rotate_rows: bad arguments");
-    Rot R;
-    for (int i = 0; i < 9; ++i) R.r[i] = R_h[i];
+extern "C" int fgc_rotate_rows(const float* x, float* y, int32_t n, int32_t vecs, const float* R, void* stream) {
+    FGC_CHECK_ARG(x && y && R && n > 0 && vecs > 0, "fgc_rotate_rows: bad arguments");
     const int64_t nvec = (int64_t)n * vecs;
-    hipLaunchKernelGGL(rotate_rows_kernel, dim3(ew_grid(nvec)), dim3(EW_THREADS), 0, ST, x, y, nvec, R);
+    FGC_LAUNCH("rotate_rows_kernel", ST, rotate_rows_kernel, dim3(ew_grid(nvec)), dim3(EW_THREADS), 0, x, y, nvec, R);
     FGC_CHECK_LAUNCH("fgc_rotate_rows");
     return FGC_OK;
 }
@@ -405,7 +404,7 @@ extern "C" int fgc_adam_step(float* p, const float* g, float* m, float* v, int64
                              float b1, float b2, float eps, void* stream) {
     FGC_CHECK_ARG(p && g && m && v && count > 0 && t >= 1, "fgc_adam_step: bad arguments");
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t));
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, ST, p, g, m, v, count, (float)lr_t, b1, b2,
+    FGC_LAUNCH("adam_kernel", ST, adam_kernel, dim3(ew_grid(count)), dim3(EW_THREADS), 0, p, g, m, v, count, (float)lr_t, b1, b2,
                        eps);
     FGC_CHECK_LAUNCH("fgc_adam_step");
     return FGC_OK;
@@ -414,7 +413,7 @@ extern "C" int fgc_adam_step(float* p, const float* g, float* m, float* v, int64
 extern "C" int fgc_infer_epilogue(const float* n_conv, const int32_t* perm, int32_t num_faces, float* out,
                                   void* stream) {
     FGC_CHECK_ARG(n_conv && perm && out && num_faces > 0, "fgc_infer_epilogue: bad arguments");
-    hipLaunchKernelGGL(infer_epilogue_kernel, dim3(ew_grid(num_faces)), dim3(EW_THREADS), 0, ST, n_conv, perm, num_faces,
+    FGC_LAUNCH("infer_epilogue_kernel", ST, infer_epilogue_kernel, dim3(ew_grid(num_faces)), dim3(EW_THREADS), 0, n_conv, perm, num_faces,
                        out);
     FGC_CHECK_LAUNCH("fgc_infer_epilogue");
     return FGC_OK;
@@ -425,7 +424,7 @@ extern "C" int fgc_gather_rows(const float* src, const int32_t* idx, int32_t cou
     FGC_CHECK_ARG(src && idx && dst && count >= 0 && c > 0, "fgc_gather_rows: bad arguments");
     if (!count) return FGC_OK;
     const int64_t cnt = (int64_t)count * c;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, src, idx, cnt, c, dst);
+    FGC_LAUNCH("gather_rows_kernel", ST, gather_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, src, idx, cnt, c, dst);
     FGC_CHECK_LAUNCH("fgc_gather_rows");
     return FGC_OK;
 }
@@ -434,7 +433,7 @@ extern "C" int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_
     FGC_CHECK_ARG(src && idx && dst && count >= 0 && c > 0, "fgc_scatter_add_rows: bad arguments");
     if (!count) return FGC_OK;
     const int64_t cnt = (int64_t)count * c;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, ST, src, idx, cnt, c, dst);
+    FGC_LAUNCH("scatter_add_rows_kernel", ST, scatter_add_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, src, idx, cnt, c, dst);
     FGC_CHECK_LAUNCH("fgc_scatter_add_rows");
     return FGC_OK;
 }

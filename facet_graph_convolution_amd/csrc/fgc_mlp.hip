@@ -378,10 +378,10 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
     hipStream_t st = (hipStream_t)stream;
     const int kpad = mlp_kpad(cin);
     float* Wp = (float*)workspace;
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, st, W1, Wp, cin, kpad, hidden);
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_fwd/pack");
     const size_t smem = (size_t)(MLP_T * (kpad + 8) + 4 * MLP_T * 4 + 4) * 4;
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, st, x, n, cin, kpad, hidden, cout,
+    FGC_LAUNCH("mlp_fwd_kernel", st, mlp_fwd_kernel, dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, x, n, cin, kpad, hidden, cout,
                        Wp, b1, W2, b2, alpha, y, abs_partial);
     FGC_CHECK_LAUNCH("fgc_mlp_fwd");
     return FGC_OK;
@@ -415,34 +415,34 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     w += align_up((size_t)gx * hidden * 4 * 4, 256);
     float* db2_part = (float*)w;
 
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, st, W1, Wp, cin, kpad, hidden);
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
     const size_t smem = (size_t)(MLP_T * (kpad + 8) + MLP_T * 4 + 4 * MLP_T * 24 + 4 * MLP_T * (kpad + 1)) * 4;
     hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(gx, gy), dim3(MLP_THREADS), smem, st, x, dy, n, cin, kpad, hidden, cout, Wp,
+    FGC_LAUNCH("mlp_bwd_kernel", st, mlp_bwd_kernel, dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy, n, cin, kpad, hidden, cout, Wp,
                        W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd");
     // fixed-order reductions
     {
         const size_t cnt = (size_t)n * cin;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, dx_slab, gy, cnt, cin, cin,
+        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, dx_slab, gy, cnt, cin, cin,
                            dx);
     }
     {
         const size_t cnt = (size_t)cin * hidden;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, st, dW1_slab, gx, cnt, hidden,
+        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, dW1_slab, gx, cnt, hidden,
                            hidden, dW1);
     }
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(hidden, 256)), dim3(256), 0, st, db1_slab, gx, (size_t)hidden,
+    FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv(hidden, 256)), dim3(256), 0, db1_slab, gx, (size_t)hidden,
                        hidden, hidden, db1);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(hidden * 4, 256)), dim3(256), 0, st, dW2_slab, gx,
+    FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv(hidden * 4, 256)), dim3(256), 0, dW2_slab, gx,
                        (size_t)hidden * 4, 4, cout, dW2);
     // db2 = column sums of dy
     {
         const int nb = n < 1024 * 64 ? cdiv(n, 64) : 1024;
         const int rpb = cdiv(n, nb);
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nb), dim3(64), 0, st, dy, n, cout, rpb, db2_part);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(64), 0, st, db2_part, nb, (size_t)cout, cout, cout, db2);
+        FGC_LAUNCH("colsum_stage1_kernel", st, colsum_stage1_kernel, dim3(nb), dim3(64), 0, dy, n, cout, rpb, db2_part);
+        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(1), dim3(64), 0, db2_part, nb, (size_t)cout, cout, cout, db2);
     }
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/reduce");
     return FGC_OK;

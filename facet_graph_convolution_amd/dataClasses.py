@@ -1,0 +1,99 @@
+"""The tensor contract between mesh preprocessing and the network, mirroring the reference's
+``dataClasses.py`` (PreprocessedData / TrainingSet / InferenceMesh, dataClasses.py:6-27,480-531).
+
+Same attribute names and per-mesh list layout:
+    in_list[i]      float64 [1, N0, 6]    unit normal | barycentre / bbox diagonal, fake rows all-zero
+    adj_list[i][l]  int64   [1, N_l, 23]  one-indexed K-lists of the 3 graph levels (binary-tree order)
+    gt_list[i]      float64 [1, N0, 3]    ground-truth normals (training sets)
+    num_faces[i], patch_indices[i], permutations[i] (= inv_perm(newToOld))
+
+Differences, by design: the adjacency / coarsening loops run natively (libfgc host routines) and a mesh is
+kept whole: the reference cuts meshes above MAX_PATCH_SIZE = 20 000 faces into BFS patches only because one
+TF graph could not hold more (settings.py:20-22); a 1M-facet mesh fits one MI355X many times over.  Patch
+mode is listed as a follow-up.
+"""
+import numpy as np
+
+from . import utils
+from .settings import K_faces, COARSENING_STEPS, COARSENING_LVLS, MIN_PATCH_SIZE
+
+
+class PreprocessedData(object):
+    def __init__(self, maxSize=10 ** 9, coarseningStepNum=COARSENING_STEPS, coarseningLvlNum=COARSENING_LVLS):
+        self.in_list = []
+        self.gt_list = []
+        self.adj_list = []
+        self.mesh_count = 0
+        self.num_faces = []
+        self.patch_indices = []
+        self.permutations = []
+        self.parents_list = []          # recorded cluster assignments (lets a run be replayed bit-exactly)
+        self.maxSize = maxSize
+        self.patchSize = maxSize
+        self.coarseningStepNum = coarseningStepNum
+        self.coarseningLvlNum = coarseningLvlNum
+        self.minPatchSize = MIN_PATCH_SIZE
+        self.seed = 0
+
+    def addMesh_TimeEfficient(self, V0, faces0, GTV=None, seed=None, parents=None):
+        """dataClasses.py:34-233, small-mesh branch (:172-233)."""
+        V0 = np.asarray(V0, dtype=np.float32)
+        faces0 = np.asarray(faces0)
+        facesNum = faces0.shape[0]
+        if facesNum > self.maxSize:
+            raise NotImplementedError(
+                "patch mode (dataClasses.py:76-171) is not built: meshes are processed whole on MI355X; "
+                "construct with maxSize >= number of faces")
+        f_normals0, f_pos0 = utils.face_features(V0, faces0)
+        f_adj0 = utils.getFacesLargeAdj(faces0, K_faces)
+        f_normals_pos = np.concatenate((f_normals0, f_pos0), axis=1)        # float64 [F,6] (dataClasses.py:64)
+        GTf_normals0 = utils.computeFacesNormals(GTV, faces0) if GTV is not None else None
+        old_N = facesNum
+        if self.coarseningLvlNum > 1:
+            levels = (self.coarseningLvlNum - 1) * self.coarseningStepNum
+            keep = tuple(self.coarseningStepNum * l for l in range(self.coarseningLvlNum))
+            cur_seed = self.seed if seed is None else seed
+            has_sat = True
+            while has_sat:      # dataClasses.py:179-192: re-draw the pairing while a row saturates K
+                klists, newToOld, par, has_sat = utils.coarsen_klists(f_adj0, f_pos0, f_normals0, levels, K_faces,
+                                                                      cur_seed, parents, keep)
+                if has_sat and parents is not None:
+                    raise RuntimeError("recorded cluster assignments saturate K=%d" % K_faces)
+                cur_seed += 1
+            self.seed = cur_seed
+            fAdjs = [k[np.newaxis].astype(np.int64) for k in klists]
+            new_N = len(newToOld)
+            pad6 = np.zeros((new_N - old_N, f_normals_pos.shape[1]))
+            f_normals_pos = np.concatenate((f_normals_pos, pad6), axis=0)[newToOld]
+            if GTf_normals0 is not None:
+                GTf_normals0 = np.concatenate((GTf_normals0, np.zeros((new_N - old_N, 3))), axis=0)[newToOld]
+            self.parents_list.append(par)
+        else:
+            fAdjs = [f_adj0[np.newaxis].astype(np.int64)]
+            newToOld = None
+        self.num_faces.append(old_N)
+        self.patch_indices.append([])
+        if newToOld is not None:
+            self.permutations.append(utils.inv_perm(newToOld))
+        self.in_list.append(f_normals_pos[np.newaxis])
+        self.adj_list.append(fAdjs)
+        if GTf_normals0 is not None:
+            self.gt_list.append(np.asarray(GTf_normals0, dtype=np.float64)[np.newaxis])
+        self.mesh_count += 1
+
+
+class TrainingSet(PreprocessedData):
+    """dataClasses.py:480-506 (array interface; OBJ parsing is outside the hot path)."""
+
+    def addMeshWithGT(self, V_noisy, faces, V_gt, seed=None, parents=None):
+        self.addMesh_TimeEfficient(V_noisy, faces, GTV=V_gt, seed=seed, parents=parents)
+
+
+class InferenceMesh(PreprocessedData):
+    """dataClasses.py:510-531."""
+
+    def addMesh(self, V, faces, seed=None, parents=None):
+        self.vertices = np.asarray(V, dtype=np.float32)[np.newaxis]
+        self.faces = np.asarray(faces)
+        self.addMesh_TimeEfficient(V, faces, seed=seed, parents=parents)
+        self.normals = self.in_list[0][0, :, :3]

@@ -1,0 +1,435 @@
+"""FacetDenoiser: the reference's 3-level graph U-Net + per-facet MLP, hand-scheduled on libfgc.
+
+Replaces, for one mesh / patch (batch size is 1 in the reference, train.py:405):
+  * ``get_model_reg_multi_scale``  (model.py:837-946)        -> ``forward``
+  * ``normalizeTensor``            (utils.py:1700-1715)      -> fused after the MLP
+  * the training objective         (train.py:439-451,503-520) -> ``loss_and_grad`` / ``train_step``
+  * the inference epilogue         (train.py:115-121,136)    -> ``infer_normals``
+
+Design (MI355X-first, nothing traced or compiled at run time):
+  * every activation, gradient and scratch buffer of a mesh lives in HBM for the whole run and is
+    allocated ONCE per mesh size (a 100k-facet mesh needs ~0.7 GB of 288 GB);
+  * parameters, gradients and Adam moments are three flat fp32 buffers (16-byte aligned views per
+    variable, creation order of the reference), so Adam is one kernel and a data-parallel
+    all-reduce is one RCCL call;
+  * pooling, upsampling, concat and leaky-ReLU never exist as tensors of their own: they are
+    address modes / epilogues of the conv kernels (see include/fgc.h);
+  * the backward pass is scheduled by hand in a fixed order (no autograd tape, no float atomics):
+    results are bitwise reproducible;
+  * the whole forward+backward enqueue is capturable into a hipGraph (``capture=True``).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, ConvBwdIO, AG_LD, DL_LD, FGC_M
+from .graph import FacetGraph, as_graph
+
+LRELU_ALPHA = 0.1      # model.py:846
+STD_W, STD_B = 0.05, 0.01  # model.py:17-18
+HIDDEN = 1024          # model.py:936
+COST_SAMPLES = 4000    # train.py:411
+
+
+def param_spec(multi_scale=False, in_channels=6):
+    """(kind, shape) per variable in the reference's creation order (model.py:430-433,447,767-768,855-941)."""
+    M = FGC_M
+
+    def conv(cin, cout):
+        return [("weight", (M, cout, cin)), ("bias", (cout,)), ("assignment", (M, cin)), ("assignment", (M,)),
+                ("assignment", (M, cin))]
+
+    def lin(cin, cout):
+        return [("weight", (cin, cout)), ("bias", (cout,))]
+
+    spec = conv(in_channels, 32) + conv(32, 64) + conv(64, 128) + conv(128, 128)
+    if multi_scale:
+        spec += lin(128, HIDDEN) + lin(HIDDEN, 3)
+    spec += conv(128, 64) + conv(128, 64)
+    if multi_scale:
+        spec += lin(64, HIDDEN) + lin(HIDDEN, 3)
+    spec += conv(64, 32) + conv(64, 32) + lin(32, HIDDEN) + lin(HIDDEN, 3)
+    return spec
+
+
+class FlatParams:
+    """All variables as 16-byte aligned views into one flat fp32 buffer (plus grad / Adam moment twins)."""
+
+    def __init__(self, spec, device):
+        self.spec = spec
+        self.offsets = []
+        off = 0
+        for _, shape in spec:
+            self.offsets.append(off)
+            off += (int(np.prod(shape)) + 3) // 4 * 4
+        self.total = off
+        self.device = torch.device(device)
+        self.theta = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.theta)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.step = 0
+
+    def _views(self, flat):
+        return [flat[o:o + int(np.prod(s))].view(*s) for o, (_, s) in zip(self.offsets, self.spec)]
+
+    @property
+    def values(self):
+        return self._views(self.theta)
+
+    @property
+    def grads(self):
+        return self._views(self.grad)
+
+    def init_random(self, seed=0):
+        """N(0, 0.05^2) weights/assignments, N(0, 0.01^2) biases from RandomState(seed) in creation order."""
+        rs = np.random.RandomState(seed)
+        host = np.zeros(self.total, dtype=np.float32)
+        for o, (kind, shape) in zip(self.offsets, self.spec):
+            std = STD_B if kind == "bias" else STD_W
+            host[o:o + int(np.prod(shape))] = rs.normal(0.0, std, size=shape).astype(np.float32).reshape(-1)
+        self.theta.copy_(torch.from_numpy(host))
+
+    def load(self, tensors):
+        assert len(tensors) == len(self.spec)
+        for view, t in zip(self.values, tensors):
+            view.copy_(torch.as_tensor(t, dtype=torch.float32).reshape(view.shape))
+
+    def num_parameters(self):
+        return sum(int(np.prod(s)) for _, s in self.spec)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _ConvLayer:
+    """Static description of one conv: which buffers it reads/writes and its parameter slots."""
+
+    def __init__(self, name, level, x0, x1, shift, pidx, y, pool, act):
+        self.name, self.level, self.x0, self.x1, self.shift = name, level, x0, x1, shift
+        self.pidx, self.y, self.pool, self.act = pidx, y, pool, act
+
+
+class FacetDenoiser:
+    def __init__(self, device="cuda", multi_scale=False, in_channels=6, seed=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FacetDenoiser needs an MI355X (no CPU fallback)")
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        self.multi_scale = multi_scale
+        self.in_channels = in_channels
+        self.params = FlatParams(param_spec(multi_scale, in_channels), self.device)
+        self.params.init_random(seed)
+        self._mesh = None
+        self._graph_fb = None
+        self.profile = False   # when True every enqueue is labelled for fgc_profile_collect
+        # parameter slots
+        k = 0
+        self.slot = {}
+        for name in ["conv1", "conv2", "conv3", "dconv3"]:
+            self.slot[name] = k
+            k += 5
+        if multi_scale:
+            self.slot["head2"] = k
+            k += 4
+        for name in ["upconv2", "dconv2"]:
+            self.slot[name] = k
+            k += 5
+        if multi_scale:
+            self.slot["head1"] = k
+            k += 4
+        for name in ["upconv1", "dconv1"]:
+            self.slot[name] = k
+            k += 5
+        self.slot["head0"] = k
+        self.layers = [
+            _ConvLayer("conv1", 0, "xr", None, 0, self.slot["conv1"], "h1", "p1", 1),
+            _ConvLayer("conv2", 1, "p1", None, 0, self.slot["conv2"], "h2", "p2", 1),
+            _ConvLayer("conv3", 2, "p2", None, 0, self.slot["conv3"], "h3", None, 1),
+            _ConvLayer("dconv3", 2, "h3", None, 0, self.slot["dconv3"], "d3", None, 1),
+            _ConvLayer("upconv2", 1, "d3", None, 2, self.slot["upconv2"], "u2", None, 0),
+            _ConvLayer("dconv2", 1, "u2", "h2", 0, self.slot["dconv2"], "d2", None, 1),
+            _ConvLayer("upconv1", 0, "d2", None, 2, self.slot["upconv1"], "u1", None, 0),
+            _ConvLayer("dconv1", 0, "u1", "h1", 0, self.slot["dconv1"], "d1", None, 1),
+        ]
+
+    # ------------------------------------------------------------------------------------------
+    # mesh binding: graphs + every buffer, once
+    # ------------------------------------------------------------------------------------------
+    def bind_mesh(self, x, adjs, gt=None):
+        """x: [1,N0,C] / [N0,C] features (float64 numpy as in in_list, or tensor); adjs: 3 K-lists or FacetGraphs;
+        gt: [1,N0,3] ground-truth normals (training only).  Casts once (float64->float32, int64->int32 as the
+        TF feed does, train.py:409-427)."""
+        dev = self.device
+        graphs = [as_graph(a, dev) for a in adjs]
+        if len(graphs) != 3:
+            raise ValueError("the network needs exactly 3 adjacency levels (model.py:858-931)")
+        xt = torch.as_tensor(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32))
+        xt = xt.reshape(-1, xt.shape[-1]).contiguous().to(dev)
+        n0, n1, n2 = (g.n for g in graphs)
+        if xt.shape[0] != n0 or n0 != 4 * n1 or n1 != 4 * n2:
+            raise ValueError("level sizes must be N0 = 4 N1 = 16 N2 and match x (got %d, %d, %d, x %d)" %
+                             (n0, n1, n2, xt.shape[0]))
+        if xt.shape[1] != self.in_channels:
+            raise ValueError("expected %d input channels" % self.in_channels)
+        f = dict(dtype=torch.float32, device=dev)
+        ns = [n0, n1, n2]
+        B = {"x": xt, "xr": torch.empty_like(xt)}
+        shapes = {"h1": (n0, 32), "p1": (n1, 32), "h2": (n1, 64), "p2": (n2, 64), "h3": (n2, 128), "d3": (n2, 128),
+                  "u2": (n1, 64), "d2": (n1, 64), "u1": (n0, 32), "d1": (n0, 32), "y0": (n0, 3), "nconv": (n0, 3)}
+        for k, s in shapes.items():
+            B[k] = torch.empty(*s, **f)
+            B["g_" + k] = torch.empty(*s, **f)   # gradient twin
+        for lay in self.layers:
+            rows = ns[lay.level] >> lay.shift
+            B["ag_" + lay.name] = torch.empty(rows, AG_LD, **f)
+        if self.multi_scale:
+            B["y1"] = torch.empty(n1, 3, **f)
+            B["y2"] = torch.empty(n2, 3, **f)
+        # shared backward scratch, sized for the largest user
+        max_ncout = max(ns[l.level] * self._cout(l) for l in self.layers)
+        max_nnz = max(g.nnz for g in graphs)
+        B["ds"] = torch.empty(max_ncout, **f)
+        B["dl"] = torch.empty(max(max_nnz, 1) * DL_LD, **f)
+        B["dag"] = torch.empty(max(ns) * AG_LD, **f)
+        B["r"] = torch.empty(max_ncout * FGC_M, **f)
+        B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
+        B["norm_scratch"] = torch.empty(2 + self.L.fgc_norm_num_partials(n0), **f)
+        B["loss"] = torch.zeros(2, **f)
+        B["R"] = torch.eye(3, **f).reshape(9).contiguous()
+        B["sample_ind"] = torch.zeros(COST_SAMPLES, dtype=torch.int32, device=dev)
+        if gt is not None:
+            gtt = torch.as_tensor(np.asarray(gt.cpu() if isinstance(gt, torch.Tensor) else gt, dtype=np.float32))
+            B["gt"] = gtt.reshape(-1, 3).contiguous().to(dev)
+            B["gtr"] = torch.empty_like(B["gt"])
+        # descriptors + workspace
+        vals, grads = self.params.values, self.params.grads
+        descs, ios, ws_f, ws_b = {}, {}, 0, 0
+        for lay in self.layers:
+            g = graphs[lay.level]
+            W0, b, u, c, v = vals[lay.pidx:lay.pidx + 5]
+            d = ConvDesc()
+            d.n, d.nnz = g.n, g.nnz
+            d.rowptr, d.col = g.rowptr.data_ptr(), g.col.data_ptr()
+            d.x0 = B[lay.x0].data_ptr()
+            d.x1 = B[lay.x1].data_ptr() if lay.x1 else None
+            d.c0 = B[lay.x0].shape[1]
+            d.c1 = B[lay.x1].shape[1] if lay.x1 else 0
+            d.shift, d.cout = lay.shift, W0.shape[1]
+            d.W0, d.b, d.u, d.c, d.v = (t.data_ptr() for t in (W0, b, u, c, v))
+            d.bias_mask, d.act, d.alpha = 1, lay.act, LRELU_ALPHA
+            descs[lay.name] = d
+            ws_f = max(ws_f, self.L.fgc_conv_workspace_bytes(C.byref(d)))
+            ws_b = max(ws_b, self.L.fgc_conv_bwd_workspace_bytes(C.byref(d)))
+            trow, tcol, tedge = g.transposed()
+            io = ConvBwdIO()
+            io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
+            io.ag, io.y, io.dy = B["ag_" + lay.name].data_ptr(), B[lay.y].data_ptr(), B["g_" + lay.y].data_ptr()
+            io.ds, io.dl, io.dag, io.r = (B[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
+            gW0, gb, gu, gc, gv = grads[lay.pidx:lay.pidx + 5]
+            io.dW0, io.db, io.du, io.dc, io.dv = (t.data_ptr() for t in (gW0, gb, gu, gc, gv))
+            ios[lay.name] = io
+        # who writes each activation gradient first (write) / second (accumulate): fixed backward order
+        #   g_h1: dconv1 (x1, write) then pool1 backward (accumulate);  g_h2: dconv2 (x1) then pool2 backward
+        for name, x0acc, x1acc in [("dconv1", 0, 0), ("upconv1", 0, 0), ("dconv2", 0, 0), ("upconv2", 0, 0),
+                                   ("dconv3", 0, 0), ("conv3", 0, 0), ("conv2", 0, 0)]:
+            lay = next(l for l in self.layers if l.name == name)
+            io = ios[name]
+            io.dx0 = B["g_" + lay.x0].data_ptr()
+            io.dx1 = B["g_" + lay.x1].data_ptr() if lay.x1 else None
+            io.accumulate0, io.accumulate1 = x0acc, x1acc
+        ios["conv1"].dx0 = None
+        ios["conv1"].dx1 = None
+        ws_f = max(ws_f, self.L.fgc_mlp_workspace_bytes(128, HIDDEN, 3))
+        ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n0, 32, HIDDEN, 3))
+        B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)
+        self._mesh = dict(graphs=graphs, B=B, descs=descs, ios=ios, ns=ns, has_gt=gt is not None)
+        self._graph_fb = None
+        return self
+
+    def _cout(self, lay):
+        return self.params.spec[lay.pidx][1][1]
+
+    # ------------------------------------------------------------------------------------------
+    # enqueue helpers (no allocation, no sync)
+    # ------------------------------------------------------------------------------------------
+    def _st(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _tag(self, name):
+        if self.profile:
+            self.L.fgc_profile_tag(name.encode())
+
+    def _enqueue_forward(self, rotate):
+        M, L, st = self._mesh, self.L, self._st()
+        B, ws = M["B"], M["B"]["ws"]
+        n0 = M["ns"][0]
+        self._tag("fwd:input")
+        if rotate:
+            _lib.check(L.fgc_rotate_rows(_p(B["x"]), _p(B["xr"]), n0, self.in_channels // 3, _p(B["R"]), st), "rotate")
+        else:
+            B["xr"].copy_(B["x"])
+        vals = self.params.values
+        for lay in self.layers:
+            self._tag("fwd:" + lay.name)
+            d = M["descs"][lay.name]
+            _lib.check(L.fgc_conv_fwd(C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]),
+                                      _p(B[lay.pool]) if lay.pool else None, _p(ws), ws.numel(), st), lay.name)
+            if self.multi_scale and lay.name in ("dconv3", "dconv2"):
+                head, out = ("head2", "y2") if lay.name == "dconv3" else ("head1", "y1")
+                W1, b1, W2, b2 = vals[self.slot[head]:self.slot[head] + 4]
+                xin = B[lay.y]
+                _lib.check(L.fgc_mlp_fwd(_p(xin), xin.shape[0], xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
+                                         _p(b2), LRELU_ALPHA, _p(B[out]), None, _p(ws), ws.numel(), st), head)
+        self._tag("fwd:mlp")
+        W1, b1, W2, b2 = vals[self.slot["head0"]:self.slot["head0"] + 4]
+        _lib.check(L.fgc_mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
+                                 _p(B["y0"]), _p(B["abs_part"]), _p(ws), ws.numel(), st), "head0")
+        self._tag("fwd:normalize")
+        _lib.check(L.fgc_normalize_fwd(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(), _p(B["nconv"]),
+                                       _p(B["norm_scratch"]), st), "normalize")
+
+    def _enqueue_loss_backward(self, rotate):
+        M, L, st = self._mesh, self.L, self._st()
+        B, ws, ns = M["B"], M["B"]["ws"], M["ns"]
+        n0 = ns[0]
+        gt = B["gt"]
+        self._tag("bwd:loss")
+        if rotate:
+            _lib.check(L.fgc_rotate_rows(_p(B["gt"]), _p(B["gtr"]), n0, 1, _p(B["R"]), st), "rotate gt")
+            gt = B["gtr"]
+        ns_samp = B["sample_ind"].numel()
+        _lib.check(L.fgc_angular_loss_fwd(_p(B["nconv"]), _p(gt), _p(B["sample_ind"]), ns_samp, _p(B["loss"]), st),
+                   "loss")
+        _lib.check(L.fgc_angular_loss_bwd(_p(B["nconv"]), _p(gt), _p(B["sample_ind"]), ns_samp, n0, _p(B["loss"]),
+                                          1.0, _p(B["g_nconv"]), st), "loss bwd")
+        _lib.check(L.fgc_normalize_bwd(_p(B["y0"]), _p(B["g_nconv"]), n0, _p(B["g_y0"]), _p(B["norm_scratch"]), st),
+                   "normalize bwd")
+        vals, grads = self.params.values, self.params.grads
+        s = self.slot["head0"]
+        self._tag("bwd:mlp")
+        _lib.check(L.fgc_mlp_bwd(_p(B["d1"]), _p(B["g_y0"]), n0, 32, HIDDEN, 3, _p(vals[s]), _p(vals[s + 1]),
+                                 _p(vals[s + 2]), LRELU_ALPHA, _p(B["g_d1"]), _p(grads[s]), _p(grads[s + 1]),
+                                 _p(grads[s + 2]), _p(grads[s + 3]), _p(ws), ws.numel(), st), "head0 bwd")
+        for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
+            self._tag("bwd:" + name)
+            if name == "conv2":   # g_h2 += d pool2
+                _lib.check(L.fgc_pool4_bwd(_p(B["h2"]), _p(B["p2"]), _p(B["g_p2"]), _p(B["g_h2"]), ns[2], 64, 1, st),
+                           "pool2 bwd")
+            if name == "conv1":   # g_h1 += d pool1
+                _lib.check(L.fgc_pool4_bwd(_p(B["h1"]), _p(B["p1"]), _p(B["g_p1"]), _p(B["g_h1"]), ns[1], 32, 1, st),
+                           "pool1 bwd")
+            _lib.check(L.fgc_conv_bwd(C.byref(M["descs"][name]), C.byref(M["ios"][name]), _p(ws), ws.numel(), st),
+                       name + " bwd")
+
+    # ------------------------------------------------------------------------------------------
+    # public API
+    # ------------------------------------------------------------------------------------------
+    def set_rotation(self, R):
+        """R [3,3] (train.py:563-565); identity = no augmentation."""
+        self._mesh["B"]["R"].copy_(torch.as_tensor(np.asarray(R, dtype=np.float32).reshape(9)))
+
+    def set_samples(self, sample_ind):
+        """Indices of the rows the loss is evaluated on (train.py:561), any of the N0 padded rows."""
+        t = torch.as_tensor(np.asarray(sample_ind).astype(np.int32))
+        B = self._mesh["B"]
+        if t.numel() != B["sample_ind"].numel():
+            B["sample_ind"] = torch.empty(t.numel(), dtype=torch.int32, device=self.device)
+            self._graph_fb = None
+        B["sample_ind"].copy_(t)
+
+    def forward(self, rotate=False):
+        """Normalised normals of the bound mesh: [N0,3] (padded, permuted order). Un-normalised output in buffers['y0']."""
+        self._enqueue_forward(rotate)
+        return self._mesh["B"]["nconv"]
+
+    def forward_backward(self, rotate=True, capture=False):
+        """One forward + backward (train.py:492-520 without the optimiser); loss in buffers['loss'][0]."""
+        if not self._mesh["has_gt"]:
+            raise RuntimeError("bind_mesh(..., gt=...) is required for training")
+        if capture:
+            if self._graph_fb is None:
+                # warm up on a side stream, then capture the whole enqueue sequence into one hipGraph
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._enqueue_forward(rotate)
+                    self._enqueue_loss_backward(rotate)
+                torch.cuda.current_stream().wait_stream(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_forward(rotate)
+                    self._enqueue_loss_backward(rotate)
+                self._graph_fb = (g, rotate)
+            self._graph_fb[0].replay()
+        else:
+            self._enqueue_forward(rotate)
+            self._enqueue_loss_backward(rotate)
+        return self._mesh["B"]["loss"]
+
+    def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+        P = self.params
+        P.step += 1
+        self._tag("adam")
+        _lib.check(self.L.fgc_adam_step(_p(P.theta), _p(P.grad), _p(P.m), _p(P.v), P.total, P.step, lr, b1, b2, eps,
+                                        self._st()), "adam")
+
+    def train_step(self, sample_ind=None, R=None, capture=False):
+        """One iteration of trainNet's loop body (train.py:558-575,619): returns the loss tensor (device, [2])."""
+        n0 = self._mesh["ns"][0]
+        if sample_ind is None:
+            sample_ind = np.random.randint(n0, size=COST_SAMPLES)
+        if R is None:
+            from .utils import rand_rotation_matrix
+            R = rand_rotation_matrix()
+        self.set_samples(sample_ind)
+        self.set_rotation(R)
+        loss = self.forward_backward(rotate=True, capture=capture)
+        self.adam_step()
+        return loss
+
+    def infer_normals(self, permutations, num_faces):
+        """Denoised unit normals in the ORIGINAL face order, [F,3] (train.py:115-121,136)."""
+        n_conv = self.forward(rotate=False)
+        perm = torch.as_tensor(np.asarray(permutations).astype(np.int32)).to(self.device)
+        out = torch.empty(num_faces, 3, dtype=torch.float32, device=self.device)
+        _lib.check(self.L.fgc_infer_epilogue(_p(n_conv), _p(perm), int(num_faces), _p(out), self._st()), "epilogue")
+        return out
+
+    @property
+    def buffers(self):
+        return self._mesh["B"]
+
+    # ------------------------------------------------------------------------------------------
+    # per-kernel timing through the library's hipEvent hooks
+    # ------------------------------------------------------------------------------------------
+    def profile_start(self):
+        self.profile = True
+        self.L.fgc_profile_enable(1)
+
+    def profile_stop(self):
+        """Returns {"tag/kernel": (launches, total_ms)}."""
+        buf = C.create_string_buffer(1 << 16)
+        n = self.L.fgc_profile_collect(buf, len(buf))
+        self.L.fgc_profile_enable(0)
+        self.profile = False
+        out = {}
+        if n > 0:
+            for line in buf.value.decode().splitlines():
+                name, cnt, ms = line.rsplit(" ", 2)
+                out[name] = (int(cnt), float(ms))
+        return out
+
+    def layer_dims(self):
+        """[(layer, n, nnz, cin, cout)] of the bound mesh, in forward order (for the roofline accounting)."""
+        M = self._mesh
+        out = []
+        for lay in self.layers:
+            g = M["graphs"][lay.level]
+            d = M["descs"][lay.name]
+            out.append((lay.name, g.n, g.nnz, d.c0 + d.c1, d.cout))
+        return out

@@ -246,14 +246,16 @@ def angular_loss_bwd(fn, gt, sample_ind, loss_out, dloss=1.0):
 
 
 def rotate_rows(x, R):
-    """Every 3-vector of every row times R^T (train.py:439-451).  R: 3x3 array-like on the host."""
+    """Every 3-vector v of every row becomes R v (train.py:439-451).  R: 3x3 array-like or device tensor."""
     x = _f32c(x)
     n, c = x.shape
     if c % 3:
         raise ValueError("channels must be a multiple of 3")
-    Rh = np.ascontiguousarray(np.asarray(R, dtype=np.float32).reshape(9))
+    if not isinstance(R, torch.Tensor) or not R.is_cuda:
+        R = torch.as_tensor(np.asarray(R, dtype=np.float32).reshape(9)).to(x.device)
+    R = R.reshape(9).float().contiguous()
     y = torch.empty_like(x)
-    check(_lib.lib().fgc_rotate_rows(ptr(x), ptr(y), n, c // 3, Rh.ctypes.data, stream_ptr()), "fgc_rotate_rows")
+    check(_lib.lib().fgc_rotate_rows(ptr(x), ptr(y), n, c // 3, ptr(R), stream_ptr()), "fgc_rotate_rows")
     return y
 
 

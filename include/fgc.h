@@ -43,6 +43,13 @@ extern "C" {
 const char* fgc_last_error(void);
 int fgc_version(void);
 
+/* Optional per-kernel timing (hipEvents around every launch of the library; off by default, not
+ * capturable into a hipGraph while on).  fgc_profile_collect synchronises and writes one line
+ * "tag/kernel count total_ms" per distinct kernel into buf; returns the bytes written. */
+int fgc_profile_enable(int on);
+int fgc_profile_tag(const char* tag);
+int fgc_profile_collect(char* buf, int32_t buf_bytes);
+
 /* ------------------------------------------------------------------------------------
  * Host-side graph conversion (CPU; pointers are HOST pointers)
  * ---------------------------------------------------------------------------------- */
@@ -57,6 +64,42 @@ int fgc_klist_from_csr(const int32_t* rowptr_h, const int32_t* col_h, int32_t n,
  * edge e = (i -> j); in-edges ordered by e.  trowptr_h [n+1], tcol_h [nnz] (= i), tedge_h [nnz] (= e). */
 int fgc_csr_transpose(const int32_t* rowptr_h, const int32_t* col_h, int32_t n, int32_t* trowptr_h,
                       int32_t* tcol_h, int32_t* tedge_h);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side mesh preprocessing (CPU, native C++; HOST pointers).  These replace the Python loops that
+ * build the tensors the network is fed (dataClasses.py:34-233).
+ * ---------------------------------------------------------------------------------- */
+
+/* unit face normals (computeFacesNormals utils.py:63-68 + normalize utils.py:26-35, fp32) and face
+ * barycentres divided by the bounding-box diagonal (getTrianglesBarycenter utils.py:1264-1294, fp32
+ * arithmetic stored as double like the reference's float64 array).  V [nv,3] f32, F [nf,3] u32. */
+int fgc_face_features(const float* V_h, int32_t nv, const uint32_t* F_h, int32_t nf, float* normals_h,
+                      double* centres_h);
+/* vertex-sharing facet adjacency K-list (getFacesLargeAdj utils.py:243-295), bit-exact: row i =
+ * [i+1, neighbours+1 in construction order (edge neighbours twice), 0...].  *unregistered counts the
+ * connections dropped because a row was full. */
+int fgc_faces_large_adj(const uint32_t* F_h, int32_t nf, int32_t nv, int32_t K, int32_t* adj_h,
+                        int64_t* unregistered);
+/* one greedy pairing pass (metis_one_level lib/coarsening.py:135-192), bit-exact given its arguments */
+int fgc_metis_one_level(const int32_t* rr_h, const int32_t* cc_h, const float* vv_h, int64_t nnz,
+                        const int64_t* rid_h, const float* weights_h, int32_t N, int32_t* cluster_id_h,
+                        double* total_assoc);
+/* Graph hierarchy = listToSparseWNormals (utils.py:1753-1796) + coarsen (lib/coarsening.py:5-31).
+ * The handle owns host memory (the only allocation the library makes); free it with fgc_hierarchy_free.
+ * parents_h (optional): `levels` recorded cluster-assignment arrays to replay (then `seed` is unused and the
+ * result is bit-identical to the reference run that produced them); parents_len_h their lengths. */
+typedef struct fgc_hierarchy fgc_hierarchy;
+int fgc_hierarchy_build(const int32_t* adj_h, int32_t n, int32_t K, const double* pos_h, const float* normals_h,
+                        int32_t levels, uint64_t seed, const int32_t* const* parents_h,
+                        const int32_t* parents_len_h, fgc_hierarchy** out);
+void fgc_hierarchy_free(fgc_hierarchy* h);
+int32_t fgc_hierarchy_size(const fgc_hierarchy* h, int32_t level);       /* padded node count */
+int32_t fgc_hierarchy_real_size(const fgc_hierarchy* h, int32_t level);  /* before fake nodes */
+int fgc_hierarchy_new_to_old(const fgc_hierarchy* h, int32_t level, int32_t* out_h);
+int fgc_hierarchy_parents(const fgc_hierarchy* h, int32_t level, int32_t* out_h);
+/* K-list of graph `level` in binary-tree order (perm_adjacency coarsening.py:269-296 + sparseToList
+ * utils.py:1799-1827); *saturated = 1 if a row had more than K-1 neighbours. */
+int fgc_hierarchy_klist(const fgc_hierarchy* h, int32_t level, int32_t K, int32_t* adj_h, int32_t* saturated);
 
 /* ------------------------------------------------------------------------------------
  * Graph convolution  (replaces custom_conv2d, model.py:427-504, invariance-off branch,
@@ -181,9 +224,10 @@ int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample
 int fgc_angular_loss_bwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns, int32_t n,
                          const float* loss_out, float dloss, float* dfn, void* stream);
 
-/* random-rotation augmentation (train.py:439-451): every 3-vector of every row times R^T.
- * R_h: HOST pointer to 9 floats (row major). vecs = channels / 3. */
-int fgc_rotate_rows(const float* x, float* y, int32_t n, int32_t vecs, const float* R_h, void* stream);
+/* random-rotation augmentation (train.py:439-451): every 3-vector v of every row becomes R v.
+ * R: DEVICE pointer to 9 floats (row major; kept on the device so that a captured hipGraph can be
+ * replayed with a new rotation).  vecs = channels / 3. */
+int fgc_rotate_rows(const float* x, float* y, int32_t n, int32_t vecs, const float* R, void* stream);
 
 /* TensorFlow-1 Adam over one flat parameter buffer (train.py:520, tf.train.AdamOptimizer defaults:
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)).  t is 1-based. */

@@ -1,0 +1,116 @@
+"""GPU parity of the full denoising network (forward, loss, all 44 gradients, inference epilogue, Adam)
+against the fixtures produced by executing the reference source."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bind(golden_dir, tag, seed, multi_scale=False):
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    prep = np.load(os.path.join(golden_dir, "prep_%s.npz" % tag))
+    net = FacetDenoiser("cuda:0", multi_scale=multi_scale, seed=seed)
+    net.bind_mesh(prep["x"], [prep["adj0"], prep["adj1"], prep["adj2"]], gt=prep["gt"])
+    return net, prep
+
+
+@pytest.mark.parametrize("name,tag,seed", [("net_ico3", "ico3", 0), ("net_torus640", "torus640", 1)])
+def test_train_forward_backward_matches_reference(golden_dir, name, tag, seed):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    net, prep = _bind(golden_dir, tag, seed)
+    assert net.params.num_parameters() == 474199 and len(net.params.spec) == int(z["n_vars"])
+    net.set_rotation(z["R"])
+    net.set_samples(z["sample_ind"])
+    loss = net.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    B = net.buffers
+    np.testing.assert_allclose(B["xr"].cpu().numpy(), z["fn_rot"][0], atol=1e-6)
+    y0 = B["y0"].cpu().numpy()
+    ref = z["y0"][0]
+    print("y0 max abs err %.3e (scale %.3f)" % (np.abs(y0 - ref).max(), np.abs(ref).max()))
+    np.testing.assert_allclose(y0, ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
+    # denoised normals: max abs 2e-5 on unit vectors (SURVEY §8c tolerance), i.e. ~1e-3 degree
+    np.testing.assert_allclose(B["nconv"].cpu().numpy(), z["n_conv"][0], rtol=0, atol=2e-5)
+    assert abs(loss[0].item() - float(z["loss"])) < 1e-4 * float(z["loss"])
+    worst = 0.0
+    for i, g in enumerate(net.params.grads):
+        ref = z["g%02d" % i]
+        scale = max(np.abs(ref).max(), 1e-3)
+        err = np.abs(g.cpu().numpy() - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
+    print("worst relative gradient error over 44 variables: %.3e" % worst)
+
+
+def test_gradients_vs_float64_truth(golden_dir):
+    """Error budget: the GPU fp32 gradients are as close to the float64 gradients as the reference's own fp32 run."""
+    z32 = np.load(os.path.join(golden_dir, "net_ico3.npz"))
+    z64 = np.load(os.path.join(golden_dir, "net_ico3_f64.npz"))
+    net, _ = _bind(golden_dir, "ico3", 0)
+    net.set_rotation(z32["R"])
+    net.set_samples(z32["sample_ind"])
+    net.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    e_gpu = e_ref = 0.0
+    for i, g in enumerate(net.params.grads):
+        t = z64["g%02d" % i]
+        scale = max(np.abs(t).max(), 1e-3)
+        e_gpu = max(e_gpu, np.abs(g.cpu().numpy() - t).max() / scale)
+        e_ref = max(e_ref, np.abs(z32["g%02d" % i] - t).max() / scale)
+    print("max rel grad error vs float64: gpu %.3e, reference fp32 %.3e" % (e_gpu, e_ref))
+    assert e_gpu < max(4 * e_ref, 1e-3)
+
+
+def test_forward_is_bitwise_reproducible_and_graph_capture_matches(golden_dir):
+    z = np.load(os.path.join(golden_dir, "net_ico3.npz"))
+    net, _ = _bind(golden_dir, "ico3", 0)
+    net.set_rotation(z["R"])
+    net.set_samples(z["sample_ind"])
+    net.forward_backward(rotate=True)
+    g1 = net.params.grad.clone()
+    n1 = net.buffers["nconv"].clone()
+    net.forward_backward(rotate=True)
+    assert torch.equal(g1, net.params.grad) and torch.equal(n1, net.buffers["nconv"])
+    net.forward_backward(rotate=True, capture=True)   # hipGraph capture + replay
+    net.forward_backward(rotate=True, capture=True)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, net.params.grad) and torch.equal(n1, net.buffers["nconv"])
+
+
+def test_inference_epilogue_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "infer_ico3.npz"))
+    net, prep = _bind(golden_dir, "ico3", 0)
+    out = net.infer_normals(prep["permutations"], int(prep["num_faces"]))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(net.buffers["nconv"].cpu().numpy(), z["n_conv"][0], atol=2e-5)
+    got = out.cpu().numpy()
+    ref = z["predicted_normals"]
+    assert got.shape == (1280, 3)
+    ang = np.degrees(np.arccos(np.clip((got * ref).sum(1), -1, 1)))
+    print("max angular deviation vs reference: %.2e deg" % ang.max())
+    assert ang.max() < 0.05 and np.abs(got - ref).max() < 2e-5
+
+
+def test_multiscale_heads_forward(golden_dir):
+    z = np.load(os.path.join(golden_dir, "net_ico3_ms.npz"))
+    net, _ = _bind(golden_dir, "ico3", 0, multi_scale=True)
+    assert len(net.params.spec) == 52
+    net.set_rotation(z["R"])
+    net.forward(rotate=True)
+    torch.cuda.synchronize()
+    for k in ("y0", "y1", "y2"):
+        ref = z[k][0]
+        np.testing.assert_allclose(net.buffers[k].cpu().numpy(), ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
+
+
+def test_adam_training_reduces_loss(golden_dir):
+    net, prep = _bind(golden_dir, "ico3", 0)
+    rs = np.random.RandomState(0)
+    losses = []
+    for it in range(30):
+        loss = net.train_step(sample_ind=rs.randint(prep["x"].shape[1], size=4000), R=np.eye(3))
+        losses.append(loss[0].item())
+    assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0], losses

@@ -1,0 +1,152 @@
+"""CPU tests of the native preprocessing (libfgc host routines) against the reference fixtures.
+
+Integer results (adjacency K-lists, pairing given its inputs, tree ordering and coarsened K-lists given the
+recorded cluster assignments) must be bit-exact; floating-point features within 1 ulp-level tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from facet_graph_convolution_amd import utils, graph
+from facet_graph_convolution_amd.dataClasses import InferenceMesh, TrainingSet
+from facet_graph_convolution_amd.meshgen import icosphere, torus, add_noise
+
+TAGS = ["ico3", "torus640"]
+
+
+def _prep(golden_dir, tag):
+    return np.load(os.path.join(golden_dir, "prep_%s.npz" % tag))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_faces_large_adj_bit_exact(golden_dir, tag):
+    z = _prep(golden_dir, tag)
+    adj = utils.getFacesLargeAdj(z["F"], 23)
+    assert adj.dtype == np.int32 and np.array_equal(adj, z["fadj"])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_face_features(golden_dir, tag):
+    z = _prep(golden_dir, tag)
+    normals, centres = utils.face_features(z["V"], z["F"])
+    assert np.abs(normals - z["normals"]).max() <= 6e-8      # fp32: same operation order, <= 1 ulp
+    assert np.abs(centres - z["centres"]).max() <= 6e-8
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_metis_one_level_bit_exact_given_its_inputs(golden_dir, tag):
+    z = _prep(golden_dir, tag)
+    cid, assoc = utils.metis_one_level(z["ol_rr"], z["ol_cc"], z["ol_vv"], z["ol_rid"], z["ol_weights"])
+    assert np.array_equal(cid, z["ol_cluster_id"])
+    assert assoc == float(z["ol_assoc"])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_hierarchy_bit_exact_given_recorded_parents(golden_dir, tag):
+    """compute_perm + perm_adjacency + sparseToList + padding/reorder: the whole tensor contract."""
+    z = _prep(golden_dir, tag)
+    parents = [z["parents%d" % i] for i in range(int(z["n_parent_levels"]))]
+    ds = TrainingSet()
+    ds.addMeshWithGT(z["V"], z["F"], z["Vclean"], parents=parents)
+    for l in range(3):
+        assert ds.adj_list[0][l].dtype == np.int64
+        assert np.array_equal(ds.adj_list[0][l], z["adj%d" % l]), "level %d" % l
+    assert np.array_equal(ds.permutations[0], z["permutations"])
+    assert ds.num_faces[0] == int(z["num_faces"])
+    assert ds.in_list[0].dtype == np.float64 and ds.in_list[0].shape == z["x"].shape
+    assert np.abs(ds.in_list[0] - z["x"]).max() <= 6e-8
+    assert np.abs(ds.gt_list[0] - z["gt"]).max() <= 6e-8
+    # fake rows are exactly zero
+    fake = np.asarray(z["x"][0] == 0).all(axis=1)
+    assert np.array_equal(fake, (ds.in_list[0][0] == 0).all(axis=1))
+
+
+def test_compute_perm_known_answer():
+    """The reference's only golden vector (lib/coarsening.py:243-244), through the native ordering:
+    parents [[4,1,1,2,2,3,0,0,3],[2,1,0,1,0]] -> [[3,4,0,9,1,2,5,8,6,7,10,11],[2,4,1,3,0,5],[0,1,2]]."""
+    n = 9
+    adj = np.zeros((n, 23), dtype=np.int32)
+    for i in range(n):           # a ring so that every node has edges
+        adj[i, :3] = [i + 1, (i + 1) % n + 1, (i - 1) % n + 1]
+    pos = np.zeros((n, 3))
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (n, 1))
+    parents = [np.array([4, 1, 1, 2, 2, 3, 0, 0, 3]), np.array([2, 1, 0, 1, 0])]
+    import ctypes as C
+    from facet_graph_convolution_amd import _lib
+    L = _lib.lib()
+    arrs = [np.ascontiguousarray(p, dtype=np.int32) for p in parents]
+    ptrs = (C.c_void_p * 2)(*[a.ctypes.data for a in arrs])
+    lens = np.asarray([9, 5], dtype=np.int32)
+    h = C.c_void_p(0)
+    _lib.check(L.fgc_hierarchy_build(adj.ctypes.data, n, 23, pos.ctypes.data, nrm.ctypes.data, 2, C.c_uint64(0),
+                                     C.cast(ptrs, C.c_void_p), lens.ctypes.data, C.byref(h)))
+    got = []
+    for lvl in range(3):
+        m = L.fgc_hierarchy_size(h, lvl)
+        out = np.empty(m, dtype=np.int32)
+        _lib.check(L.fgc_hierarchy_new_to_old(h, lvl, out.ctypes.data))
+        got.append(out.tolist())
+    L.fgc_hierarchy_free(h)
+    assert got == [[3, 4, 0, 9, 1, 2, 5, 8, 6, 7, 10, 11], [2, 4, 1, 3, 0, 5], [0, 1, 2]]
+
+
+def test_own_pairing_is_a_valid_draw_and_deterministic():
+    """Without recorded parents the build draws its own pairing (seeded): structural invariants of the reference
+    (coarsening.py:215,237-239; dataClasses.py:116-131) must hold and the result must be reproducible."""
+    V, F = icosphere(3)
+    V = add_noise(V, F)
+    a = InferenceMesh()
+    a.addMesh(V, F, seed=3)
+    b = InferenceMesh()
+    b.addMesh(V, F, seed=3)
+    adjs = a.adj_list[0]
+    for l in range(3):
+        assert np.array_equal(adjs[l], b.adj_list[0][l])
+    n0, n1, n2 = (adjs[l].shape[1] for l in range(3))
+    assert n0 == 4 * n1 == 16 * n2 and n0 % 16 == 0
+    assert 1.0 <= n0 / 1280 <= 1.35
+    perm = a.permutations[0]
+    assert sorted(perm.tolist()) == list(range(n0))                 # complete permutation
+    x = a.in_list[0][0]
+    real_rows = perm[:1280]
+    assert (np.abs(x[real_rows]).sum(1) > 0).all() and (x[np.setdiff1d(np.arange(n0), real_rows)] == 0).all()
+    for l in range(3):
+        k = adjs[l][0]
+        n = k.shape[0]
+        assert (k[:, 0] == np.arange(1, n + 1)).all()               # slot 0 = self
+        assert k.max() <= n and k.min() >= 0
+        # symmetric, sorted, duplicate-free neighbour lists
+        rows = [set(r[1:][r[1:] > 0] - 1) for r in k]
+        for i, r in enumerate(rows):
+            nz = k[i, 1:][k[i, 1:] > 0]
+            assert (np.diff(nz) > 0).all()
+            for j in r:
+                assert i in rows[j]
+
+
+def test_klist_csr_round_trip_and_transpose(golden_dir):
+    z = _prep(golden_dir, "ico3")
+    for key in ("fadj", "adj0", "adj1", "adj2"):
+        k = z[key]
+        k = k[0] if k.ndim == 3 else k
+        rowptr, col = graph.csr_from_klist(k)
+        assert np.array_equal(np.diff(rowptr), (k != 0).sum(1))     # deg = count_nonzero (model.py:436)
+        back = graph.klist_from_csr(rowptr, col, k.shape[1])
+        assert np.array_equal(back, k.astype(np.int32))             # bit-identical round trip
+        trow, tcol, tedge = graph.csr_transpose(rowptr, col)
+        # every forward edge e = (i -> j) appears exactly once among j's in-edges
+        src = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+        assert np.array_equal(np.sort(tedge), np.arange(len(col)))
+        assert np.array_equal(src[tedge], tcol)
+        assert np.array_equal(col[tedge], np.repeat(np.arange(len(trow) - 1), np.diff(trow)))
+
+
+def test_csr_rejects_bad_input():
+    bad = np.array([[1, 5, 0]], dtype=np.int32)          # neighbour id 5 > n = 1
+    with pytest.raises(RuntimeError):
+        graph.csr_from_klist(bad)
+    # empty slots in the middle of a row are skipped, order kept
+    k = np.array([[1, 0, 2], [2, 1, 0]], dtype=np.int32)
+    rowptr, col = graph.csr_from_klist(k)
+    assert rowptr.tolist() == [0, 2, 4] and col.tolist() == [0, 1, 1, 0]
