@@ -71,16 +71,16 @@ def algorithmic_bytes_fwd_bwd(net):
     return fwd, fwd * 3879.0 / 1584.0
 
 
-def cpu_baseline(sample_faces=(100, 100)):
+def cpu_baseline(sample_faces=(70, 70)):
     """The oracle timed on this host: one forward+backward of the reference-shaped torch-CPU restatement on a
-    20 000-facet torus (the reference's own patch size, settings.py:20), all host threads."""
+    9 800-facet torus (bounded so that the default bench run stays within minutes), up to 32 host threads."""
     import torch
     from oracle import model_ref as R
     ds, F = build_mesh(sample_faces[0], sample_faces[1], seed=7)
     x = torch.tensor(ds.in_list[0].astype(np.float32))
     gt = torch.tensor(ds.gt_list[0].astype(np.float32))
     adjs = [torch.tensor(a.astype(np.int32)) for a in ds.adj_list[0]]
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)   # more threads than this only add contention on these op sizes
     torch.set_num_threads(threads)
     params = [p.requires_grad_(True) for p in R.init_params(0)]
     samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
@@ -91,7 +91,7 @@ def cpu_baseline(sample_faces=(100, 100)):
     dt = time.time() - t0
     return {"value": F / dt, "unit": "facets/s", "cores": threads, "kind": "port",
             "sample": "oracle/model_ref.py (reference-shaped K-padded torch CPU fp32), 1 forward+backward of the "
-                      "full net on a torus 100x100 = %d facets (N0=%d), %.1f s" % (F, x.shape[1], dt)}
+                      "full net on a torus %dx%d = %d facets (N0=%d), %.1f s" % (sample_faces[0], sample_faces[1], F, x.shape[1], dt)}
 
 
 def main():
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="replay the forward+backward enqueue as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernels", type=str, default="", help="write the full per-kernel table to this file")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +196,12 @@ def main():
             fl = kernel_flops(kind, *dims[layer]) if kind else None
             rows.append((ms, key, cnt, avg_us, fl))
         rows.sort(reverse=True)
+        if args.dump_kernels and rank == 0:
+            with open(args.dump_kernels, "w") as fh:
+                for ms, key, cnt, avg_us, fl in rows:
+                    fh.write("%-60s launches/step %4.1f  avg %9.2f us  per-step %9.2f us  share %5.2f%%  %s\n" % (
+                        key, cnt / args.steps, avg_us, ms / args.steps * 1e3, 100 * ms / total_ms,
+                        ("%.1f TFLOP/s" % (fl / (avg_us * 1e-6) / 1e12)) if fl else ""))
         for ms, key, cnt, avg_us, fl in rows[:12]:
             kernels[key] = {"launches": cnt, "avg_us": round(avg_us, 2), "share": round(ms / total_ms, 4),
                             "tflops": round(fl / (avg_us * 1e-6) / 1e12, 2) if fl else None}

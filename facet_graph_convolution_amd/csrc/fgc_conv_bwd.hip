@@ -14,6 +14,7 @@
 //   K3  reductions over nodes (f32 MFMA, K = nodes):  dW0 = r^T x,  [du; dv] = dag^T x ; db, dc column sums
 // No float atomics anywhere: every sum has a fixed order, results are bitwise reproducible.
 #include "fgc_conv_core.h"
+#include "fgc_reduce.h"
 
 namespace fgc {
 
@@ -25,30 +26,37 @@ void fill_core_params(CoreParams& p, const ConvGeom& g, int n, const int* rowptr
 size_t conv_smem_bytes(const ConvGeom& g, size_t extra);
 __global__ void pack_weight_kernel(const float* __restrict__ W0, float* __restrict__ Wp, int cin, int cout, int kdim,
                                    int ncols, int npad, int kc, int kpass, int passes, int transposed);
-__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nslabs, size_t count, int in_ld, int out_ld,
-                                    float* __restrict__ out);
 
 __device__ __forceinline__ float slope_from_y(float y, float alpha) { return y > 0.f ? 1.f : (y < 0.f ? alpha : 0.f); }
 
 // ---------------------------------------------------------------------------------------------
 // s = dy * lrelu'(y) / deg ; db partial column sums of dy * lrelu'(y) over rows that got the bias
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void ds_db_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                    const int* __restrict__ rowptr, int n, int cout, int act,
+// workgroup = (256 / cp2) row lanes x cp2 columns (cp2 = cout rounded up to a power of two); coalesced over columns
+__global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                    const int* __restrict__ rowptr, int n, int cout, int cp2, int act,
                                                     float alpha, int bias_mask, int rows_per_block,
                                                     float* __restrict__ ds, float* __restrict__ db_part) {
+    __shared__ float part[256];
+    const int col = threadIdx.x % cp2, rl = threadIdx.x / cp2, nrl = 256 / cp2;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(n, r0 + rows_per_block);
-    for (int col = threadIdx.x; col < cout; col += blockDim.x) {
-        float acc = 0.f;
-        for (int r = r0; r < r1; ++r) {
+    float acc = 0.f;
+    if (col < cout) {
+        for (int r = r0 + rl; r < r1; r += nrl) {
             const int d = rowptr[r + 1] - rowptr[r];
             float g = dy[(size_t)r * cout + col];
             if (act) g *= slope_from_y(y[(size_t)r * cout + col], alpha);
             if (!bias_mask || d > 0) acc += g;
             ds[(size_t)r * cout + col] = d > 0 ? g / (float)d : 0.f;
         }
-        db_part[(size_t)blockIdx.x * cout + col] = acc;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && col < cout) {
+        float v = 0.f;
+        for (int t = 0; t < nrl; ++t) v += part[t * cp2 + col];
+        db_part[(size_t)blockIdx.x * cout + col] = v;
     }
 }
 
@@ -426,77 +434,97 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
 
 // ---------------------------------------------------------------------------------------------
 // K3: C[P,Q] = sum_rows A[row,P] * X[row >> shift, Q]   (X = [x0 | x1]); f32 MFMA with K = rows.
-// grid (P/64, nsplit): each workgroup owns 64 columns of A, all Q, and a contiguous row range; its
-// partial goes to slab[split][P][Q]; a fixed-order pass sums the slabs.
+// Both operands are row-major with the reduction index as the slow dimension, so a lane's 16-byte load of
+// A[row, p0+4*lr .. +3] holds the SAME k (row) for 4 different output rows: MFMA number e takes element e,
+// i.e. MFMA e owns output rows p0 + 4*i + e (i = MFMA row index).  One dwordx4 of A and one of X per lane feed
+// 16 MFMAs (a 64 x 64 tile per wave, 4 rows of K per step); no LDS staging, no barrier in the loop.
+// grid (P tiles * Q tiles, row splits); the 4 waves of a workgroup interleave the k-steps of their split and are
+// summed through LDS in a fixed order; partials go to slab[split][P][Q], reduced by reduce_slabs.
 // ---------------------------------------------------------------------------------------------
-constexpr int TN_QT = 8;  // Q <= 128
-
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, int P,
-                                                      const float* __restrict__ x0, const float* __restrict__ x1,
-                                                      int c0, int c1, int shift, int rows, int rows_per_split,
-                                                      float* __restrict__ slab) {
-    __shared__ __attribute__((aligned(16))) float As[16][64];
-    __shared__ __attribute__((aligned(16))) float Bs[16][128];
+template <bool VEC4>
+__device__ __forceinline__ void tn_load(const float* __restrict__ A, int lda, int P, const float* __restrict__ x0,
+                                        const float* __restrict__ x1, int c0, int c1, int shift, int row, bool valid,
+                                        int pbase, int qbase, f32x4& a, f32x4& b) {
+    a = f32x4{0.f, 0.f, 0.f, 0.f};
+    b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!valid) return;
     const int Q = c0 + c1;
-    const int qpad = (Q + 15) & ~15;
-    const int nqt = qpad >> 4;
-    const int p0 = blockIdx.x * 64;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int r_begin = blockIdx.y * rows_per_split;
-    const int r_end = min(rows, r_begin + rows_per_split);
-    f32x4 acc[TN_QT];
-#pragma unroll
-    for (int q = 0; q < TN_QT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int rb = r_begin; rb < r_end; rb += 16) {
-        __syncthreads();
-        for (int t = tid; t < 16 * 64; t += 256) {
-            const int rr = t >> 6, pp = t & 63;
-            const int row = rb + rr;
-            As[rr][pp] = (row < r_end && p0 + pp < P) ? A[(size_t)row * lda + p0 + pp] : 0.f;
-        }
-        for (int t = tid; t < 16 * qpad; t += 256) {
-            const int rr = t / qpad, qq = t % qpad;
-            const int row = rb + rr;
-            float v = 0.f;
-            if (row < r_end && qq < Q) {
-                const size_t sr = (size_t)(row >> shift);
-                v = qq < c0 ? x0[sr * c0 + qq] : x1[sr * c1 + (qq - c0)];
-            }
-            Bs[rr][qq] = v;
-        }
-        __syncthreads();
-        float a[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = As[lq * 4 + t][wave * 16 + lr];
-#pragma unroll
-        for (int q = 0; q < TN_QT; ++q) {
-            if (q >= nqt) break;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Bs[lq * 4 + t][q * 16 + lr], acc[q], 0, 0, 0);
-        }
-    }
-    float* out = slab + (size_t)blockIdx.y * P * Q;
-#pragma unroll
-    for (int q = 0; q < TN_QT; ++q) {
-        if (q >= nqt) break;
+    const size_t sr = (size_t)(row >> shift);
+    if (VEC4) {
+        if (pbase < P) a = *reinterpret_cast<const f32x4*>(A + (size_t)row * lda + pbase);
+        if (qbase < c0) b = *reinterpret_cast<const f32x4*>(x0 + sr * c0 + qbase);
+        else if (qbase < Q) b = *reinterpret_cast<const f32x4*>(x1 + sr * c1 + (qbase - c0));
+    } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int pp = p0 + wave * 16 + lq * 4 + t;
-            const int qq = q * 16 + lr;
-            if (pp < P && qq < Q) out[(size_t)pp * Q + qq] = acc[q][t];
+            if (pbase + t < P) a[t] = A[(size_t)row * lda + pbase + t];
+            const int q = qbase + t;
+            if (q < c0) b[t] = x0[sr * c0 + q];
+            else if (q < Q) b[t] = x1[sr * c1 + (q - c0)];
         }
     }
 }
 
-static int tn_splits(int P, int rows) {
-    const int pb = cdiv(P, 64);
-    int s = 1024 / pb;
-    const int maxs = cdiv(rows, 64);
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, int P,
+                                                      const float* __restrict__ x0, const float* __restrict__ x1,
+                                                      int c0, int c1, int shift, int rows, int rows_per_split,
+                                                      float* __restrict__ slab) {
+    __shared__ float red[4][64][65];
+    const int Q = c0 + c1;
+    const int npt = (P + 63) >> 6;
+    const int pt = blockIdx.x % npt, qt = blockIdx.x / npt;
+    const int p0 = pt * 64, q0 = qt * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_end = min(rows, r_begin + rows_per_split);
+    const int nsteps = (r_end - r_begin + 3) >> 2;
+    const int pbase = p0 + 4 * lr, qbase = q0 + 4 * lr;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 a, b, an, bn;
+    int s = wave;
+    {
+        const int row = r_begin + 4 * s + lq;
+        tn_load<VEC4>(A, lda, P, x0, x1, c0, c1, shift, row, s < nsteps && row < r_end, pbase, qbase, a, b);
+    }
+    for (; s < nsteps; s += 4) {
+        const int sn = s + 4;
+        const int rown = r_begin + 4 * sn + lq;
+        tn_load<VEC4>(A, lda, P, x0, x1, c0, c1, shift, rown, sn < nsteps && rown < r_end, pbase, qbase, an, bn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        a = an;
+        b = bn;
+    }
+    // C layout of acc[i][j]: column index lr -> q = 4*lr + j ; row index lq*4+reg -> p = 4*(lq*4+reg) + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) red[wave][4 * (lq * 4 + t) + i][4 * lr + j] = acc[i][j][t];
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.y * P * Q;
+    for (int t = tid; t < 64 * 64; t += 256) {
+        const int pp = t >> 6, qq = t & 63;
+        if (p0 + pp < P && q0 + qq < Q)
+            out[(size_t)(p0 + pp) * Q + q0 + qq] = (red[0][pp][qq] + red[1][pp][qq]) + (red[2][pp][qq] + red[3][pp][qq]);
+    }
+}
+
+static int tn_splits(int P, int Q, int rows) {
+    const int tiles = cdiv(P, 64) * cdiv(Q, 64);
+    int s = 768 / tiles;
+    const int maxs = cdiv(rows, 256);
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
-    if (s > 256) s = 256;
     return s;
 }
 
@@ -507,6 +535,7 @@ struct BwdWorkspace {
     float* dc_part;   // [tiles][12]
     float* slab;      // gemm_tn partials
     float* duv;       // [24, cin]
+    float* rtmp;      // scratch of the fixed-order reductions
     size_t bytes;
     int nb_db, rows_per_db;
     int splitW, splitUV;
@@ -526,16 +555,19 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     };
     w.Wq = take((size_t)g1.passes * opad * g1.kpass);
     w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
-    w.rows_per_db = 256;
+    w.nb_db = d->n < 512 * 64 ? cdiv(d->n, 64) : 512;
+    w.rows_per_db = cdiv(d->n, w.nb_db);
     w.nb_db = cdiv(d->n, w.rows_per_db);
     w.db_part = take((size_t)w.nb_db * d->cout);
     w.dc_part = take((size_t)cdiv(d->n, TILE) * 12);
-    w.splitW = tn_splits(FGC_M * d->cout, d->n);
-    w.splitUV = tn_splits(24, d->n);
+    w.splitW = tn_splits(FGC_M * d->cout, cin, d->n);
+    w.splitUV = tn_splits(24, cin, d->n);
     const size_t s1 = (size_t)w.splitW * FGC_M * d->cout * cin;
     const size_t s2 = (size_t)w.splitUV * 24 * cin;
     w.slab = take(s1 > s2 ? s1 : s2);
     w.duv = take((size_t)24 * cin);
+    w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + reduce_tmp_floats(w.splitUV, (size_t)24 * cin) +
+                  reduce_tmp_floats(cdiv(d->n, TILE), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
     w.bytes = off;
     return w;
 }
@@ -604,11 +636,15 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const int ostride = opad + 8;
 
     // s = dy*lrelu'(y)/deg, db partials
-    FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(128), 0, io->dy, io->y, d->rowptr, d->n, cout, d->act,
-                       d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
-    FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(1), dim3(128), 0, w.db_part, w.nb_db, (size_t)cout, cout, cout,
-                       io->db);
-    FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");
+    {
+        int cp2 = 1;
+        while (cp2 < cout) cp2 <<= 1;
+        FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
+                   d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");
+        rc = reduce_slabs("reduce:db", w.db_part, w.nb_db, (size_t)cout, cout, cout, io->db, w.rtmp, st);
+        if (rc) return rc;
+    }
     // operand packing
     {
         const size_t tot = (size_t)g1.passes * opad * g1.kpass;
@@ -633,9 +669,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             default: rc = launch_logits<8>(p, lp, vec4, smem, st); break;
         }
         if (rc) return rc;
-        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(1), dim3(64), 0, w.dc_part, cdiv(d->n, TILE), (size_t)12, 12,
-                           FGC_M, io->dc);
-        FGC_CHECK_LAUNCH("fgc_conv_bwd/dc");
+        rc = reduce_slabs("reduce:dc", w.dc_part, cdiv(d->n, TILE), (size_t)12, 12, FGC_M, io->dc, w.rtmp, st);
+        if (rc) return rc;
     }
     // K2
     {
@@ -653,27 +688,30 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         }
         if (rc) return rc;
     }
-    // K3: dW0 = r^T x
+    // K3: dW0 = r^T x ; [du; dv] = dag^T x
     {
+        const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0) && ((uintptr_t)io->dag % 16 == 0);
         const int P = FGC_M * cout;
-        const int rps = cdiv(cdiv(d->n, w.splitW), 16) * 16;
-        const int ns = cdiv(d->n, rps);
-        FGC_LAUNCH("gemm_tn_kernel", st, gemm_tn_kernel, dim3(cdiv(P, 64), ns), dim3(256), 0, io->r, P, P, d->x0, d->x1, d->c0,
-                           d->c1, d->shift, d->n, rps, w.slab);
-        const size_t cnt = (size_t)P * cin;
-        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, w.slab, ns, cnt, cin, cin,
-                           io->dW0);
+        int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;
+        int ns = cdiv(d->n, rps);
+        const dim3 g1(cdiv(P, 64) * cdiv(cin, 64), ns);
+        if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+                           d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        else FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<false>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+                        d->c0, d->c1, d->shift, d->n, rps, w.slab);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
-    }
-    // [du; dv] = dag^T x
-    {
-        const int rps = cdiv(cdiv(d->n, w.splitUV), 16) * 16;
-        const int ns = cdiv(d->n, rps);
-        FGC_LAUNCH("gemm_tn_kernel", st, gemm_tn_kernel, dim3(1, ns), dim3(256), 0, io->dag, FGC_AG_LD, 24, d->x0, d->x1, d->c0,
-                           d->c1, d->shift, d->n, rps, w.slab);
-        const size_t cnt = (size_t)24 * cin;
-        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, w.slab, ns, cnt, cin, cin,
-                           w.duv);
+        rc = reduce_slabs("reduce:dW", w.slab, ns, (size_t)P * cin, cin, cin, io->dW0, w.rtmp, st);
+        if (rc) return rc;
+        rps = cdiv(cdiv(d->n, w.splitUV), 4) * 4;
+        ns = cdiv(d->n, rps);
+        const dim3 g2(cdiv(cin, 64), ns);
+        if (v4) FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<true>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
+                           d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        else FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<false>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
+                        d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/duv");
+        rc = reduce_slabs("reduce:duv", w.slab, ns, (size_t)24 * cin, cin, cin, w.duv, w.rtmp, st);
+        if (rc) return rc;
         if (hipMemcpyAsync(io->du, w.duv, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
             hipMemcpyAsync(io->dv, w.duv + (size_t)12 * cin, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) !=
                 hipSuccess) {

@@ -178,31 +178,33 @@ __device__ __forceinline__ void aggregate_pass(const CoreParams& p, const Smem& 
     const int d = min(max(s.deg[node] - kbase, 0), KMAX);
     const int cbase = pass * p.kc + cl * 4;
     const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
-    int k = 0;
-    for (; k + 4 <= d; k += 4) {
-        f32x4 xv[4];
+    // batches of 4 neighbour rows; the next batch's global loads are issued before the current batch's FMAs
+    f32x4 xc[4], xn[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xv[t] = load_chunk<VEC4>(p, __float_as_int(qb[(k + t) * QLD + 9]), cbase);
+    for (int t = 0; t < 4; ++t) {
+        xc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < d) xc[t] = load_chunk<VEC4>(p, __float_as_int(qb[t * QLD + 9]), cbase);
+    }
+    for (int k = 0; k < d; k += 4) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float* q = qb + (k + t) * QLD;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
-            const float q8 = q[8];
-            z[0] += q0[0] * xv[t]; z[1] += q0[1] * xv[t]; z[2] += q0[2] * xv[t]; z[3] += q0[3] * xv[t];
-            z[4] += q1[0] * xv[t]; z[5] += q1[1] * xv[t]; z[6] += q1[2] * xv[t]; z[7] += q1[3] * xv[t];
-            z[8] += q8 * xv[t];
+            xn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k + 4 + t < d) xn[t] = load_chunk<VEC4>(p, __float_as_int(qb[(k + 4 + t) * QLD + 9]), cbase);
         }
-    }
-    for (; k < d; ++k) {
-        const f32x4 xv = load_chunk<VEC4>(p, __float_as_int(qb[k * QLD + 9]), cbase);
-        const float* q = qb + k * QLD;
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
-        const float q8 = q[8];
-        z[0] += q0[0] * xv; z[1] += q0[1] * xv; z[2] += q0[2] * xv; z[3] += q0[3] * xv;
-        z[4] += q1[0] * xv; z[5] += q1[1] * xv; z[6] += q1[2] * xv; z[7] += q1[3] * xv;
-        z[8] += q8 * xv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (k + t < d) {
+                const float* q = qb + (k + t) * QLD;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
+                const float q8 = q[8];
+                z[0] += q0[0] * xc[t]; z[1] += q0[1] * xc[t]; z[2] += q0[2] * xc[t]; z[3] += q0[3] * xc[t];
+                z[4] += q1[0] * xc[t]; z[5] += q1[1] * xc[t]; z[6] += q1[2] * xc[t]; z[7] += q1[3] * xc[t];
+                z[8] += q8 * xc[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xc[t] = xn[t];
     }
 }
 
@@ -260,16 +262,23 @@ __device__ __forceinline__ void gemm_pass(const CoreParams& p, const Smem& s, in
 #pragma unroll
     for (int c = 0; c < CTW; ++c) ctv[c] = (wt.ct0 + c * wt.ctstep) < nct;
     if (!ctv[0]) return;
-    for (int g = kg0; g < kg1; ++g) {
-        f32x4 a[RT], b[CTW];
-#pragma unroll
-        for (int r = 0; r < RT; ++r)
-            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + g * 16 + lq * 4);
+    // B fragments (packed weights, L2 resident) are fetched two k-groups ahead of the MFMAs that consume them
+    auto loadb = [&](int g, f32x4 (&b)[CTW]) {
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
             b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ctv[c]) b[c] = Wp4[(wrow0 + g * 4 + lq) * p.npad + (wt.ct0 + c * wt.ctstep) * 16 + lr];
+            if (ctv[c] && g < kg1) b[c] = Wp4[(wrow0 + g * 4 + lq) * p.npad + (wt.ct0 + c * wt.ctstep) * 16 + lr];
         }
+    };
+    f32x4 b0[CTW], b1[CTW], b2[CTW];
+    loadb(kg0, b0);
+    loadb(kg0 + 1, b1);
+    for (int g = kg0; g < kg1; ++g) {
+        loadb(g + 2, b2);
+        f32x4 a[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + g * 16 + lq * 4);
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
             if (!ctv[c]) continue;
@@ -277,8 +286,13 @@ __device__ __forceinline__ void gemm_pass(const CoreParams& p, const Smem& s, in
             for (int r = 0; r < RT; ++r) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b0[c][t], acc[r][c], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            b0[c] = b1[c];
+            b1[c] = b2[c];
         }
     }
 }

@@ -2,7 +2,7 @@
 // /root/reference/Code/model.py:763-769,937-941).  The [n, hidden] activation never leaves the CU:
 // each wave produces 16-column slabs of it with f32 MFMA, applies bias + leaky ReLU in the
 // accumulator layout and folds them straight into the tiny second layer on the VALU.
-#include "fgc_common.h"
+#include "fgc_reduce.h"
 
 namespace fgc {
 
@@ -310,19 +310,6 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
     }
 }
 
-// out[j] = sum_s slab[s][j] (fixed order), optional column remap: out index j -> (j / in_ld) * out_ld + j % in_ld for
-// j % in_ld < out_ld
-__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nslabs, size_t count, int in_ld, int out_ld,
-                                    float* __restrict__ out) {
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(j % in_ld);
-        if (c >= out_ld) continue;
-        float v = 0.f;
-        for (int s = 0; s < nslabs; ++s) v += slab[(size_t)s * count + j];
-        out[(j / in_ld) * out_ld + c] = v;
-    }
-}
-
 // column sums of a [rows, c] matrix in two deterministic stages
 __global__ void colsum_stage1_kernel(const float* __restrict__ a, int rows, int c, int rows_per_block,
                                      float* __restrict__ part /* [gridDim.x][c] */) {
@@ -363,6 +350,7 @@ extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hi
     b += align_up(gx * (size_t)hidden * 4, 256);           // db1 slabs
     b += align_up(gx * (size_t)hidden * 4 * 4, 256);       // dW2 slabs
     b += align_up((size_t)1024 * 4 * 4, 256);              // db2 partials
+    b += align_up(reduce_tmp_floats(1024, 4) * 4 + reduce_tmp_floats((int)gx, (size_t)cin * hidden) * 4 + 256, 256);
     return b;
 }
 
@@ -414,6 +402,8 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     float* dW2_slab = (float*)w;
     w += align_up((size_t)gx * hidden * 4 * 4, 256);
     float* db2_part = (float*)w;
+    w += align_up((size_t)1024 * 4 * 4, 256);
+    float* rtmp = (float*)w;
 
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
@@ -423,26 +413,21 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                        W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd");
     // fixed-order reductions
-    {
-        const size_t cnt = (size_t)n * cin;
-        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, dx_slab, gy, cnt, cin, cin,
-                           dx);
-    }
-    {
-        const size_t cnt = (size_t)cin * hidden;
-        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv((int)cnt, 256)), dim3(256), 0, dW1_slab, gx, cnt, hidden,
-                           hidden, dW1);
-    }
-    FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv(hidden, 256)), dim3(256), 0, db1_slab, gx, (size_t)hidden,
-                       hidden, hidden, db1);
-    FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(cdiv(hidden * 4, 256)), dim3(256), 0, dW2_slab, gx,
-                       (size_t)hidden * 4, 4, cout, dW2);
+    int rc = reduce_slabs("reduce:mlp_dx", dx_slab, gy, (size_t)n * cin, cin, cin, dx, rtmp, st);
+    if (rc) return rc;
+    rc = reduce_slabs("reduce:mlp_dW1", dW1_slab, gx, (size_t)cin * hidden, hidden, hidden, dW1, rtmp, st);
+    if (rc) return rc;
+    rc = reduce_slabs("reduce:mlp_db1", db1_slab, gx, (size_t)hidden, hidden, hidden, db1, rtmp, st);
+    if (rc) return rc;
+    rc = reduce_slabs("reduce:mlp_dW2", dW2_slab, gx, (size_t)hidden * 4, 4, cout, dW2, rtmp, st);
+    if (rc) return rc;
     // db2 = column sums of dy
     {
         const int nb = n < 1024 * 64 ? cdiv(n, 64) : 1024;
         const int rpb = cdiv(n, nb);
         FGC_LAUNCH("colsum_stage1_kernel", st, colsum_stage1_kernel, dim3(nb), dim3(64), 0, dy, n, cout, rpb, db2_part);
-        FGC_LAUNCH("reduce_slabs_kernel", st, reduce_slabs_kernel, dim3(1), dim3(64), 0, db2_part, nb, (size_t)cout, cout, cout, db2);
+        rc = reduce_slabs("reduce:mlp_db2", db2_part, nb, (size_t)cout, cout, cout, db2, rtmp, st);
+        if (rc) return rc;
     }
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/reduce");
     return FGC_OK;
