@@ -13,7 +13,9 @@
 //         dx_j     = r_j W  (f32 MFMA) + da_j u + dg_j v ; 4:1 row sum when the input was upsampled
 //   K3  reductions over nodes (f32 MFMA, K = nodes):  dW0 = r^T x,  [du; dv] = dag^T x ; db, dc column sums
 // No float atomics anywhere: every sum has a fixed order, results are bitwise reproducible.
-#include "fgc_conv_core.h"
+#include <stdlib.h>
+
+#include "fgc_conv_pc.h"
 #include "fgc_reduce.h"
 
 namespace fgc {
@@ -276,22 +278,193 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p,
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1, matrix-core form (wide layers: 32-channel passes, float4 rows, degree <= 24).
+// The per-edge products dq[m][k] = <dz_i[m,:], x_j(k)> of one node are a [9 x 32] x [32 x d] matrix product: the
+// wave that owns the node issues it as 16x16x4 MFMAs (rows = m, columns = the node's edges, K = channels):
+//   A fragment  dz_i[m = lane&15][cb + 4*(lane>>4) .. +3]        one ds_read_b128 from the dz tile
+//   B fragment  x_j(k = lane&15)[cb + 4*(lane>>4) .. +3]         one global dwordx4 per lane (64 B per edge)
+// so the VALU only does the softmax and its backward; no per-edge FMA chains, no butterfly per edge.
+// ---------------------------------------------------------------------------------------------
+constexpr int NPW = TILE / 4;  // nodes per wave
+
+__global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CoreParams p, LogitParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw, p.zstride);
+    float* dst = s.extra;                       // ds tile [TILE][ostride]
+    float* red = dst + TILE * lp.ostride;       // [4][12]
+    const int tile0 = blockIdx.x * TILE;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+
+    for (int t = tid; t < TILE * lp.opad; t += NTHREADS) {
+        const int r = t / lp.opad, o = t % lp.opad;
+        const int i = tile0 + r;
+        dst[r * lp.ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
+    }
+    softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
+    __syncthreads();
+
+    const int nct = p.kpass >> 4;   // 18
+    const int okg = lp.opad >> 4;
+    const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
+
+    f32x4 dq[NPW][2];               // [node of this wave][edge tile 0..15 / 16..31]
+#pragma unroll
+    for (int nn = 0; nn < NPW; ++nn) {
+        dq[nn][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dq[nn][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int mrow = lr < FGC_M ? lr : FGC_M - 1;  // rows 9..15 of the product are never read
+
+    for (int pass = 0; pass < p.passes; ++pass) {
+        // ---- dz tile = ds tile x Wq[pass] (f32 MFMA) -> LDS
+        {
+            f32x4 acc[RT][K1_CTW];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < okg; ++g) {
+                f32x4 a[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * lp.ostride + g * 16 + lq * 4);
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c) {
+                    const int ct = min(wave + c * 4, nct - 1);
+                    const f32x4 b = Wq4[((size_t)pass * (lp.opad >> 2) + g * 4 + lq) * p.kpass + ct * 16 + lr];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r)
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r][c], 0, 0, 0);
+                }
+            }
+            if (pass > 0) __syncthreads();  // the previous pass' readers of ztile are done
+#pragma unroll
+            for (int c = 0; c < K1_CTW; ++c) {
+                const int ct = wave + c * 4;
+                if (ct >= nct) continue;
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        s.ztile[(size_t)(r * 16 + lq * 4 + t) * p.zstride + ct * 16 + lr] = acc[r][c][t];
+            }
+        }
+        __syncthreads();
+        // ---- per node: dq += dz_i (9 x 32) . X_i (32 x d)
+        const int cpass = pass * p.kc;
+        auto rowof = [&](int node, int d, int et) {
+            const int e = min(et * 16 + lr, d - 1);
+            return __float_as_int(s.qbuf[((size_t)node * KMAX + e) * QLD + 9]);
+        };
+        f32x4 bc[2], bn[2];
+        {
+            const int node = wave * NPW;
+            const int d = __builtin_amdgcn_readfirstlane(min(s.deg[node], KMAX));
+            const int row = d > 0 ? rowof(node, d, 0) : 0;
+            bc[0] = load_chunk<true>(p, row, cpass + 4 * lq);
+            bc[1] = load_chunk<true>(p, row, cpass + 16 + 4 * lq);
+        }
+#pragma unroll
+        for (int nn = 0; nn < NPW; ++nn) {
+            const int node = wave * NPW + nn;
+            const int d = __builtin_amdgcn_readfirstlane(min(s.deg[node], KMAX));
+            if (nn + 1 < NPW) {  // next node's rows are requested before this node's MFMAs
+                const int nd = __builtin_amdgcn_readfirstlane(min(s.deg[node + 1], KMAX));
+                const int row = nd > 0 ? rowof(node + 1, nd, 0) : 0;
+                bn[0] = load_chunk<true>(p, row, cpass + 4 * lq);
+                bn[1] = load_chunk<true>(p, row, cpass + 16 + 4 * lq);
+            }
+            const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(zr + 16);
+            if (d > 0) {
+                f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {  // two independent accumulation chains
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], bc[0][t], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], bc[1][t], t1, 0, 0, 0);
+                }
+                dq[nn][0] += t0 + t1;
+                if (d > 16) {  // rare: 17..24 neighbours
+                    const int row = rowof(node, d, 1);
+                    const f32x4 x0 = load_chunk<true>(p, row, cpass + 4 * lq);
+                    const f32x4 x1 = load_chunk<true>(p, row, cpass + 16 + 4 * lq);
+                    f32x4 u0 = f32x4{0.f, 0.f, 0.f, 0.f}, u1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], x0[t], u0, 0, 0, 0);
+                        u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], x1[t], u1, 0, 0, 0);
+                    }
+                    dq[nn][1] += u0 + u1;
+                }
+            }
+            bc[0] = bn[0];
+            bc[1] = bn[1];
+        }
+    }
+
+    // ---- softmax backward: lane (edge = lr, m0 = 4*lq) holds dq[m0..m0+3][edge]
+    f32x4 dcacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nn = 0; nn < NPW; ++nn) {
+        const int node = wave * NPW + nn;
+        const int i = tile0 + node;
+        const int d = __builtin_amdgcn_readfirstlane(min(s.deg[node], KMAX));
+        f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d > 0 && i < p.n) {
+            const int e0 = p.rowptr[i];
+            const int ntile = d > 16 ? 2 : 1;
+            for (int et = 0; et < ntile; ++et) {
+                const int edge = et * 16 + lr;
+                const bool ok = edge < d;
+                const float* qr = s.qbuf + ((size_t)node * KMAX + min(edge, d - 1)) * QLD;
+                f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
+                else if (lq == 2) q[0] = qr[8];
+                f32x4 g = et == 0 ? dq[nn][0] : dq[nn][1];
+                if (lq == 2) { g[1] = 0.f; g[2] = 0.f; g[3] = 0.f; }
+                if (lq == 3) g = f32x4{0.f, 0.f, 0.f, 0.f};
+                float dot = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
+                dot += __shfl_xor(dot, 16);
+                dot += __shfl_xor(dot, 32);
+                f32x4 dl;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dl[t] = ok ? q[t] * (g[t] - dot) : 0.f;
+                if (ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = dl;
+                da += dl;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = da[t];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                da[t] = v;
+            }
+        }
+        if (i < p.n && lr == 0 && lq < 3) *reinterpret_cast<f32x4*>(lp.dag + (size_t)i * FGC_AG_LD + 4 * lq) = da;
+        dcacc += da;
+    }
+    // dc partial of this workgroup: lanes lr == 0 hold the per-wave sums (m0 = 4*lq)
+    __syncthreads();
+    if (lr == 0 && lq < 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[wave * 12 + 4 * lq + t] = dcacc[t];
+    }
+    __syncthreads();
+    if (tid < 12) {
+        const float v = tid < FGC_M ? (red[tid] + red[12 + tid]) + (red[24 + tid] + red[36 + tid]) : 0.f;
+        lp.dc_part[(size_t)blockIdx.x * 12 + tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2: data gradient = forward core over the transposed graph
 // ---------------------------------------------------------------------------------------------
-struct DataEpilogue {
-    const float* dl;      // [nnz, 12]
-    float* dag;           // reads 0..8 (da), writes 12..20 (dg)
-    float* r;             // [n, 9*cout]
-    int rld;              // 9*cout
-    const float* u;       // [9, cin]
-    const float* v;       // [9, cin]
-    int cin, c0f, c1f;    // forward input split
-    int shiftf;           // forward input shift (0 / 2)
-    float* dx0;
-    float* dx1;
-    int acc0, acc1;
-};
-
 template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, DataEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -299,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
     float* dagt = s.extra;  // [TILE][24]: da | dg of the tile's nodes
     const int tile0 = blockIdx.x * TILE;
     const int tid = threadIdx.x;
-    const WaveTiling wt = wave_tiling(p.npad);
+    const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 
     float dgsum[FGC_M];
 #pragma unroll
@@ -486,22 +659,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 a, b, an, bn;
-    int s = wave;
-    {
-        const int row = r_begin + 4 * s + lq;
-        tn_load<VEC4>(A, lda, P, x0, x1, c0, c1, shift, row, s < nsteps && row < r_end, pbase, qbase, a, b);
-    }
-    for (; s < nsteps; s += 4) {
-        const int sn = s + 4;
-        const int rown = r_begin + 4 * sn + lq;
-        tn_load<VEC4>(A, lda, P, x0, x1, c0, c1, shift, rown, sn < nsteps && rown < r_end, pbase, qbase, an, bn);
+    // two operand register sets with fixed roles (unrolled by 2, no copies of in-flight loads)
+    f32x4 a0, b0, a1, b1;
+    auto ld = [&](int step, f32x4& a, f32x4& b) {
+        const int row = r_begin + 4 * step + lq;
+        tn_load<VEC4>(A, lda, P, x0, x1, c0, c1, shift, row, step < nsteps && row < r_end, pbase, qbase, a, b);
+    };
+    auto mm = [&](const f32x4& a, const f32x4& b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        a = an;
-        b = bn;
+    };
+    ld(wave, a0, b0);
+    ld(wave + 4, a1, b1);
+    for (int s = wave; s < nsteps; s += 8) {
+        mm(a0, b0);
+        ld(s + 8, a0, b0);
+        if (s + 4 < nsteps) mm(a1, b1);
+        ld(s + 12, a1, b1);
     }
     // C layout of acc[i][j]: column index lr -> q = 4*lr + j ; row index lq*4+reg -> p = 4*(lq*4+reg) + i
 #pragma unroll
@@ -663,6 +839,19 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         LogitParams lp{io->ds, cout, opad, ostride, w.Wq, io->dl, io->dag, w.dc_part};
         const size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
         const bool vec4 = conv_vec4_ok(d);
+        if (g1.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX &&
+            !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1')) {
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute((const void*)conv_bwd_logits_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024);
+                attr = true;
+            }
+            FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, conv_bwd_logits_mfma_kernel, dim3(cdiv(d->n, TILE)),
+                       dim3(NTHREADS), smem, p, lp);
+            FGC_CHECK_LAUNCH("fgc_conv_bwd/logits_mfma");
+            rc = 0;
+        } else
         switch (g1.lpn) {
             case 2: rc = launch_logits<2>(p, lp, vec4, smem, st); break;
             case 4: rc = launch_logits<4>(p, lp, vec4, smem, st); break;
@@ -681,6 +870,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
+        if (g2.lpn == 8 && vec4 && io->max_in_deg > 0 && io->max_in_deg <= KMAX && !(getenv("FGC_NO_PC") && getenv("FGC_NO_PC")[0] == '1')) {
+            rc = launch_data_pc(p, ep, g2, st);
+            if (rc) return rc;
+        } else
         switch (g2.lpn) {
             case 2: rc = launch_data<2>(p, ep, vec4, smem, st); break;
             case 4: rc = launch_data<4>(p, ep, vec4, smem, st); break;

@@ -166,6 +166,34 @@ __device__ __forceinline__ f32x4 load_chunk(const CoreParams& p, int row, int cb
     return v;
 }
 
+// ---- row batches: all gathers of a node are issued before the first FMA (one memory round trip per pass) ------
+constexpr int RB = 16;  // rows held in registers at once (degree 13 on a closed valence-6 mesh; K_faces = 23 max)
+
+template <bool VEC4>
+__device__ __forceinline__ void load_rows(const CoreParams& p, const float* qb, int d, int k0, int cbase,
+                                          f32x4 (&xv)[RB]) {
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+        xv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k0 + t < d) xv[t] = load_chunk<VEC4>(p, __float_as_int(qb[(k0 + t) * QLD + 9]), cbase);
+    }
+}
+
+__device__ __forceinline__ void fma_rows(const float* qb, int d, int k0, const f32x4 (&xv)[RB], f32x4 (&z)[FGC_M]) {
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+        if (k0 + t < d) {
+            const float* q = qb + (k0 + t) * QLD;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
+            const float q8 = q[8];
+            z[0] += q0[0] * xv[t]; z[1] += q0[1] * xv[t]; z[2] += q0[2] * xv[t]; z[3] += q0[3] * xv[t];
+            z[4] += q1[0] * xv[t]; z[5] += q1[1] * xv[t]; z[6] += q1[2] * xv[t]; z[7] += q1[3] * xv[t];
+            z[8] += q8 * xv[t];
+        }
+    }
+}
+
 // ---- phase A: z[m][4] = sum_k q[k][m] * x_j(k)[4] ---------------------------------------------
 // thread (node, cl): node = tid / LPN (only the first TILE*LPN threads work), cl = tid % LPN
 // accumulates into z (caller zeroes it); covers the edge chunk currently held in qbuf
@@ -178,33 +206,10 @@ __device__ __forceinline__ void aggregate_pass(const CoreParams& p, const Smem& 
     const int d = min(max(s.deg[node] - kbase, 0), KMAX);
     const int cbase = pass * p.kc + cl * 4;
     const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
-    // batches of 4 neighbour rows; the next batch's global loads are issued before the current batch's FMAs
-    f32x4 xc[4], xn[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        xc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t < d) xc[t] = load_chunk<VEC4>(p, __float_as_int(qb[t * QLD + 9]), cbase);
-    }
-    for (int k = 0; k < d; k += 4) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            xn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (k + 4 + t < d) xn[t] = load_chunk<VEC4>(p, __float_as_int(qb[(k + 4 + t) * QLD + 9]), cbase);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (k + t < d) {
-                const float* q = qb + (k + t) * QLD;
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
-                const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
-                const float q8 = q[8];
-                z[0] += q0[0] * xc[t]; z[1] += q0[1] * xc[t]; z[2] += q0[2] * xc[t]; z[3] += q0[3] * xc[t];
-                z[4] += q1[0] * xc[t]; z[5] += q1[1] * xc[t]; z[6] += q1[2] * xc[t]; z[7] += q1[3] * xc[t];
-                z[8] += q8 * xc[t];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) xc[t] = xn[t];
+    for (int k0 = 0; k0 < d; k0 += RB) {
+        f32x4 xv[RB];
+        load_rows<VEC4>(p, qb, d, k0, cbase, xv);
+        fma_rows(qb, d, k0, xv, z);
     }
 }
 
@@ -233,8 +238,7 @@ __device__ __forceinline__ void zero_zpad(const CoreParams& p, const Smem& s) {
 struct WaveTiling {
     int ct0, ctstep, kparts, kpart;
 };
-__device__ __forceinline__ WaveTiling wave_tiling(int npad) {
-    const int w = threadIdx.x >> 6;
+__device__ __forceinline__ WaveTiling wave_tiling(int npad, int w) {
     const int nct = npad >> 4;
     WaveTiling t;
     t.kparts = nct >= 3 ? 1 : (nct == 2 ? 2 : 4);
@@ -254,47 +258,82 @@ __device__ __forceinline__ void gemm_pass(const CoreParams& p, const Smem& s, in
     const int lr = lane & 15, lq = lane >> 4;
     const int nct = p.npad >> 4;
     const int kg_total = p.kpass >> 4;
-    const int kg0 = kg_total * wt.kpart / wt.kparts;
-    const int kg1 = kg_total * (wt.kpart + 1) / wt.kparts;
+    // wave-uniform by construction; readfirstlane makes that provable, so the k loop is a scalar loop (no exec
+    // masking) and the compiler can emit counted s_waitcnt vmcnt(N) for the fragment ring instead of vmcnt(0)
+    const int kg0 = __builtin_amdgcn_readfirstlane(kg_total * wt.kpart / wt.kparts);
+    const int kg1 = __builtin_amdgcn_readfirstlane(kg_total * (wt.kpart + 1) / wt.kparts);
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(p.Wp);
     const size_t wrow0 = (size_t)pass * (p.kpass >> 2);
     bool ctv[CTW];
 #pragma unroll
-    for (int c = 0; c < CTW; ++c) ctv[c] = (wt.ct0 + c * wt.ctstep) < nct;
+    for (int c = 0; c < CTW; ++c)
+        ctv[c] = __builtin_amdgcn_readfirstlane((wt.ct0 + c * wt.ctstep) < nct ? 1 : 0) != 0;  // wave-uniform
     if (!ctv[0]) return;
     // B fragments (packed weights, L2 resident) are fetched two k-groups ahead of the MFMAs that consume them
+    // UNCONDITIONAL loads (indices clamped into the packed operand): a load inside an exec-masked branch makes
+    // hipcc fall back to s_waitcnt vmcnt(0), which would drain the whole prefetch ring at every k-group
     auto loadb = [&](int g, f32x4 (&b)[CTW]) {
+        const int gg = min(g, kg1 - 1);
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
-            b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ctv[c] && g < kg1) b[c] = Wp4[(wrow0 + g * 4 + lq) * p.npad + (wt.ct0 + c * wt.ctstep) * 16 + lr];
+            const int ct = min(wt.ct0 + c * wt.ctstep, nct - 1);
+            b[c] = Wp4[(wrow0 + gg * 4 + lq) * p.npad + ct * 16 + lr];
         }
     };
-    f32x4 b0[CTW], b1[CTW], b2[CTW];
-    loadb(kg0, b0);
-    loadb(kg0 + 1, b1);
-    for (int g = kg0; g < kg1; ++g) {
-        loadb(g + 2, b2);
-        f32x4 a[RT];
+    // Four fragment buffers with FIXED roles (the loop is unrolled by 4, no register copies: a copy of a
+    // just-requested fragment would make the compiler wait for it).  Buffer u is refilled for k-group g+4 right
+    // after its MFMAs were issued, i.e. three k-groups (>= 768 MFMA cycles) before it is needed again.
+    f32x4 b[4][CTW];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) loadb(kg0 + u, b[u]);
+    auto loada = [&](int g, f32x4 (&a)[RT]) {
+        const int gg = min(g, kg1 - 1);
 #pragma unroll
         for (int r = 0; r < RT; ++r)
-            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + g * 16 + lq * 4);
+            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + gg * 16 + lq * 4);
+    };
+    auto mm = [&](const f32x4 (&a)[RT], const f32x4 (&bb)[CTW]) {
 #pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-            if (!ctv[c]) continue;
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int r = 0; r < RT; ++r) {
+            for (int c = 0; c < CTW; ++c) {
+                if (!ctv[c]) continue;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b0[c][t], acc[r][c], 0, 0, 0);
+                for (int r = 0; r < RT; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], bb[c][t], acc[r][c], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-            b0[c] = b1[c];
-            b1[c] = b2[c];
-        }
+    };
+    // steady state: whole groups of four, nothing conditional inside (every path issues the same loads, so the
+    // compiler's s_waitcnt bookkeeping can count them); the A fragments (LDS) run one k-group ahead in two
+    // alternating register sets
+    f32x4 a0[RT], a1[RT];
+    int g = kg0;
+    loada(g, a0);
+    for (; g + 4 <= kg1; g += 4) {
+        loada(g + 1, a1);
+        mm(a0, b[0]);
+        loadb(g + 4, b[0]);
+        loada(g + 2, a0);
+        mm(a1, b[1]);
+        loadb(g + 5, b[1]);
+        loada(g + 3, a1);
+        mm(a0, b[2]);
+        loadb(g + 6, b[2]);
+        loada(g + 4, a0);
+        mm(a1, b[3]);
+        loadb(g + 7, b[3]);
     }
+    // remainder (< 4 k-groups): their B fragments are already in b[0..2], a0 holds group g
+    if (g < kg1) {
+        loada(g + 1, a1);
+        mm(a0, b[0]);
+    }
+    if (g + 1 < kg1) {
+        loada(g + 2, a0);
+        mm(a1, b[1]);
+    }
+    if (g + 2 < kg1) mm(a0, b[2]);
 }
 
 // accumulators -> LDS out tile [kparts][TILE][oldd]; caller must have synchronised so that

@@ -1,5 +1,7 @@
 // Forward graph convolution (replaces custom_conv2d, /root/reference/Code/model.py:427-504).
-#include "fgc_conv_core.h"
+#include <stdlib.h>
+
+#include "fgc_conv_pc.h"
 
 namespace fgc {
 
@@ -90,21 +92,12 @@ __global__ __launch_bounds__(256) void proj_kernel(const float* __restrict__ x0,
 // ---------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------
-struct FwdEpilogue {
-    const float* bias;
-    int bias_mask;
-    int act;
-    float alpha;
-    float* y;
-    float* y_pool;
-};
-
 template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(CoreParams p, FwdEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
     const int tile0 = blockIdx.x * TILE;
-    const WaveTiling wt = wave_tiling(p.npad);
+    const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 
     const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
     zero_zpad(p, s);
@@ -287,6 +280,8 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FwdEpilogue ep{d->b, d->bias_mask, d->act, d->alpha, y, y_pool};
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
+    if (g.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX && !(getenv("FGC_NO_PC") && getenv("FGC_NO_PC")[0] == '1'))
+        return launch_fwd_pc(p, ep, g, st);
     switch (g.lpn) {
         case 2: return launch_fwd<2>(p, ep, vec4, smem, st);
         case 4: return launch_fwd<4>(p, ep, vec4, smem, st);

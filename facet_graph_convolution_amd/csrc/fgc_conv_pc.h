@@ -1,0 +1,34 @@
+// Producer/consumer variant of the fused conv core for the wide layers (LPN = 8, float4 rows).
+#pragma once
+#include "fgc_conv_core.h"
+
+namespace fgc {
+
+struct FwdEpilogue {
+    const float* bias;
+    int bias_mask;
+    int act;
+    float alpha;
+    float* y;
+    float* y_pool;
+};
+
+struct DataEpilogue {
+    const float* dl;      // [nnz, 12]
+    float* dag;           // reads 0..8 (da), writes 12..20 (dg)
+    float* r;             // [n, 9*cout]
+    int rld;              // 9*cout
+    const float* u;       // [9, cin]
+    const float* v;       // [9, cin]
+    int cin, c0f, c1f;    // forward input split
+    int shiftf;           // forward input shift (0 / 2)
+    float* dx0;
+    float* dx1;
+    int acc0, acc1;
+};
+
+size_t pc_smem_bytes(const ConvGeom& g);
+int launch_fwd_pc(const CoreParams& p, const FwdEpilogue& ep, const ConvGeom& g, hipStream_t st);
+int launch_data_pc(const CoreParams& p, const DataEpilogue& ep, const ConvGeom& g, hipStream_t st);
+
+}  // namespace fgc

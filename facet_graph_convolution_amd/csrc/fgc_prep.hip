@@ -371,6 +371,52 @@ extern "C" int fgc_hierarchy_build(const int32_t* adj, int32_t n, int32_t K, con
             std::stable_sort(rid.begin(), rid.end(), [&](int64_t a, int64_t b) { return ss[a] < ss[b]; });
         }
     }
+    if (!parents_in) {
+        // Spatial order of the coarsest clusters (Morton code of their centroid).  The reference leaves that order
+        // to the pairing ("Order of last layer is random", coarsening.py:200); every finer level inherits it through
+        // the binary tree, so consecutive 16-node blocks become spatial neighbours: the gather of a tile then hits
+        // rows its neighbours just fetched (L1/L2), and a contiguous split of the node range is a compact patch
+        // (what facet sharding across GPUs needs).  Results are identical up to this relabelling.
+        const int L = levels;
+        std::vector<int> top(n);
+        for (int i = 0; i < n; ++i) {
+            int c = i;
+            for (int l = 0; l < L; ++l) c = h.parents[l][c];
+            top[i] = c;
+        }
+        const int nc = h.graphs[L].n;
+        std::vector<double> cen(3 * (size_t)nc, 0.0);
+        std::vector<int> cnt(nc, 0);
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; ++i) {
+            for (int t = 0; t < 3; ++t) {
+                cen[3 * (size_t)top[i] + t] += pos[3 * (size_t)i + t];
+                mn[t] = std::min(mn[t], pos[3 * (size_t)i + t]);
+                mx[t] = std::max(mx[t], pos[3 * (size_t)i + t]);
+            }
+            cnt[top[i]]++;
+        }
+        std::vector<uint64_t> code(nc);
+        for (int c = 0; c < nc; ++c) {
+            uint64_t m = 0;
+            uint32_t q[3];
+            for (int t = 0; t < 3; ++t) {
+                const double v = cnt[c] ? cen[3 * (size_t)c + t] / cnt[c] : 0.0;
+                const double u = mx[t] > mn[t] ? (v - mn[t]) / (mx[t] - mn[t]) : 0.0;
+                q[t] = (uint32_t)std::min(1023.0, std::max(0.0, u * 1023.0));
+            }
+            for (int b = 9; b >= 0; --b)
+                for (int t = 0; t < 3; ++t) m = (m << 1) | ((q[t] >> b) & 1u);
+            code[c] = m;
+        }
+        std::vector<int> order(nc);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code[a] < code[b]; });
+        std::vector<int> rank(nc);
+        for (int r = 0; r < nc; ++r) rank[order[r]] = r;
+        for (auto& v : h.parents[L - 1]) v = rank[v];
+        coarsen_graph(h.graphs[L - 1], h.parents[L - 1], h.graphs[L]);
+    }
     compute_perm(h.parents, h.perms);
     *out = H;
     return FGC_OK;

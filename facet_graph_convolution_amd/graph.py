@@ -71,6 +71,8 @@ class FacetGraph:
         self.n = self.klist_shape[0]
         self.K = self.klist_shape[1]
         self.nnz = int(self.rowptr_h[-1])
+        self.max_deg = int(np.diff(self.rowptr_h).max()) if self.n else 0
+        self.max_in_deg = int(np.bincount(self.col_h, minlength=1).max()) if self.nnz else 0
         self.device = torch.device(device)
         self.rowptr = torch.from_numpy(self.rowptr_h).to(self.device)
         self.col = torch.from_numpy(np.ascontiguousarray(self.col_h) if self.nnz else np.zeros(1, np.int32)).to(

@@ -222,12 +222,14 @@ class FacetDenoiser:
             d.shift, d.cout = lay.shift, W0.shape[1]
             d.W0, d.b, d.u, d.c, d.v = (t.data_ptr() for t in (W0, b, u, c, v))
             d.bias_mask, d.act, d.alpha = 1, lay.act, LRELU_ALPHA
+            d.max_deg = g.max_deg
             descs[lay.name] = d
             ws_f = max(ws_f, self.L.fgc_conv_workspace_bytes(C.byref(d)))
             ws_b = max(ws_b, self.L.fgc_conv_bwd_workspace_bytes(C.byref(d)))
             trow, tcol, tedge = g.transposed()
             io = ConvBwdIO()
             io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
+            io.max_in_deg = g.max_in_deg
             io.ag, io.y, io.dy = B["ag_" + lay.name].data_ptr(), B[lay.y].data_ptr(), B["g_" + lay.y].data_ptr()
             io.ds, io.dl, io.dag, io.r = (B[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
             gW0, gb, gu, gc, gv = grads[lay.pidx:lay.pidx + 5]

@@ -53,6 +53,7 @@ def make_conv_desc(graph, x0, x1, shift, params, bias_mask, act, alpha):
     d.bias_mask = int(bool(bias_mask))
     d.act = int(act)
     d.alpha = float(alpha)
+    d.max_deg = graph.max_deg
     return d
 
 
@@ -113,6 +114,7 @@ def conv_bwd(graph, x0, x1, shift, params, ag, y, dy, bias_mask=True, act=0, alp
         dx0 = dx1 = None
     io = ConvBwdIO()
     io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
+    io.max_in_deg = graph.max_in_deg
     io.ag, io.y, io.dy = ag.data_ptr(), (y.data_ptr() if y is not None else None), dy.data_ptr()
     io.ds, io.dl, io.dag, io.r = ds.data_ptr(), dl.data_ptr(), dag.data_ptr(), r.data_ptr()
     io.dx0 = dx0.data_ptr() if dx0 is not None else None

@@ -132,6 +132,8 @@ typedef struct fgc_conv_desc {
     int32_t bias_mask;      /* model.py:496-500 */
     int32_t act;
     float alpha;
+    int32_t max_deg;        /* max_i deg(i) if the caller knows it, else 0.  <= 24 (every reference K-list) enables
+                               the producer/consumer kernels; 0 or larger falls back to the edge-chunking path */
 } fgc_conv_desc;
 
 /* bytes of scratch the conv entry points need for this descriptor (packed weights) */
@@ -154,6 +156,7 @@ typedef struct fgc_conv_bwd_io {
     const int32_t* trowptr; /* [n+1] */
     const int32_t* tcol;    /* [nnz] */
     const int32_t* tedge;   /* [nnz] */
+    int32_t max_in_deg;     /* max in-degree of the transposed graph if known, else 0 (see max_deg) */
     const float* ag;        /* saved by forward */
     const float* y;         /* forward output (post activation) */
     const float* dy;        /* [n, cout] */
