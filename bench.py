@@ -11,9 +11,12 @@ Workload (BASELINE.json configs[1]): torus 250 x 200 quads = 100 000 facets (SUR
 preprocessed natively (adjacency + 4 pairing levels + binary-tree order) before the timed region;
 everything is resident in HBM when the clock starts.
 
-N > 1: one process per GPU (torchrun), each rank trains on its own 100k-facet mesh (different noise
-seed) and the flat fp32 gradient (1.9 MB) is averaged with ONE RCCL all-reduce per step ("weak" scaling).
-The single-mesh facet-sharded path with per-layer halo exchange is not built yet.
+N > 1: one process per GPU (torchrun).  Default (--mode shard): ONE mesh of N x 100 000 facets (torus
+250N x 200) is facet-sharded over the N GPUs (shard.py): each rank owns a contiguous range of the coarsest
+graph level and everything under it, halo rows are exchanged by RCCL all-to-all before every conv (and
+s = dy/deg rows plus cross-edge d-logits in backward), the flat fp32 gradient is all-reduced once per
+step.  Per-GPU work is fixed as N grows ("weak" scaling); --scaling strong shards the 100k mesh instead.
+--mode replicas: each rank trains on its own 100k-facet mesh, gradient all-reduce only.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      dominant kernel's achieved TFLOP/s from hipEvent timings taken live in this process
@@ -105,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", type=str, default="", help="write the full per-kernel table to this file")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="multi-GPU decomposition")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     args = ap.parse_args()
 
     import torch
@@ -115,26 +120,53 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
                          (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FGC_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (host-staged exchange)
+    backend = os.environ.get("FGC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(ndev, 1) if backend == "gloo" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from facet_graph_convolution_amd.net import FacetDenoiser
     from facet_graph_convolution_amd.utils import rand_rotation_matrix
 
-    ds, F = build_mesh(args.nu, args.nv, seed=rank)
-    net = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
-    n0 = ds.in_list[0].shape[1]
-    rs = np.random.RandomState(100 + rank)
+    shard = world > 1 and args.mode == "shard"
+    if shard:
+        from facet_graph_convolution_amd.shard import ShardPlan, DistComm, graphs_to_host_csr
+        nu = args.nu * world if args.scaling == "weak" else args.nu
+        ds, F_total = build_mesh(nu, args.nv, seed=0)          # every rank builds the same mesh (seeded)
+        plan = ShardPlan(graphs_to_host_csr(ds.adj_list[0]), rank, world)
+        net = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0], plan=plan,
+                                                   comm=DistComm())
+        n0 = ds.in_list[0].shape[1]            # samples are drawn over the WHOLE mesh, same stream on every rank
+        rs = np.random.RandomState(100)
+        F = F_total / world                    # facets per GPU (for the per-GPU accounting below)
+        halo_frac = [net._mesh["nh"][l] / max(net._mesh["ns"][l], 1) for l in range(3)]
+    else:
+        ds, F = build_mesh(args.nu, args.nv, seed=rank)
+        F_total = F * world
+        net = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+        n0 = ds.in_list[0].shape[1]
+        rs = np.random.RandomState(100 + rank)
+        halo_frac = None
 
     def step():
         net.set_samples(rs.randint(n0, size=4000))
         net.set_rotation(rand_rotation_matrix(randnums=rs.uniform(size=3)))
-        net.forward_backward(rotate=True, capture=bool(args.graph))
-        if world > 1:
-            dist.all_reduce(net.params.grad, op=dist.ReduceOp.AVG)
+        net.forward_backward(rotate=True, capture=bool(args.graph) and not shard)
+        if world > 1 and not shard:
+            if backend == "nccl":
+                dist.all_reduce(net.params.grad, op=dist.ReduceOp.AVG)
+            else:
+                g = net.params.grad.cpu()
+                dist.all_reduce(g)
+                net.params.grad.copy_(g / world)
         net.adam_step()
 
     def sync_barrier():
@@ -152,7 +184,7 @@ def main():
     sync_barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss = net.buffers["loss"][0].item()
@@ -164,10 +196,12 @@ def main():
         net.forward(rotate=False)
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3
+    if world > 1:
+        dist.barrier()
 
     roofline = None
     kernels = {}
-    if not args.no_roofline:
+    if not args.no_roofline and not shard:
         # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
         # `steps` eager steps of the same work as the timed region
         net.profile_start()
@@ -223,24 +257,29 @@ def main():
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "facets/sec (fwd+bwd) on 100k-facet mesh",
-            "value": world * F * args.steps / dt,
+            "value": F_total * args.steps / dt,
             "unit": "facets/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (shard and args.scaling == "strong") else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "torus %dx%d quads = %d facets per GPU (N0=%d padded nodes), full graph U-Net + MLP: "
+            "config": {"workload": "torus %dx%d quads = %d facets per GPU (N0=%d padded nodes%s), full graph U-Net + MLP: "
                                    "rotate + forward + angular loss + backward + Adam, fp32%s" %
-                                   (args.nu, args.nv, F, n0, ", hipGraph replay" if args.graph else ""),
-                       "parallelism": "1 mesh per GPU, flat-gradient all-reduce" if world > 1 else "single GPU"},
+                                   (args.nu, args.nv, int(F), n0, " in the whole mesh" if shard else "",
+                                    ", hipGraph replay" if (args.graph and not shard) else ""),
+                       "parallelism": ("single GPU" if world == 1 else
+                                       ("one %d-facet mesh facet-sharded over %d GPUs, halo all-to-all per conv + flat-gradient "
+                                        "all-reduce (halo/owned rows per level on rank 0: %s)" %
+                                        (F_total, world, ", ".join("%.3f" % h for h in halo_frac))) if shard else
+                                       "1 mesh per GPU, flat-gradient all-reduce")},
             "loss_deg": loss,
             "forward_only_ms": fwd_ms,
-            "forward_only_facets_per_s": F / (fwd_ms * 1e-3),
+            "forward_only_facets_per_s": F_total / (fwd_ms * 1e-3),
             "hbm_roofline_frac_whole_step": fb_b / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),
             "algorithmic_bytes_fwd_bwd": fb_b,
             "roofline": roofline,

@@ -27,13 +27,13 @@ class ConvDesc(C.Structure):
         ("x0", C.c_void_p), ("x1", C.c_void_p),
         ("c0", C.c_int32), ("c1", C.c_int32), ("shift", C.c_int32), ("cout", C.c_int32),
         ("W0", C.c_void_p), ("b", C.c_void_p), ("u", C.c_void_p), ("c", C.c_void_p), ("v", C.c_void_p),
-        ("bias_mask", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("max_deg", C.c_int32),
+        ("bias_mask", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("src_rows", C.c_int32), ("max_deg", C.c_int32),
     ]
 
 
 class ConvBwdIO(C.Structure):
     _fields_ = [
-        ("trowptr", C.c_void_p), ("tcol", C.c_void_p), ("tedge", C.c_void_p), ("max_in_deg", C.c_int32),
+        ("trowptr", C.c_void_p), ("tcol", C.c_void_p), ("tedge", C.c_void_p), ("max_in_deg", C.c_int32), ("stages", C.c_int32),
         ("ag", C.c_void_p), ("y", C.c_void_p), ("dy", C.c_void_p),
         ("ds", C.c_void_p), ("dl", C.c_void_p), ("dag", C.c_void_p), ("r", C.c_void_p),
         ("dx0", C.c_void_p), ("dx1", C.c_void_p),
@@ -88,6 +88,10 @@ _SIGS = {
     "fgc_normalize_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "fgc_normalize_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_normalize_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_normalize_bwd_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
+    "fgc_normalize_bwd_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgc_angular_loss_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "fgc_angular_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_float, C.c_void_p, C.c_void_p]),

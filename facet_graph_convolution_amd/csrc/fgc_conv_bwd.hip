@@ -811,8 +811,9 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const int opad = (cout + 15) / 16 * 16;
     const int ostride = opad + 8;
 
+    const int stages = io->stages ? io->stages : 7;
     // s = dy*lrelu'(y)/deg, db partials
-    {
+    if (stages & 1) {
         int cp2 = 1;
         while (cp2 < cout) cp2 <<= 1;
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
@@ -822,7 +823,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         if (rc) return rc;
     }
     // operand packing
-    {
+    if (stages & 6) {
         const size_t tot = (size_t)g1.passes * opad * g1.kpass;
         FGC_LAUNCH("pack_logit_weight_kernel", st, pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, d->W0, w.Wq, cin, cout,
                            opad, g1.kc, g1.kpass, g1.passes);
@@ -832,7 +833,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
     }
     // K1
-    {
+    if (stages & 2) {
         CoreParams p;
         fill_core_params(p, g1, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, cout, io->ag,
                          d->shift, 0, 12, nullptr);
@@ -862,7 +863,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         if (rc) return rc;
     }
     // K2
-    {
+    if (stages & 4) {
         CoreParams p;
         fill_core_params(p, g2, d->n, io->trowptr, io->tcol, io->tedge, io->ds, nullptr, cout, 0, 0, cin, io->ag,
                          d->shift, 12, 0, w.Wpt);
@@ -870,7 +871,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
-        if (g2.lpn == 8 && vec4 && io->max_in_deg > 0 && io->max_in_deg <= KMAX && !(getenv("FGC_NO_PC") && getenv("FGC_NO_PC")[0] == '1')) {
+        if (g2.lpn == 8 && vec4 && io->max_in_deg > 0 && io->max_in_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1')) {
             rc = launch_data_pc(p, ep, g2, st);
             if (rc) return rc;
         } else
@@ -882,7 +883,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         if (rc) return rc;
     }
     // K3: dW0 = r^T x ; [du; dv] = dag^T x
-    {
+    if (stages & 4) {
         const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0) && ((uintptr_t)io->dag % 16 == 0);
         const int P = FGC_M * cout;
         int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;

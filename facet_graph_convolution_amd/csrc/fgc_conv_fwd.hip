@@ -269,7 +269,7 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, d->W0, Wp, cin, d->cout,
                        cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
     FGC_CHECK_LAUNCH("fgc_conv_fwd/pack");
-    const int rows = d->n >> d->shift;
+    const int rows = d->src_rows > 0 ? d->src_rows : (d->n >> d->shift);
     FGC_LAUNCH("proj_kernel", st, proj_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, d->x0, d->x1, d->c0, d->c1, rows, d->u,
                        d->c, d->v, ag);
     FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
@@ -280,7 +280,7 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FwdEpilogue ep{d->b, d->bias_mask, d->act, d->alpha, y, y_pool};
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
-    if (g.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX && !(getenv("FGC_NO_PC") && getenv("FGC_NO_PC")[0] == '1'))
+    if (g.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1'))
         return launch_fwd_pc(p, ep, g, st);
     switch (g.lpn) {
         case 2: return launch_fwd<2>(p, ep, vec4, smem, st);

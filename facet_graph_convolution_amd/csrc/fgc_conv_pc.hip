@@ -115,7 +115,7 @@ __device__ __forceinline__ void data_epilogue(const CoreParams& p, const DataEpi
 
 template <bool DATA>
 __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de,
-                                                               int ntiles, int otile_floats, unsigned long long* dbg) {
+                                                               int ntiles, int otile_floats) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const PcSmem S = pc_carve(smem_raw, p.zstride, otile_floats);
     const int tid = threadIdx.x;
@@ -145,11 +145,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, Fw
 #pragma unroll
     for (int t = 0; t < RB; ++t) xnext[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    unsigned long long tS = 0, tL = 0, tF = 0, tG = 0, tE = 0, tB1 = 0, tB2 = 0, t0 = 0, t1 = 0;
-#define STAMP(var) do { if (dbg) { t1 = __builtin_amdgcn_s_memtime(); var += t1 - t0; t0 = t1; } } while (0)
-    if (dbg) t0 = __builtin_amdgcn_s_memtime();
     for (int sidx = 0; sidx <= nitems; ++sidx) {
-        if (dbg) t0 = __builtin_amdgcn_s_memtime();
         if (producer) {
             if (sidx < nitems) {
                 const int ti = sidx / P, pass = sidx - ti * P;
@@ -199,7 +195,6 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, Fw
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    STAMP(tS);
                 }
                 f32x4 z[FGC_M];
 #pragma unroll
@@ -218,9 +213,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, Fw
                     }
                     have_next = pass + 1 < P;
                     if (have_next) load_rows<true>(p, qb, d, 0, cbase + p.kc, xnext);
-                    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(tL); }
                     fma_rows(qb, d, 0, xc, z);
-                    STAMP(tF);
                     if (d > RB) {  // rare: more than 16 neighbours
                         f32x4 xt[RB];
                         load_rows<true>(p, qb, d, RB, cbase, xt);
@@ -248,7 +241,6 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, Fw
             s.deg = nullptr;
             s.extra = nullptr;
             gemm_pass(p, s, pass, wt, acc);
-            STAMP(tG);
             if (pass == P - 1) {
                 store_acc(S.otile, oldd, wt, p.npad, acc);
 #pragma unroll
@@ -257,9 +249,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, Fw
                     for (int c = 0; c < CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (dbg) t0 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // (A) ztile[sidx&1] and otile are complete
-        STAMP(tB1);
         if (!producer && sidx >= 1 && want_gemm) {
             const int it = sidx - 1;
             const int ti = it / P, pass = it - ti * P;
@@ -269,13 +259,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(CoreParams p, Fw
                 else fwd_epilogue(p, fe, S.otile, oldd, wt.kparts, S.deg + (ti & 1) * TILE, tile0, ctid);
             }
         }
-        STAMP(tE);
         __syncthreads();  // (B) otile may be rewritten, deg/dagt of the older tile may be reused
-        STAMP(tB2);
-    }
-    if (dbg && (tid == 0 || tid == 256)) {
-        unsigned long long* o = dbg + ((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 8;
-        o[0] = tS; o[1] = tL; o[2] = tF; o[3] = tG; o[4] = tE; o[5] = tB1; o[6] = tB2; o[7] = nitems;
     }
 }
 
@@ -290,25 +274,8 @@ static int launch_pc(const CoreParams& p, const FwdEpilogue& fe, const DataEpilo
         attr_set = true;
     }
     const int grid = ntiles < 256 ? ntiles : 256;
-    unsigned long long* dbg = nullptr;
-    if (getenv("FGC_PC_DBG")) {
-        static unsigned long long* buf = nullptr;
-        if (!buf) hipMalloc(&buf, 256 * 2 * 8 * 8);
-        dbg = buf;
-    }
     FGC_LAUNCH(DATA ? "conv_pc_kernel<data>" : "conv_pc_kernel<fwd>", st, (conv_pc_kernel<DATA>), dim3(grid),
-               dim3(PC_THREADS), smem, p, fe, de, ntiles, pc_otile_floats(g), dbg);
-    if (dbg) {
-        hipStreamSynchronize(st);
-        unsigned long long h[256 * 2 * 8];
-        hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        double s[2][8] = {};
-        for (int b = 0; b < grid; ++b)
-            for (int r = 0; r < 2; ++r)
-                for (int k = 0; k < 8; ++k) s[r][k] += (double)h[(b * 2 + r) * 8 + k] / grid;
-        fprintf(stderr, "PCDBG %s n=%d cg=%d nout=%d items/WG %.1f | producer: softmax %.0f loadwait %.0f fma %.0f barA %.0f barB %.0f | consumer: gemm %.0f epi %.0f barA %.0f barB %.0f (cycles per WG, 100MHz ticks?)\n",
-                DATA ? "data" : "fwd", p.n, p.cg, p.nout, s[0][7], s[0][0], s[0][1], s[0][2], s[0][5], s[0][6], s[1][3], s[1][4], s[1][5], s[1][6]);
-    }
+               dim3(PC_THREADS), smem, p, fe, de, ntiles, pc_otile_floats(g));
     FGC_CHECK_LAUNCH("conv_pc_kernel");
     return FGC_OK;
 }

@@ -372,6 +372,29 @@ extern "C" int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, flo
     return FGC_OK;
 }
 
+extern "C" int fgc_normalize_apply(const float* x, int32_t n, const float* scratch, float* y, void* stream) {
+    FGC_CHECK_ARG(x && y && scratch && n > 0, "fgc_normalize_apply: bad arguments");
+    FGC_LAUNCH("normalize_fwd_kernel", ST, normalize_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, x, n, scratch, y);
+    FGC_CHECK_LAUNCH("fgc_normalize_apply");
+    return FGC_OK;
+}
+extern "C" int fgc_normalize_bwd_partial(const float* x, const float* dy, int32_t n, const float* scratch, float* dx,
+                                         float* partial, void* stream) {
+    FGC_CHECK_ARG(x && dy && dx && scratch && partial && n > 0, "fgc_normalize_bwd_partial: bad arguments");
+    FGC_LAUNCH("normalize_bwd_stage1", ST, normalize_bwd_stage1, dim3(fgc_norm_num_partials(n)), dim3(256), 0, x, dy, n,
+               scratch, dx, partial);
+    FGC_CHECK_LAUNCH("fgc_normalize_bwd_partial");
+    return FGC_OK;
+}
+extern "C" int fgc_normalize_bwd_apply(const float* x, int32_t n, float total_count, const float* scratch, float* dx,
+                                       void* stream) {
+    FGC_CHECK_ARG(x && dx && scratch && n > 0 && total_count > 0, "fgc_normalize_bwd_apply: bad arguments");
+    FGC_LAUNCH("normalize_bwd_stage2", ST, normalize_bwd_stage2, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, x,
+               (int64_t)n * 3, scratch, 1.0f / total_count, dx);
+    FGC_CHECK_LAUNCH("fgc_normalize_bwd_apply");
+    return FGC_OK;
+}
+
 extern "C" int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns,
                                     float* loss_out, void* stream) {
     FGC_CHECK_ARG(fn && gt && sample_ind && loss_out && ns > 0, "fgc_angular_loss_fwd: bad arguments");

@@ -127,6 +127,7 @@ class FacetDenoiser:
         self._mesh = None
         self._graph_fb = None
         self.profile = False   # when True every enqueue is labelled for fgc_profile_collect
+        self.comm = None       # exchange back end of a facet-sharded run (shard.DistComm)
         # parameter slots
         k = 0
         self.slot = {}
@@ -160,51 +161,74 @@ class FacetDenoiser:
     # ------------------------------------------------------------------------------------------
     # mesh binding: graphs + every buffer, once
     # ------------------------------------------------------------------------------------------
-    def bind_mesh(self, x, adjs, gt=None):
+    def bind_mesh(self, x, adjs, gt=None, plan=None, comm=None):
         """x: [1,N0,C] / [N0,C] features (float64 numpy as in in_list, or tensor); adjs: 3 K-lists or FacetGraphs;
         gt: [1,N0,3] ground-truth normals (training only).  Casts once (float64->float32, int64->int32 as the
-        TF feed does, train.py:409-427)."""
+        TF feed does, train.py:409-427).
+
+        plan / comm (facet sharding, shard.py): x, adjs, gt are still the WHOLE mesh; this rank keeps only its
+        shard ([owned rows | halo rows] per level) and exchanges halos through `comm` between the layers."""
         dev = self.device
-        graphs = [as_graph(a, dev) for a in adjs]
-        if len(graphs) != 3:
-            raise ValueError("the network needs exactly 3 adjacency levels (model.py:858-931)")
         xt = torch.as_tensor(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32))
-        xt = xt.reshape(-1, xt.shape[-1]).contiguous().to(dev)
-        n0, n1, n2 = (g.n for g in graphs)
-        if xt.shape[0] != n0 or n0 != 4 * n1 or n1 != 4 * n2:
-            raise ValueError("level sizes must be N0 = 4 N1 = 16 N2 and match x (got %d, %d, %d, x %d)" %
-                             (n0, n1, n2, xt.shape[0]))
+        xt = xt.reshape(-1, xt.shape[-1]).contiguous()
         if xt.shape[1] != self.in_channels:
             raise ValueError("expected %d input channels" % self.in_channels)
+        gtt = None
+        if gt is not None:
+            gtt = torch.as_tensor(np.asarray(gt.cpu() if isinstance(gt, torch.Tensor) else gt, dtype=np.float32))
+            gtt = gtt.reshape(-1, 3).contiguous()
+        if plan is None:
+            graphs = [as_graph(a, dev) for a in adjs]
+            if len(graphs) != 3:
+                raise ValueError("the network needs exactly 3 adjacency levels (model.py:858-931)")
+            nh = [0, 0, 0]
+            n_total = [g.n for g in graphs]
+            own_lo = 0
+        else:
+            from .shard import LocalGraph
+            graphs = [LocalGraph(P, dev) for P in plan.levels]
+            nh = [g.n_halo for g in graphs]
+            n_total = list(plan.n_total)
+            own_lo = plan.levels[0].lo
+            xt = xt[torch.from_numpy(plan.local_rows(0))]
+            if gtt is not None:
+                gtt = gtt[plan.levels[0].lo:plan.levels[0].hi]
+        n0, n1, n2 = (g.n for g in graphs)
+        if n0 != 4 * n1 or n1 != 4 * n2 or xt.shape[0] != n0 + nh[0]:
+            raise ValueError("level sizes must be N0 = 4 N1 = 16 N2 and match x (got %d, %d, %d, x %d)" %
+                             (n0, n1, n2, xt.shape[0]))
+        xt = xt.contiguous().to(dev)
         f = dict(dtype=torch.float32, device=dev)
         ns = [n0, n1, n2]
         B = {"x": xt, "xr": torch.empty_like(xt)}
-        shapes = {"h1": (n0, 32), "p1": (n1, 32), "h2": (n1, 64), "p2": (n2, 64), "h3": (n2, 128), "d3": (n2, 128),
-                  "u2": (n1, 64), "d2": (n1, 64), "u1": (n0, 32), "d1": (n0, 32), "y0": (n0, 3), "nconv": (n0, 3)}
-        for k, s in shapes.items():
-            B[k] = torch.empty(*s, **f)
-            B["g_" + k] = torch.empty(*s, **f)   # gradient twin
+        # rows: owned + the halo rows a consumer gathers (d3 / d2 are read 4x-upsampled by the level above, their tail
+        # rows hold the parents of THAT level's halo nodes)
+        shapes = {"h1": (n0 + nh[0], 32), "p1": (n1 + nh[1], 32), "h2": (n1 + nh[1], 64), "p2": (n2 + nh[2], 64),
+                  "h3": (n2 + nh[2], 128), "d3": (n2 + nh[1], 128), "u2": (n1 + nh[1], 64), "d2": (n1 + nh[0], 64),
+                  "u1": (n0 + nh[0], 32), "d1": (n0, 32), "y0": (n0, 3), "nconv": (n0, 3)}
+        for k, sh in shapes.items():
+            B[k] = torch.zeros(*sh, **f)
+            B["g_" + k] = torch.zeros(*sh, **f)   # gradient twin
         for lay in self.layers:
-            rows = ns[lay.level] >> lay.shift
-            B["ag_" + lay.name] = torch.empty(rows, AG_LD, **f)
+            B["ag_" + lay.name] = torch.empty(B[lay.x0].shape[0], AG_LD, **f)
         if self.multi_scale:
             B["y1"] = torch.empty(n1, 3, **f)
             B["y2"] = torch.empty(n2, 3, **f)
         # shared backward scratch, sized for the largest user
-        max_ncout = max(ns[l.level] * self._cout(l) for l in self.layers)
-        max_nnz = max(g.nnz for g in graphs)
-        B["ds"] = torch.empty(max_ncout, **f)
-        B["dl"] = torch.empty(max(max_nnz, 1) * DL_LD, **f)
+        max_ds = max((ns[l.level] + nh[l.level]) * self._cout(l) for l in self.layers)
+        max_r = max(ns[l.level] * self._cout(l) for l in self.layers)
+        max_dl = max(g.nnz + getattr(g, "n_cross_in", 0) for g in graphs)
+        B["ds"] = torch.zeros(max_ds, **f)
+        B["dl"] = torch.zeros(max(max_dl, 1) * DL_LD, **f)
         B["dag"] = torch.empty(max(ns) * AG_LD, **f)
-        B["r"] = torch.empty(max_ncout * FGC_M, **f)
+        B["r"] = torch.empty(max_r * FGC_M, **f)
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
-        B["norm_scratch"] = torch.empty(2 + self.L.fgc_norm_num_partials(n0), **f)
+        B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
         B["loss"] = torch.zeros(2, **f)
         B["R"] = torch.eye(3, **f).reshape(9).contiguous()
         B["sample_ind"] = torch.zeros(COST_SAMPLES, dtype=torch.int32, device=dev)
-        if gt is not None:
-            gtt = torch.as_tensor(np.asarray(gt.cpu() if isinstance(gt, torch.Tensor) else gt, dtype=np.float32))
-            B["gt"] = gtt.reshape(-1, 3).contiguous().to(dev)
+        if gtt is not None:
+            B["gt"] = gtt.contiguous().to(dev)
             B["gtr"] = torch.empty_like(B["gt"])
         # descriptors + workspace
         vals, grads = self.params.values, self.params.grads
@@ -214,7 +238,8 @@ class FacetDenoiser:
             W0, b, u, c, v = vals[lay.pidx:lay.pidx + 5]
             d = ConvDesc()
             d.n, d.nnz = g.n, g.nnz
-            d.rowptr, d.col = g.rowptr.data_ptr(), g.col.data_ptr()
+            col = g.col_up if (plan is not None and lay.shift) else g.col
+            d.rowptr, d.col = g.rowptr.data_ptr(), col.data_ptr()
             d.x0 = B[lay.x0].data_ptr()
             d.x1 = B[lay.x1].data_ptr() if lay.x1 else None
             d.c0 = B[lay.x0].shape[1]
@@ -222,6 +247,7 @@ class FacetDenoiser:
             d.shift, d.cout = lay.shift, W0.shape[1]
             d.W0, d.b, d.u, d.c, d.v = (t.data_ptr() for t in (W0, b, u, c, v))
             d.bias_mask, d.act, d.alpha = 1, lay.act, LRELU_ALPHA
+            d.src_rows = B[lay.x0].shape[0]
             d.max_deg = g.max_deg
             descs[lay.name] = d
             ws_f = max(ws_f, self.L.fgc_conv_workspace_bytes(C.byref(d)))
@@ -230,6 +256,7 @@ class FacetDenoiser:
             io = ConvBwdIO()
             io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
             io.max_in_deg = g.max_in_deg
+            io.stages = 0
             io.ag, io.y, io.dy = B["ag_" + lay.name].data_ptr(), B[lay.y].data_ptr(), B["g_" + lay.y].data_ptr()
             io.ds, io.dl, io.dag, io.r = (B[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
             gW0, gb, gu, gc, gv = grads[lay.pidx:lay.pidx + 5]
@@ -237,19 +264,20 @@ class FacetDenoiser:
             ios[lay.name] = io
         # who writes each activation gradient first (write) / second (accumulate): fixed backward order
         #   g_h1: dconv1 (x1, write) then pool1 backward (accumulate);  g_h2: dconv2 (x1) then pool2 backward
-        for name, x0acc, x1acc in [("dconv1", 0, 0), ("upconv1", 0, 0), ("dconv2", 0, 0), ("upconv2", 0, 0),
-                                   ("dconv3", 0, 0), ("conv3", 0, 0), ("conv2", 0, 0)]:
+        for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2"]:
             lay = next(l for l in self.layers if l.name == name)
             io = ios[name]
             io.dx0 = B["g_" + lay.x0].data_ptr()
             io.dx1 = B["g_" + lay.x1].data_ptr() if lay.x1 else None
-            io.accumulate0, io.accumulate1 = x0acc, x1acc
+            io.accumulate0, io.accumulate1 = 0, 0
         ios["conv1"].dx0 = None
         ios["conv1"].dx1 = None
         ws_f = max(ws_f, self.L.fgc_mlp_workspace_bytes(128, HIDDEN, 3))
         ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n0, 32, HIDDEN, 3))
         B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)
-        self._mesh = dict(graphs=graphs, B=B, descs=descs, ios=ios, ns=ns, has_gt=gt is not None)
+        self._mesh = dict(graphs=graphs, B=B, descs=descs, ios=ios, ns=ns, nh=nh, has_gt=gt is not None,
+                          plan=plan, n_total=n_total, own_lo=own_lo)
+        self.comm = comm
         self._graph_fb = None
         return self
 
@@ -257,7 +285,11 @@ class FacetDenoiser:
         return self.params.spec[lay.pidx][1][1]
 
     # ------------------------------------------------------------------------------------------
-    # enqueue helpers (no allocation, no sync)
+    # enqueue helpers (no allocation, no sync).  The schedules are GENERATORS: they yield an exchange request
+    # wherever a facet-sharded run must talk to its peers; an unsharded run just drains them.
+    #   ("rows", level, tensor, width_rows_own, parent)   halo rows of `tensor` (parent: rows of the coarse parents)
+    #   ("edges", level)                                   d-logits of incoming cross-shard edges
+    #   ("sum", tensor)                                    all-reduce
     # ------------------------------------------------------------------------------------------
     def _st(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -266,17 +298,29 @@ class FacetDenoiser:
         if self.profile:
             self.L.fgc_profile_tag(name.encode())
 
-    def _enqueue_forward(self, rotate):
+    @property
+    def sharded(self):
+        return self._mesh["plan"] is not None
+
+    def _forward_gen(self, rotate):
         M, L, st = self._mesh, self.L, self._st()
         B, ws = M["B"], M["B"]["ws"]
         n0 = M["ns"][0]
+        rows0 = B["x"].shape[0]
         self._tag("fwd:input")
         if rotate:
-            _lib.check(L.fgc_rotate_rows(_p(B["x"]), _p(B["xr"]), n0, self.in_channels // 3, _p(B["R"]), st), "rotate")
+            _lib.check(L.fgc_rotate_rows(_p(B["x"]), _p(B["xr"]), rows0, self.in_channels // 3, _p(B["R"]), st),
+                       "rotate")
         else:
             B["xr"].copy_(B["x"])
         vals = self.params.values
+        halo_before = {"conv2": [("p1", 1, False)], "conv3": [("p2", 2, False)], "dconv3": [("h3", 2, False)],
+                       "upconv2": [("d3", 1, True)], "dconv2": [("u2", 1, False), ("h2", 1, False)],
+                       "upconv1": [("d2", 0, True)], "dconv1": [("u1", 0, False), ("h1", 0, False)]}
         for lay in self.layers:
+            if self.sharded:
+                for name, level, parent in halo_before.get(lay.name, []):
+                    yield ("rows", level, B[name], parent)
             self._tag("fwd:" + lay.name)
             d = M["descs"][lay.name]
             _lib.check(L.fgc_conv_fwd(C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]),
@@ -285,17 +329,26 @@ class FacetDenoiser:
                 head, out = ("head2", "y2") if lay.name == "dconv3" else ("head1", "y1")
                 W1, b1, W2, b2 = vals[self.slot[head]:self.slot[head] + 4]
                 xin = B[lay.y]
-                _lib.check(L.fgc_mlp_fwd(_p(xin), xin.shape[0], xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
+                nrows = M["ns"][lay.level]
+                _lib.check(L.fgc_mlp_fwd(_p(xin), nrows, xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
                                          _p(b2), LRELU_ALPHA, _p(B[out]), None, _p(ws), ws.numel(), st), head)
         self._tag("fwd:mlp")
         W1, b1, W2, b2 = vals[self.slot["head0"]:self.slot["head0"] + 4]
         _lib.check(L.fgc_mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
                                  _p(B["y0"]), _p(B["abs_part"]), _p(ws), ws.numel(), st), "head0")
         self._tag("fwd:normalize")
-        _lib.check(L.fgc_normalize_fwd(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(), _p(B["nconv"]),
-                                       _p(B["norm_scratch"]), st), "normalize")
+        if not self.sharded:
+            _lib.check(L.fgc_normalize_fwd(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(),
+                                           _p(B["nconv"]), _p(B["norm_scratch"]), st), "normalize")
+        else:
+            # global mean |y| (utils.py:1705 takes it over the whole tensor): one scalar all-reduce
+            tot = B["abs_part"].sum().reshape(1)
+            yield ("sum", tot)
+            B["norm_scratch"][0:1] = tot / (3.0 * M["n_total"][0]) + 1e-5
+            _lib.check(L.fgc_normalize_apply(_p(B["y0"]), n0, _p(B["norm_scratch"]), _p(B["nconv"]), st),
+                       "normalize")
 
-    def _enqueue_loss_backward(self, rotate):
+    def _loss_backward_gen(self, rotate):
         M, L, st = self._mesh, self.L, self._st()
         B, ws, ns = M["B"], M["B"]["ws"], M["ns"]
         n0 = ns[0]
@@ -304,13 +357,35 @@ class FacetDenoiser:
         if rotate:
             _lib.check(L.fgc_rotate_rows(_p(B["gt"]), _p(B["gtr"]), n0, 1, _p(B["R"]), st), "rotate gt")
             gt = B["gtr"]
-        ns_samp = B["sample_ind"].numel()
-        _lib.check(L.fgc_angular_loss_fwd(_p(B["nconv"]), _p(gt), _p(B["sample_ind"]), ns_samp, _p(B["loss"]), st),
-                   "loss")
-        _lib.check(L.fgc_angular_loss_bwd(_p(B["nconv"]), _p(gt), _p(B["sample_ind"]), ns_samp, n0, _p(B["loss"]),
-                                          1.0, _p(B["g_nconv"]), st), "loss bwd")
-        _lib.check(L.fgc_normalize_bwd(_p(B["y0"]), _p(B["g_nconv"]), n0, _p(B["g_y0"]), _p(B["norm_scratch"]), st),
-                   "normalize bwd")
+        samp = B["sample_ind_local"] if self.sharded else B["sample_ind"]
+        ns_samp = samp.numel()
+        if ns_samp:
+            _lib.check(L.fgc_angular_loss_fwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, _p(B["loss"]), st), "loss")
+        else:
+            B["loss"].zero_()
+        if self.sharded:
+            # loss = sum over ranks of (sum of angles) / sum over ranks of (real rows)
+            tot = torch.stack([torch.nan_to_num(B["loss"][0] * B["loss"][1]), B["loss"][1]])
+            yield ("sum", tot)
+            B["loss"][0:1] = tot[0:1] / tot[1:2]
+            B["loss"][1:2] = tot[1:2]
+        if ns_samp:
+            _lib.check(L.fgc_angular_loss_bwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, n0, _p(B["loss"]), 1.0,
+                                              _p(B["g_nconv"]), st), "loss bwd")
+        else:
+            B["g_nconv"].zero_()
+        if not self.sharded:
+            _lib.check(L.fgc_normalize_bwd(_p(B["y0"]), _p(B["g_nconv"]), n0, _p(B["g_y0"]), _p(B["norm_scratch"]),
+                                           st), "normalize bwd")
+        else:
+            sc = B["norm_scratch"]
+            _lib.check(L.fgc_normalize_bwd_partial(_p(B["y0"]), _p(B["g_nconv"]), n0, _p(sc), _p(B["g_y0"]),
+                                                   C.c_void_p(sc.data_ptr() + 8), st), "normalize bwd 1")
+            tot = sc[2:].sum().reshape(1)
+            yield ("sum", tot)
+            sc[1:2] = -tot / (sc[0:1] * sc[0:1])
+            _lib.check(L.fgc_normalize_bwd_apply(_p(B["y0"]), n0, 3.0 * M["n_total"][0], _p(sc), _p(B["g_y0"]), st),
+                       "normalize bwd 2")
         vals, grads = self.params.values, self.params.grads
         s = self.slot["head0"]
         self._tag("bwd:mlp")
@@ -325,8 +400,61 @@ class FacetDenoiser:
             if name == "conv1":   # g_h1 += d pool1
                 _lib.check(L.fgc_pool4_bwd(_p(B["h1"]), _p(B["p1"]), _p(B["g_p1"]), _p(B["g_h1"]), ns[1], 32, 1, st),
                            "pool1 bwd")
-            _lib.check(L.fgc_conv_bwd(C.byref(M["descs"][name]), C.byref(M["ios"][name]), _p(ws), ws.numel(), st),
-                       name + " bwd")
+            d, io = M["descs"][name], M["ios"][name]
+            if not self.sharded:
+                io.stages = 0
+                _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd")
+                continue
+            lay = next(l for l in self.layers if l.name == name)
+            cout = d.cout
+            nloc = ns[lay.level] + M["nh"][lay.level]
+            io.stages = 1       # s = dy * lrelu'(y) / deg on owned rows, then the halo rows of s from their owners
+            _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/ds")
+            yield ("rows", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False)
+            io.stages = 2       # d-logits of owned edges, then those of incoming cross-shard edges
+            _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/logits")
+            yield ("edges", lay.level)
+            io.stages = 4
+            _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/data")
+        if self.sharded:
+            yield ("sum", self.params.grad)     # every rank summed its own facets: one flat all-reduce
+
+    # ---- exchange requests -> (send buffer, send counts, receive view, receive counts) ---------------------
+    def _materialise(self, req):
+        from . import ops
+        M = self._mesh
+        kind = req[0]
+        if kind == "sum":
+            return ("sum", req[1])
+        g = M["graphs"][req[1]]
+        if kind == "rows":
+            t, parent = req[2], req[3]
+            tail = t.shape[0] - g.n_halo
+            idx = g.send_parent_rows if parent else g.send_rows
+            nsend = sum(g.send_counts)
+            send = ops.gather_rows(t, idx[:nsend]) if nsend else t[:0]
+            return ("a2a", send, g.send_counts, t[tail:], g.recv_counts)
+        if kind == "edges":
+            dl = M["B"]["dl"][:(g.nnz + g.n_cross_in) * DL_LD].view(-1, DL_LD)
+            nsend = sum(g.cross_send_counts)
+            send = ops.gather_rows(dl, g.send_edges[:nsend]) if nsend else dl[:0]
+            return ("a2a", send, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
+        raise ValueError(kind)
+
+    def _drain(self, gen):
+        """Run a schedule on this rank: no-op exchanges when unsharded, collectives through self.comm otherwise."""
+        for req in gen:
+            m = self._materialise(req)
+            if m[0] == "sum":
+                self.comm.all_reduce_sum(m[1])
+            else:
+                self.comm.all_to_all_rows(m[1], m[2], m[3], m[4])
+
+    def _enqueue_forward(self, rotate):
+        self._drain(self._forward_gen(rotate))
+
+    def _enqueue_loss_backward(self, rotate):
+        self._drain(self._loss_backward_gen(rotate))
 
     # ------------------------------------------------------------------------------------------
     # public API
@@ -343,6 +471,10 @@ class FacetDenoiser:
             B["sample_ind"] = torch.empty(t.numel(), dtype=torch.int32, device=self.device)
             self._graph_fb = None
         B["sample_ind"].copy_(t)
+        if self.sharded:
+            lo = self._mesh["own_lo"]
+            loc = t[(t >= lo) & (t < lo + self._mesh["ns"][0])] - lo
+            B["sample_ind_local"] = loc.to(torch.int32).to(self.device)
 
     def forward(self, rotate=False):
         """Normalised normals of the bound mesh: [N0,3] (padded, permuted order). Un-normalised output in buffers['y0']."""

@@ -1,0 +1,290 @@
+"""Facet sharding: one mesh split over P ranks with a one-hop halo per graph level.
+
+The reference has no multi-device path (single tf.Session, train.py:396); this is the MI355X-native design for
+BASELINE configs 4-5.  Ownership follows the binary tree: rank r owns a contiguous range of COARSEST nodes and the
+4x / 16x ranges under it, so pooling, upsampling and the skip concats stay local.  Because the coarsest level is
+ordered along a Morton curve (csrc/fgc_prep.hip) a contiguous range is a compact surface patch and the halo is a
+thin rim.  Per graph level and rank the plan holds
+
+  * the owned row range [lo, hi) and the sorted global ids of the HALO rows (every remote node that is a
+    neighbour or an in-neighbour of an owned node); local row index = id - lo for owned rows, n_own + position
+    for halo rows, so a source tensor is simply [owned rows | halo rows] and the kernels need no change;
+  * the local CSR over owned rows (two column variants: plain local ids, and "virtual" ids 4*(n_own/4 + h) for
+    convolutions that read a 4x-upsampled coarse tensor whose tail rows hold the halo nodes' parents);
+  * the local transposed CSR for backward, whose edge ids address [owned edges | incoming cross-shard edges];
+  * send lists: which owned rows / owned edges every peer needs, in the order the peer stores them.
+
+Exchanges per step: 7 row exchanges forward, per conv backward one row exchange (s = dy/deg) and one per-edge
+exchange (d logits of cross edges); one flat-gradient all-reduce, two scalar all-reduces for normalizeTensor and
+one for the loss.  Everything is an all-to-all of packed rows: with RCCL over xGMI every peer pair has its own
+link, so the exchange is one hop, never a ring.
+"""
+import numpy as np
+import torch
+
+
+def _owner_ranges(n2, world):
+    """Contiguous split of the coarsest level; level l ranges are these times 4^(2-l)."""
+    cuts = [(n2 * r) // world for r in range(world + 1)]
+    return cuts
+
+
+class LevelPlan:
+    pass
+
+
+def build_level_plan(rowptr, col, lo_hi, rank):
+    """Plan of one graph level for `rank`.  rowptr/col: GLOBAL CSR (host numpy), lo_hi: list of (lo, hi) per rank."""
+    world = len(lo_hi)
+    lo, hi = lo_hi[rank]
+    n = len(rowptr) - 1
+    deg = np.diff(rowptr)
+    src = np.repeat(np.arange(n, dtype=np.int64), deg)
+    dst = col.astype(np.int64)
+    eid = np.arange(len(col), dtype=np.int64)
+    owner_of = np.zeros(n, dtype=np.int64)
+    for r, (a, b) in enumerate(lo_hi):
+        owner_of[a:b] = r
+
+    P = LevelPlan()
+    P.lo, P.hi, P.n_own = lo, hi, hi - lo
+    e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+    P.nnz = e1 - e0
+    out_dst = dst[e0:e1]
+    in_mask = (dst >= lo) & (dst < hi)
+    in_src, in_dst, in_eid = src[in_mask], dst[in_mask], eid[in_mask]
+    remote_out = out_dst[(out_dst < lo) | (out_dst >= hi)]
+    remote_in = in_src[(in_src < lo) | (in_src >= hi)]
+    P.halo_ids = np.unique(np.concatenate([remote_out, remote_in])).astype(np.int64)
+    P.n_halo = len(P.halo_ids)
+    P.halo_owner = owner_of[P.halo_ids] if P.n_halo else np.zeros(0, np.int64)
+    P.recv_counts = [int((P.halo_owner == q).sum()) for q in range(world)]
+
+    def to_local(g):
+        g = np.asarray(g, dtype=np.int64)
+        own = (g >= lo) & (g < hi)
+        out = np.where(own, g - lo, 0)
+        if P.n_halo:
+            h = np.searchsorted(P.halo_ids, g[~own])
+            out[~own] = P.n_own + h
+        return out
+
+    P.rowptr = (rowptr[lo:hi + 1] - e0).astype(np.int32)
+    loc = to_local(out_dst)
+    P.col = loc.astype(np.int32)
+    # variant for 4x-upsampled sources: owned j keeps j (j >> 2 = its parent's local row because n_own % 4 == 0),
+    # halo h becomes 4 * (n_own / 4 + h): row (n_own/4 + h) of the coarse tensor holds that halo node's parent
+    up = loc.copy()
+    is_h = loc >= P.n_own
+    up[is_h] = 4 * (P.n_own // 4 + (loc[is_h] - P.n_own))
+    P.col_up = up.astype(np.int32)
+    P.max_deg = int(np.diff(P.rowptr).max()) if P.n_own else 0
+
+    # rows of mine that peer q needs, in q's halo order (ascending global id)
+    P.send_rows = []
+    for q, (a, b) in enumerate(lo_hi):
+        if q == rank:
+            P.send_rows.append(np.zeros(0, np.int64))
+            continue
+        qe0, qe1 = int(rowptr[a]), int(rowptr[b])
+        q_out = dst[qe0:qe1]
+        q_in_mask = (dst >= a) & (dst < b)
+        q_in_src = src[q_in_mask]
+        need = np.unique(np.concatenate([q_out, q_in_src]))
+        need = need[(need >= lo) & (need < hi)]
+        P.send_rows.append(need - lo)
+    P.send_counts = [len(s) for s in P.send_rows]
+
+    # ---- transposed CSR over owned targets; in-edges of a node ordered by global edge id (= unsharded order)
+    local_in = (in_src >= lo) & (in_src < hi)
+    # incoming cross edges, stored behind the owned edges grouped by source rank in (target, source, eid) order
+    cross_src, cross_dst, cross_eid = in_src[~local_in], in_dst[~local_in], in_eid[~local_in]
+    cross_owner = owner_of[cross_src] if len(cross_src) else np.zeros(0, np.int64)
+    order = np.lexsort((cross_eid, cross_src, cross_dst, cross_owner))
+    slot_of = np.empty(len(order), dtype=np.int64)
+    slot_of[order] = np.arange(len(order))
+    P.n_cross_in = len(order)
+    P.cross_recv_counts = [int((cross_owner == q).sum()) for q in range(world)]
+    tedge_all = np.empty(len(in_eid), dtype=np.int64)
+    tedge_all[local_in] = in_eid[local_in] - e0
+    tedge_all[~local_in] = P.nnz + slot_of
+    tcol_all = to_local(in_src)
+    tkey = np.lexsort((in_eid, in_dst))
+    tdst = in_dst[tkey] - lo
+    P.trowptr = np.zeros(P.n_own + 1, dtype=np.int32)
+    np.add.at(P.trowptr, tdst + 1, 1)
+    P.trowptr = np.cumsum(P.trowptr).astype(np.int32)
+    P.tcol = tcol_all[tkey].astype(np.int32)
+    P.tedge = tedge_all[tkey].astype(np.int32)
+    P.max_in_deg = int(np.diff(P.trowptr).max()) if P.n_own else 0
+    # my outgoing cross edges to peer q, in q's storage order (target, source, eid)
+    P.send_edges = []
+    o_src, o_dst, o_eid = src[e0:e1], out_dst, eid[e0:e1]
+    for q, (a, b) in enumerate(lo_hi):
+        m = (o_dst >= a) & (o_dst < b) if q != rank else np.zeros(len(o_dst), bool)
+        s_, d_, e_ = o_src[m], o_dst[m], o_eid[m]
+        k = np.lexsort((e_, s_, d_))
+        P.send_edges.append((e_[k] - e0).astype(np.int64))
+    P.cross_send_counts = [len(s) for s in P.send_edges]
+    return P
+
+
+class ShardPlan:
+    """Everything rank `rank` of `world` needs to run its shard of one mesh."""
+
+    def __init__(self, graphs_h, rank, world):
+        """graphs_h: [(rowptr, col)] x 3 global CSRs (host numpy), levels 0..2."""
+        n = [len(g[0]) - 1 for g in graphs_h]
+        if n[0] != 4 * n[1] or n[1] != 4 * n[2]:
+            raise ValueError("level sizes must be N0 = 4 N1 = 16 N2")
+        if world > n[2]:
+            raise ValueError("more ranks than coarsest nodes")
+        cuts = _owner_ranges(n[2], world)
+        self.rank, self.world = rank, world
+        self.ranges = []
+        for l in range(3):
+            f = 4 ** (2 - l)
+            self.ranges.append([(cuts[r] * f, cuts[r + 1] * f) for r in range(world)])
+        self.levels = [build_level_plan(graphs_h[l][0], graphs_h[l][1], self.ranges[l], rank) for l in range(3)]
+        self.n_total = n
+
+    def local_rows(self, level):
+        """Global ids of the local rows [owned | halo] of a level."""
+        P = self.levels[level]
+        return np.concatenate([np.arange(P.lo, P.hi, dtype=np.int64), P.halo_ids])
+
+
+class LocalGraph:
+    """Device-resident local CSR of one level of a shard (same attribute names as graph.FacetGraph)."""
+
+    def __init__(self, P, device):
+        self.n, self.nnz = P.n_own, P.nnz
+        self.n_halo, self.n_cross_in = P.n_halo, P.n_cross_in
+        self.max_deg, self.max_in_deg = P.max_deg, P.max_in_deg
+        pad = (lambda a: a if len(a) else np.zeros(1, a.dtype))
+        dev = torch.device(device)
+        self.rowptr = torch.from_numpy(P.rowptr.copy()).to(dev)
+        self.col = torch.from_numpy(pad(P.col).copy()).to(dev)
+        self.col_up = torch.from_numpy(pad(P.col_up).copy()).to(dev)
+        self._t = tuple(torch.from_numpy(pad(a).copy()).to(dev) for a in (P.trowptr, P.tcol, P.tedge))
+        self.send_rows = torch.from_numpy(pad(np.concatenate(P.send_rows)).astype(np.int32)).to(dev)
+        self.send_parent_rows = torch.from_numpy(pad(np.concatenate(P.send_rows) // 4).astype(np.int32)).to(dev)
+        self.send_counts, self.recv_counts = list(P.send_counts), list(P.recv_counts)
+        self.send_edges = torch.from_numpy(pad(np.concatenate(P.send_edges)).astype(np.int32)).to(dev)
+        self.cross_send_counts, self.cross_recv_counts = list(P.cross_send_counts), list(P.cross_recv_counts)
+
+    def transposed(self):
+        return self._t
+
+
+# ---------------------------------------------------------------------------------------------------
+# exchange back ends
+# ---------------------------------------------------------------------------------------------------
+class DistComm:
+    """One shard per process; RCCL (backend 'nccl') on GPUs, gloo through host staging in CPU-only tests."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.host_staged = dist.get_backend(group) == "gloo"
+
+    def all_to_all_rows(self, send, send_counts, recv, recv_counts):
+        """send [sum(send_counts), C] -> recv [sum(recv_counts), C] (views into larger tensors are fine)."""
+        if self.host_staged:
+            s = send.cpu()
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            self._gloo_a2a(r, s, recv_counts, send_counts)
+            recv.copy_(r)
+        else:
+            self.dist.all_to_all_single(recv, send, list(recv_counts), list(send_counts), group=self.group)
+
+    def _gloo_a2a(self, r, s, recv_counts, send_counts):
+        # gloo has no all_to_all_single on every build: P2P rounds instead
+        so, ro = np.cumsum([0] + list(send_counts)), np.cumsum([0] + list(recv_counts))
+        reqs = []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            if send_counts[q]:
+                reqs.append(self.dist.isend(s[so[q]:so[q + 1]].contiguous(), q, group=self.group))
+        for q in range(self.world):
+            if q == self.rank or not recv_counts[q]:
+                continue
+            buf = torch.empty((recv_counts[q],) + tuple(r.shape[1:]), dtype=r.dtype)
+            self.dist.recv(buf, q, group=self.group)
+            r[ro[q]:ro[q + 1]] = buf
+        for q in reqs:
+            q.wait()
+
+    def all_reduce_sum(self, t):
+        if self.host_staged:
+            c = t.cpu()
+            self.dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+
+
+
+
+def graphs_to_host_csr(adjs):
+    """3 K-lists (or FacetGraphs) -> [(rowptr, col)] host CSRs for ShardPlan."""
+    from .graph import FacetGraph, csr_from_klist
+    out = []
+    for a in adjs:
+        if isinstance(a, FacetGraph):
+            out.append((a.rowptr_h, a.col_h))
+        else:
+            out.append(csr_from_klist(a))
+    return out
+
+
+def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0):
+    """`world` shard networks of one mesh inside ONE process (parity tests of the sharded schedule on a single GPU)."""
+    from .net import FacetDenoiser
+    gh = graphs_to_host_csr(adjs)
+    nets = []
+    for r in range(world):
+        plan = ShardPlan(gh, r, world)
+        nets.append(FacetDenoiser(device, seed=seed).bind_mesh(x, adjs, gt=gt, plan=plan))
+    return nets
+
+
+def sim_run(nets, make_gen):
+    """Advance the schedules of all shards in lock step; every yielded request is an exchange among them."""
+    gens = [make_gen(n) for n in nets]
+    while True:
+        reqs = []
+        for g in gens:
+            try:
+                reqs.append(next(g))
+            except StopIteration:
+                reqs.append(None)
+        if all(r is None for r in reqs):
+            return
+        assert all(r is not None for r in reqs), "shards disagree on the exchange schedule"
+        mats = [n._materialise(r) for n, r in zip(nets, reqs)]
+        if mats[0][0] == "sum":
+            tot = mats[0][1].clone()
+            for m in mats[1:]:
+                tot += m[1]
+            for m in mats:
+                m[1].copy_(tot)
+            continue
+        for dst, md in enumerate(mats):
+            recv, recv_counts = md[3], md[4]
+            ro = np.cumsum([0] + list(recv_counts))
+            for src, ms in enumerate(mats):
+                if src == dst or not recv_counts[src]:
+                    continue
+                send, send_counts = ms[1], ms[2]
+                so = np.cumsum([0] + list(send_counts))
+                assert send_counts[dst] == recv_counts[src], (src, dst, send_counts[dst], recv_counts[src])
+                recv[ro[src]:ro[src + 1]].copy_(send[so[dst]:so[dst + 1]])
+
+
+def sim_forward_backward(nets, rotate=True):
+    sim_run(nets, lambda n: n._forward_gen(rotate))
+    sim_run(nets, lambda n: n._loss_backward_gen(rotate))

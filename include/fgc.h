@@ -132,6 +132,8 @@ typedef struct fgc_conv_desc {
     int32_t bias_mask;      /* model.py:496-500 */
     int32_t act;
     float alpha;
+    int32_t src_rows;       /* rows of x0/x1 to compute assignment logits for; 0 = n >> shift.  Larger when the
+                               source tensors carry halo rows behind the owned ones (facet sharding) */
     int32_t max_deg;        /* max_i deg(i) if the caller knows it, else 0.  <= 24 (every reference K-list) enables
                                the producer/consumer kernels; 0 or larger falls back to the edge-chunking path */
 } fgc_conv_desc;
@@ -157,6 +159,10 @@ typedef struct fgc_conv_bwd_io {
     const int32_t* tcol;    /* [nnz] */
     const int32_t* tedge;   /* [nnz] */
     int32_t max_in_deg;     /* max in-degree of the transposed graph if known, else 0 (see max_deg) */
+    int32_t stages;         /* 0 = whole backward.  Otherwise a bit mask, so that a facet-sharded caller can exchange
+                               halo rows between the pieces: 1 = ds/db, 2 = logits (dl, da, dc), 4 = data + weight
+                               gradients (r, dg, dx, dW0, du, dv).  ds then has rows for halo sources behind the n
+                               owned ones, and dl rows for incoming cross-shard edges behind the nnz owned ones. */
     const float* ag;        /* saved by forward */
     const float* y;         /* forward output (post activation) */
     const float* dy;        /* [n, cout] */
@@ -218,6 +224,16 @@ int32_t fgc_norm_num_partials(int32_t n);
 int fgc_normalize_fwd(const float* x, int32_t n, const float* abs_partial, int32_t num_partials, float* y,
                       float* scratch, void* stream);
 int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, float* dx, float* scratch, void* stream);
+/* The same op in pieces, for a tensor whose rows are sharded over ranks (the global mean and its gradient need one
+ * scalar all-reduce each, done by the caller between the pieces):
+ *   apply:        y = normalise rows of x with scratch[0] = mean|x| + 1e-5 supplied by the caller
+ *   bwd_partial:  dx <- d(x/s) per row, partial[0..fgc_norm_num_partials(n)) <- block sums of <d(x/s), x>
+ *   bwd_apply:    dx <- dx / s + sign(x) * scratch[1] / total_count, scratch[1] = -(global sum) / s^2 from the caller */
+int fgc_normalize_apply(const float* x, int32_t n, const float* scratch, float* y, void* stream);
+int fgc_normalize_bwd_partial(const float* x, const float* dy, int32_t n, const float* scratch, float* dx,
+                              float* partial, void* stream);
+int fgc_normalize_bwd_apply(const float* x, int32_t n, float total_count, const float* scratch, float* dx,
+                            void* stream);
 
 /* angular loss on sampled rows (train.py:509-517 gather + faceNormalsLoss train.py:1272-1294).
  * fn, gt [n,3]; sample_ind int32 [ns]; loss_out [2] = {loss in degrees, number of real rows}.

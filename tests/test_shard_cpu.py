@@ -1,0 +1,105 @@
+"""CPU tests of the facet-sharding plan and of the exchange back end (gloo, world size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from facet_graph_convolution_amd.graph import csr_from_klist
+from facet_graph_convolution_amd.shard import ShardPlan
+
+
+def _graphs(golden_dir, tag="ico3"):
+    z = np.load(os.path.join(golden_dir, "prep_%s.npz" % tag))
+    return [csr_from_klist(z["adj%d" % l]) for l in range(3)], z
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_plan_is_consistent(golden_dir, world):
+    gh, _ = _graphs(golden_dir)
+    plans = [ShardPlan(gh, r, world) for r in range(world)]
+    for l in range(3):
+        rowptr, col = gh[l]
+        n = len(rowptr) - 1
+        src = np.repeat(np.arange(n), np.diff(rowptr))
+        # ownership is a partition, aligned so that pooling / upsampling stay local
+        assert sum(p.levels[l].n_own for p in plans) == n
+        for p in plans:
+            P = p.levels[l]
+            assert P.lo % (4 ** (2 - l)) == 0 and P.n_own % (4 ** (2 - l)) == 0
+            ids = p.local_rows(l)
+            # local CSR reproduces the global rows
+            for i in range(0, P.n_own, max(1, P.n_own // 17)):
+                glob = col[rowptr[P.lo + i]:rowptr[P.lo + i + 1]]
+                loc = P.col[P.rowptr[i]:P.rowptr[i + 1]]
+                assert np.array_equal(ids[loc], glob)
+                up = P.col_up[P.rowptr[i]:P.rowptr[i + 1]]
+                own = loc < P.n_own
+                assert np.array_equal(up[own], loc[own])
+                assert np.array_equal(up[~own] // 4, P.n_own // 4 + (loc[~own] - P.n_own))
+            # what peers send me, in their order, is exactly my halo
+            got = []
+            for q in range(world):
+                Q = plans[q].levels[l]
+                got.append(Q.send_rows[p.rank] + Q.lo)
+                assert len(Q.send_rows[p.rank]) == P.recv_counts[q]
+            assert np.array_equal(np.concatenate(got), P.halo_ids)
+            # transposed CSR: every in-edge of an owned node, in global edge order, owned or cross
+            gl_in = np.where((col >= P.lo) & (col < P.hi))[0]
+            assert len(P.tedge) == len(gl_in)
+            cross_sent = np.concatenate([plans[q].levels[l].send_edges[p.rank] + rowptr[plans[q].levels[l].lo]
+                                         for q in range(world)]) if world > 1 else np.zeros(0, np.int64)
+            assert len(cross_sent) == P.n_cross_in
+            for j in range(0, P.n_own, max(1, P.n_own // 13)):
+                e_glob = np.sort(np.where(col == P.lo + j)[0])
+                te = P.tedge[P.trowptr[j]:P.trowptr[j + 1]]
+                tc = P.tcol[P.trowptr[j]:P.trowptr[j + 1]]
+                assert np.array_equal(ids[tc], src[e_glob])
+                back = np.where(te < P.nnz, te + rowptr[P.lo], cross_sent[np.maximum(te - P.nnz, 0)])
+                assert np.array_equal(back, e_glob)
+
+
+def _worker(rank, world, port, golden_dir, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from facet_graph_convolution_amd.shard import DistComm
+        gh, z = _graphs(golden_dir)
+        plan = ShardPlan(gh, rank, world)
+        comm = DistComm()
+        ok = True
+        for l in range(3):
+            P = plan.levels[l]
+            ids = plan.local_rows(l)
+            # a "feature" that encodes the global row id: after the exchange the halo rows must hold their own ids
+            t = torch.zeros(len(ids), 3)
+            t[:P.n_own, 0] = torch.arange(P.lo, P.hi, dtype=torch.float32)
+            t[:P.n_own, 1] = 7.0
+            send = t[torch.from_numpy(np.concatenate(P.send_rows)).long()]
+            comm.all_to_all_rows(send, P.send_counts, t[P.n_own:], P.recv_counts)
+            ok &= bool(torch.equal(t[:, 0], torch.from_numpy(ids).float()))
+            ok &= bool((t[:, 1] == 7.0).all())
+        s = torch.tensor([float(rank + 1)])
+        comm.all_reduce_sum(s)
+        ok &= s.item() == world * (world + 1) / 2
+        out.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_halo_exchange(golden_dir):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}
