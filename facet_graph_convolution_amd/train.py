@@ -1,0 +1,121 @@
+"""Training / inference drivers: the behaviour of the reference's ``trainNet`` and ``inferNetOld``
+(train.py:380-632, 29-144) on the MI355X kernels.  The TensorFlow session plumbing is not reproduced; what is:
+
+  * one iteration = random patch (here: random mesh), 4000 random loss rows (fake rows included), a fresh random
+    rotation applied to inputs and ground truth, ONE forward + backward + TF1-Adam update (the reference runs the
+    forward three times per iteration, train.py:577,619,620: an artefact, not a contract);
+  * the NaN watchdog (train.py:505-506,620-623), the smoothed loss every 50 iterations and the CSV of losses
+    (train.py:580-586,629-632), checkpoints every SAVEITER iterations (train.py:551-552) with resume;
+  * inference: forward without rotation, un-permute, drop fake rows, normalise twice (train.py:115-121,136).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .net import FacetDenoiser, COST_SAMPLES
+from .settings import SAVEITER
+from .utils import rand_rotation_matrix
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fn, gt):
+        idx = torch.arange(fn.shape[0], dtype=torch.int32, device=fn.device)
+        out = ops.angular_loss_fwd(fn, gt, idx)
+        ctx.save_for_backward(fn, gt, idx, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        fn, gt, idx, out = ctx.saved_tensors
+        return ops.angular_loss_bwd(fn, gt, idx, out, 1.0) * dloss, None
+
+
+def faceNormalsLoss(fn, gt_fn):
+    """train.py:1272-1294: mean angle in degrees over the rows whose ground truth is not a fake (all-zero) row."""
+    return _LossFn.apply(fn.reshape(-1, 3).contiguous(), gt_fn.reshape(-1, 3).contiguous().float())
+
+
+def save_checkpoint(path, net, iteration):
+    """Weights + Adam moments + step (what tf.train.Saver keeps by default, train.py:522,551-552)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    P = net.params
+    torch.save({"theta": P.theta.cpu(), "m": P.m.cpu(), "v": P.v.cpu(), "step": P.step, "iteration": iteration,
+                "multi_scale": net.multi_scale}, path)
+
+
+def load_checkpoint(path, net):
+    ck = torch.load(path, map_location="cpu")
+    P = net.params
+    if ck["theta"].numel() != P.theta.numel():
+        raise RuntimeError("checkpoint has %d parameters, network has %d" % (ck["theta"].numel(), P.theta.numel()))
+    P.theta.copy_(ck["theta"])
+    P.m.copy_(ck["m"])
+    P.v.copy_(ck["v"])
+    P.step = int(ck["step"])
+    return int(ck["iteration"])
+
+
+def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device="cuda", seed=0, log=print,
+             capture=True, validSet=None):
+    """train.py:380-632.  trainSet / validSet: dataClasses.TrainingSet.  Returns (net, lossArray [iters/50, 2])."""
+    meshes = []
+    for i in range(len(trainSet.in_list)):
+        net = None
+        meshes.append((trainSet.in_list[i], trainSet.adj_list[i], trainSet.gt_list[i]))
+    net = FacetDenoiser(device, seed=seed)
+    start = 0
+    ckpt = os.path.join(network_path, net_name + ".pt") if network_path else None
+    if ckpt and os.path.exists(ckpt):
+        start = load_checkpoint(ckpt, net)
+    rs = np.random.RandomState(seed + 1)
+    evalStepNum = 50
+    lossArray = np.zeros([max(num_iterations // evalStepNum, 1), 2])
+    bound = -1
+    train_loss, train_samp, hasNan = 0.0, 0, False
+    for it in range(num_iterations):
+        if ckpt and it % SAVEITER == 0 and it > 0:
+            save_checkpoint(ckpt, net, start + it)
+        b = rs.randint(len(meshes))
+        if b != bound:       # the reference feeds a new patch through feed_dict; here the mesh is (re)bound to HBM
+            x, adjs, gt = meshes[b]
+            net.bind_mesh(x, adjs, gt=gt)
+            bound = b
+        n0 = meshes[b][0].shape[1]
+        loss = net.train_step(sample_ind=rs.randint(n0, size=COST_SAMPLES),
+                              R=rand_rotation_matrix(randnums=rs.uniform(size=3)), capture=capture)
+        if it % evalStepNum == 0 or it == num_iterations - 1:
+            lv = loss[0].item()      # the only host sync of the loop
+            if not np.isfinite(lv):  # NaN watchdog (train.py:620-623)
+                hasNan = True
+                log("WARNING! NAN FOUND AFTER TRAINING!!!! training example %d/%d" % (b, len(meshes)))
+            train_loss += lv
+            train_samp += 1
+            if it % evalStepNum == 0:
+                log("Iteration %d, training loss %g" % (it, train_loss / train_samp))
+                lossArray[min(it // evalStepNum, len(lossArray) - 1), 0] = train_loss / train_samp
+                train_loss, train_samp = 0.0, 0
+    if ckpt:
+        save_checkpoint(ckpt, net, start + num_iterations)
+        with open(os.path.join(network_path, net_name + ".csv"), "ab") as fh:
+            np.savetxt(fh, lossArray, delimiter=",")
+    return net, lossArray
+
+
+def inferNetOld(inputMesh, net_or_checkpoint, device="cuda"):
+    """train.py:29-144 up to the denoised normals (the vertex update that follows is outside this path).
+    inputMesh: dataClasses.InferenceMesh.  Returns predicted unit normals [F, 3] (numpy) in face order."""
+    if isinstance(net_or_checkpoint, FacetDenoiser):
+        net = net_or_checkpoint
+    else:
+        net = FacetDenoiser(device)
+        load_checkpoint(net_or_checkpoint, net)
+    out = None
+    for i in range(len(inputMesh.in_list)):
+        net.bind_mesh(inputMesh.in_list[i], inputMesh.adj_list[i])
+        pred = net.infer_normals(inputMesh.permutations[i], inputMesh.num_faces[i])
+        out = pred if out is None else out
+    torch.cuda.synchronize()
+    return out.cpu().numpy()

@@ -1,0 +1,174 @@
+"""ORACLE (test infrastructure only): CPU restatement of the reference's mesh preprocessing.
+
+Plain numpy / Python loops following the reference line by line; meant for meshes of a few thousand faces.
+Pinned against tests/golden/prep_*.npz (outputs of the reference source itself) by tests/test_oracle_prep.py.
+
+ref: utils.py:26-35,63-68,243-295,1264-1294,1753-1835; lib/coarsening.py:135-241,269-296; dataClasses.py:172-233
+"""
+import math
+
+import numpy as np
+import scipy.sparse
+
+
+def normalize_once(a):
+    """ref: utils.py:26-31"""
+    norms = np.sqrt((a * a).sum(1))[:, np.newaxis] + 0.00000001
+    return a * (1 / norms)
+
+
+def face_normals(verts, faces):
+    """ref: utils.py:63-68 (normalize = normalizeOnce twice, utils.py:33-35)"""
+    T = verts[faces]
+    N = np.cross(T[::, 1] - T[::, 0], T[::, 2] - T[::, 0])
+    return normalize_once(normalize_once(N))
+
+
+def barycentres(vl, fl):
+    """ref: utils.py:1264-1294 (normalize=True): divide by the bbox diagonal, no centring"""
+    mn, mx = vl.min(0), vl.max(0)
+    diag = math.sqrt(sum(math.pow(float(mx[t] - mn[t]), 2) for t in range(3)))
+    vl = vl / diag
+    out = np.empty([fl.shape[0], 3])
+    for f in range(fl.shape[0]):
+        out[f, :] = (vl[fl[f, 0], :] + vl[fl[f, 1], :] + vl[fl[f, 2], :]) / 3
+    return out
+
+
+def faces_large_adj(faces, K):
+    """ref: utils.py:243-295.  Per vertex (ascending id) every pair of incident faces is appended to both rows."""
+    fnum = faces.shape[0]
+    fadj = np.zeros([fnum, K], dtype=np.int32)
+    find = np.ones([fnum], dtype=np.int64)
+    incident = {}
+    for f in range(fnum):
+        for t in range(3):
+            incident.setdefault(int(faces[f, t]), []).append(f)
+    fadj[:, 0] = np.arange(fnum) + 1
+    for v in sorted(incident):
+        fl = incident[v]
+        for a in range(len(fl)):
+            for b in range(a + 1, len(fl)):
+                f1, f2 = fl[a], fl[b]
+                if find[f1] < K:
+                    fadj[f1, find[f1]] = f2 + 1
+                    find[f1] += 1
+                if find[f2] < K:
+                    fadj[f2, find[f2]] = f1 + 1
+                    find[f2] += 1
+    return fadj
+
+
+def metis_one_level(rr, cc, vv, rid, weights):
+    """ref: lib/coarsening.py:135-192 (float32 arithmetic as numpy >= 2 evaluates it)"""
+    nnz = rr.shape[0]
+    N = rr[nnz - 1] + 1
+    marked = np.zeros(N, bool)
+    rowstart = np.zeros(N, np.int32)
+    rowlength = np.zeros(N, np.int32)
+    cluster_id = np.zeros(N, np.int32)
+    oldval = rr[0]
+    for ii in range(nnz):
+        if rr[ii] > oldval:
+            oldval = rr[ii]
+            rowstart[rr[ii]] = ii
+        rowlength[rr[ii]] += 1
+    clustercount = 0
+    total = np.float32(0.0)
+    for ii in range(N):
+        tid = rid[ii]
+        if marked[tid]:
+            continue
+        wmax = np.float32(0.0)
+        rs = rowstart[tid]
+        marked[tid] = True
+        best = -1
+        for jj in range(rowlength[tid]):
+            nid = cc[rs + jj]
+            if marked[nid]:
+                tval = np.float32(0.0)
+            else:
+                tval = np.float32(vv[rs + jj]) * (np.float32(1.0) / np.float32(weights[tid]) +
+                                                   np.float32(1.0) / np.float32(weights[nid]))
+            if tval > wmax:
+                wmax = tval
+                best = nid
+        cluster_id[tid] = clustercount
+        if best > -1:
+            cluster_id[best] = clustercount
+            marked[best] = True
+        total = np.float32(total + wmax)
+        clustercount += 1
+    return cluster_id, float(total)
+
+
+def compute_perm(parents):
+    """ref: lib/coarsening.py:194-241"""
+    indices = []
+    if len(parents) > 0:
+        indices.append(list(range(max(parents[-1]) + 1)))
+    for parent in parents[::-1]:
+        pool = len(parent)
+        layer = []
+        for i in indices[-1]:
+            node = list(np.where(parent == i)[0])
+            assert 0 <= len(node) <= 2
+            if len(node) == 1:
+                node.append(pool)
+                pool += 1
+            elif len(node) == 0:
+                node += [pool, pool + 1]
+                pool += 2
+            layer.extend(node)
+        indices.append(layer)
+    return indices[::-1]
+
+
+def coarsened_klists(adj, parents, K=23, keep=(0, 2, 4)):
+    """Structure of graph levels given the cluster assignments, then perm_adjacency + sparseToList.
+    ref: lib/coarsening.py:5-31,100-112,269-296; utils.py:1799-1827.  Returns (klists, newToOld)."""
+    n = adj.shape[0]
+    rows, cols = [], []
+    for i in range(n):
+        for k in range(1, adj.shape[1]):
+            j = adj[i, k] - 1
+            if j < 0:
+                break
+            rows.append(i)
+            cols.append(j)
+    graphs = [scipy.sparse.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n, n))]
+    for cid in parents:
+        g = graphs[-1].tocoo()
+        nn = int(cid.max()) + 1
+        graphs.append(scipy.sparse.csr_matrix((g.data, (cid[g.row], cid[g.col])), shape=(nn, nn)))
+    perms = compute_perm(parents)
+    klists = []
+    for lvl in keep:
+        A = graphs[lvl].tocoo()
+        A.setdiag(0)
+        idx = perms[lvl]
+        M, Mnew = A.shape[0], len(idx)
+        if Mnew > M:
+            A = scipy.sparse.vstack([A, scipy.sparse.coo_matrix((Mnew - M, M), dtype=np.float32)])
+            A = scipy.sparse.hstack([A, scipy.sparse.coo_matrix((Mnew, Mnew - M), dtype=np.float32)]).tocoo()
+        perm = np.argsort(idx)
+        A = scipy.sparse.coo_matrix((A.data, (perm[A.row], perm[A.col])), shape=(Mnew, Mnew)).tocsr()
+        A.eliminate_zeros()
+        out = np.zeros((Mnew, K), dtype=np.int32)
+        out[:, 0] = np.arange(Mnew) + 1
+        cur = np.ones(Mnew, dtype=np.int64)
+        cx = A.tocoo()
+        for i, j in zip(cx.row, cx.col):
+            if i != j and cur[i] < K:
+                out[i, cur[i]] = j + 1
+                cur[i] += 1
+        klists.append(out)
+    return klists, np.asarray(perms[0])
+
+
+def inv_perm(perm):
+    """ref: utils.py:1830-1835"""
+    inverse = [0] * max(len(perm), int(np.amax(perm)) + 1)
+    for i, p in enumerate(perm):
+        inverse[p] = i
+    return np.array(inverse)

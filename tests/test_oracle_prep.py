@@ -1,0 +1,47 @@
+"""The preprocessing oracle against the reference fixtures, and the product's native preprocessing against the
+oracle on meshes the fixtures do not cover."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import prep_ref as O
+from facet_graph_convolution_amd import utils
+from facet_graph_convolution_amd.dataClasses import InferenceMesh
+from facet_graph_convolution_amd.meshgen import torus, icosphere, add_noise
+
+
+@pytest.mark.parametrize("tag", ["ico3", "torus640"])
+def test_oracle_matches_reference_fixtures(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "prep_%s.npz" % tag))
+    assert np.array_equal(O.faces_large_adj(z["F"], 23), z["fadj"])
+    assert np.abs(O.face_normals(z["V"], z["F"]) - z["normals"]).max() < 1e-7
+    assert np.abs(O.barycentres(z["V"], z["F"]) - z["centres"]).max() < 1e-7
+    cid, assoc = O.metis_one_level(z["ol_rr"], z["ol_cc"], z["ol_vv"], z["ol_rid"], z["ol_weights"])
+    assert np.array_equal(cid, z["ol_cluster_id"]) and assoc == float(z["ol_assoc"])
+    parents = [z["parents%d" % i] for i in range(4)]
+    klists, new_to_old = O.coarsened_klists(z["fadj"], parents)
+    for l in range(3):
+        assert np.array_equal(klists[l], z["adj%d" % l][0])
+    assert np.array_equal(O.inv_perm(new_to_old), z["permutations"])
+
+
+def test_compute_perm_known_answer_oracle():
+    got = O.compute_perm([np.array([4, 1, 1, 2, 2, 3, 0, 0, 3]), np.array([2, 1, 0, 1, 0])])
+    assert got == [[3, 4, 0, 9, 1, 2, 5, 8, 6, 7, 10, 11], [2, 4, 1, 3, 0, 5], [0, 1, 2]]
+
+
+@pytest.mark.parametrize("mesh", ["torus30x20", "ico2"])
+def test_native_preprocessing_matches_oracle_on_other_meshes(mesh):
+    V, F = torus(30, 20) if mesh == "torus30x20" else icosphere(2)
+    V = add_noise(V, F)
+    assert np.array_equal(utils.getFacesLargeAdj(F, 23), O.faces_large_adj(F, 23))
+    n, c = utils.face_features(V, F)
+    assert np.abs(n - O.face_normals(V, F)).max() < 1e-6 and np.abs(c - O.barycentres(V, F)).max() < 1e-7
+    # the product draws its own pairing; given ITS cluster assignments the oracle must rebuild the same tensors
+    m = InferenceMesh()
+    m.addMesh(V, F, seed=11)
+    klists, new_to_old = O.coarsened_klists(utils.getFacesLargeAdj(F, 23), m.parents_list[0])
+    for l in range(3):
+        assert np.array_equal(klists[l], m.adj_list[0][l][0])
+    assert np.array_equal(O.inv_perm(new_to_old), m.permutations[0])
