@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfgc.so")
+LIB_PATH = os.environ.get("FGC_LIB", os.path.join(_HERE, "csrc", "libfgc.so"))  # FGC_LIB: developer A/B builds
 
 FGC_M = 9
 AG_LD = 24

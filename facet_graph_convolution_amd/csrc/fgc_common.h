@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/fgc.h"
 
@@ -82,6 +83,10 @@ static inline ConvGeom conv_geom(int cin, int cout) {
     g.cout = cout;
     int lpn = 2;
     while (lpn < 8 && lpn * 4 < cin) lpn *= 2;
+    if (const char* f = getenv("FGC_FORCE_LPN")) {   // developer experiment
+        const int v = atoi(f);
+        if ((v == 2 || v == 4 || v == 8) && v < lpn) lpn = v;
+    }
     g.lpn = lpn;
     g.kc = 4 * lpn;
     g.passes = (cin + g.kc - 1) / g.kc;

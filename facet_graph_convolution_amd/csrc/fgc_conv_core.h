@@ -22,7 +22,10 @@
 namespace fgc {
 
 constexpr int TILE = 32;        // nodes per workgroup
-constexpr int KMAX = 24;        // >= K_faces (23) edge slots per node kept in LDS
+#ifndef FGC_KMAX
+#define FGC_KMAX 24
+#endif
+constexpr int KMAX = FGC_KMAX;  // >= K_faces (23) edge slots per node kept in LDS
 constexpr int QLD = 12;         // floats per edge in qbuf: q[0..8], [9] = source row of the neighbour (int bits)
 constexpr int NTHREADS = 256;
 constexpr int MAX_NPAD = 128;   // GEMM N limit (cout / cin of the transposed op)
@@ -93,17 +96,35 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
     }
     if (kl == 0) s.deg[node] = d;
     const int kend = min(d, kbase + KMAX);
-    for (int kk = kbase + kl; kk < kend; kk += 8) {
+    // all neighbour ids first, then all their logit rows: two memory round trips for the (up to 3) edges of this
+    // thread instead of two per edge
+    constexpr int EPT = KMAX / 8;  // edges per thread
+    int jj[EPT];
+    f32x4 g0[EPT], g1[EPT];
+    float g8[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int kk = kbase + kl + 8 * t;
+        jj[t] = kk < kend ? p.col[e0 + kk] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const float* gr = p.ag + (size_t)(jj[t] >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
+        g0[t] = *reinterpret_cast<const f32x4*>(gr);
+        g1[t] = *reinterpret_cast<const f32x4*>(gr + 4);
+        g8[t] = gr[8];
+    }
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int kk = kbase + kl + 8 * t;
+        if (kk >= kend) continue;
         const int e = e0 + kk;
         const int k = kk - kbase;
-        const int j = p.col[e];
-        const float* gr = p.ag + (size_t)(j >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gr + 4);
+        const int j = jj[t];
         float l[FGC_M];
-        l[0] = ctr[0] + g0[0]; l[1] = ctr[1] + g0[1]; l[2] = ctr[2] + g0[2]; l[3] = ctr[3] + g0[3];
-        l[4] = ctr[4] + g1[0]; l[5] = ctr[5] + g1[1]; l[6] = ctr[6] + g1[2]; l[7] = ctr[7] + g1[3];
-        l[8] = ctr[8] + gr[8];
+        l[0] = ctr[0] + g0[t][0]; l[1] = ctr[1] + g0[t][1]; l[2] = ctr[2] + g0[t][2]; l[3] = ctr[3] + g0[t][3];
+        l[4] = ctr[4] + g1[t][0]; l[5] = ctr[5] + g1[t][1]; l[6] = ctr[6] + g1[t][2]; l[7] = ctr[7] + g1[t][3];
+        l[8] = ctr[8] + g8[t];
         float mx = l[0];
 #pragma unroll
         for (int m = 1; m < FGC_M; ++m) mx = fmaxf(mx, l[m]);
@@ -192,6 +213,30 @@ __device__ __forceinline__ void fma_rows(const float* qb, int d, int k0, const f
             z[8] += q8 * xv[t];
         }
     }
+}
+
+// ---- early gathers: the neighbour rows of the first RB edges are requested at kernel entry (row ids straight from
+// the CSR), so that the memory round trip runs under the softmax phase; later passes are requested one pass ahead.
+template <int LPN>
+__device__ __forceinline__ void early_row_ids(const CoreParams& p, int tile0, int (&rows)[RB], int& d) {
+    const int node = threadIdx.x / LPN;
+    const int i = tile0 + node;
+    d = 0;
+    int e0 = 0;
+    if (node < TILE && i < p.n) {
+        e0 = p.rowptr[i];
+        d = p.rowptr[i + 1] - e0;
+    }
+#pragma unroll
+    for (int t = 0; t < RB; ++t) rows[t] = d > 0 ? (p.col[e0 + min(t, d - 1)] >> p.shift) : 0;
+}
+
+template <int LPN, bool VEC4>
+__device__ __forceinline__ void issue_rows(const CoreParams& p, const int (&rows)[RB], int pass, f32x4 (&xv)[RB]) {
+    const int cl = threadIdx.x % LPN;
+    const int cbase = pass * p.kc + cl * 4;
+#pragma unroll
+    for (int t = 0; t < RB; ++t) xv[t] = load_chunk<VEC4>(p, rows[t], cbase);
 }
 
 // ---- phase A: z[m][4] = sum_k q[k][m] * x_j(k)[4] ---------------------------------------------
