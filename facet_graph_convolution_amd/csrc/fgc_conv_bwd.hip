@@ -287,6 +287,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p,
 // ---------------------------------------------------------------------------------------------
 constexpr int NPW = TILE / 4;  // nodes per wave
 
+template <bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
             const int node = wave * NPW;
             const int d = __builtin_amdgcn_readfirstlane(min(s.deg[node], KMAX));
             const int row = d > 0 ? rowof(node, d, 0) : 0;
-            bc[0] = load_chunk<true>(p, row, cpass + 4 * lq);
-            bc[1] = load_chunk<true>(p, row, cpass + 16 + 4 * lq);
+            bc[0] = load_chunk<VEC4>(p, row, cpass + 4 * lq);
+            bc[1] = load_chunk<VEC4>(p, row, cpass + 16 + 4 * lq);
         }
 #pragma unroll
         for (int nn = 0; nn < NPW; ++nn) {
@@ -374,8 +375,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
             if (nn + 1 < NPW) {  // next node's rows are requested before this node's MFMAs
                 const int nd = __builtin_amdgcn_readfirstlane(min(s.deg[node + 1], KMAX));
                 const int row = nd > 0 ? rowof(node + 1, nd, 0) : 0;
-                bn[0] = load_chunk<true>(p, row, cpass + 4 * lq);
-                bn[1] = load_chunk<true>(p, row, cpass + 16 + 4 * lq);
+                bn[0] = load_chunk<VEC4>(p, row, cpass + 4 * lq);
+                bn[1] = load_chunk<VEC4>(p, row, cpass + 16 + 4 * lq);
             }
             const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
                 dq[nn][0] += t0 + t1;
                 if (d > 16) {  // rare: 17..24 neighbours
                     const int row = rowof(node, d, 1);
-                    const f32x4 x0 = load_chunk<true>(p, row, cpass + 4 * lq);
-                    const f32x4 x1 = load_chunk<true>(p, row, cpass + 16 + 4 * lq);
+                    const f32x4 x0 = load_chunk<VEC4>(p, row, cpass + 4 * lq);
+                    const f32x4 x1 = load_chunk<VEC4>(p, row, cpass + 16 + 4 * lq);
                     f32x4 u0 = f32x4{0.f, 0.f, 0.f, 0.f}, u1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -840,16 +841,22 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         LogitParams lp{io->ds, cout, opad, ostride, w.Wq, io->dl, io->dag, w.dc_part};
         const size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
         const bool vec4 = conv_vec4_ok(d);
-        if (g1.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX &&
+        if (g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX &&
             !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1')) {
             static bool attr = false;
             if (!attr) {
-                hipFuncSetAttribute((const void*)conv_bwd_logits_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024);
+                hipFuncSetAttribute((const void*)conv_bwd_logits_mfma_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)conv_bwd_logits_mfma_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr = true;
             }
-            FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, conv_bwd_logits_mfma_kernel, dim3(cdiv(d->n, TILE)),
-                       dim3(NTHREADS), smem, p, lp);
+            if (vec4)
+                FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, (conv_bwd_logits_mfma_kernel<true>),
+                           dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);
+            else
+                FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, (conv_bwd_logits_mfma_kernel<false>),
+                           dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);
             FGC_CHECK_LAUNCH("fgc_conv_bwd/logits_mfma");
             rc = 0;
         } else

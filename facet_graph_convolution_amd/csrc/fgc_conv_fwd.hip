@@ -1,6 +1,8 @@
 // Forward graph convolution (replaces custom_conv2d, /root/reference/Code/model.py:427-504).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "fgc_conv_pc.h"
 
 namespace fgc {
@@ -32,60 +34,65 @@ __global__ void pack_weight_kernel(const float* __restrict__ W0, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// assignment logits: ag[r][m] = u[m].x_r + c[m], ag[r][12+m] = v[m].x_r   (model.py:79-80,94)
-// one lane per source row; x staged through LDS in 32-channel chunks.
+// assignment logits on the matrix cores: ag[rows, 24] = x[rows, cin] * [u | v]^T (+ c).  One wave per 16 rows, A
+// fragments straight from global memory (one dwordx4 per lane per 16 channels), B = [u|v] staged once per workgroup
+// in LDS (column tile 0 = the 9 a-logits, tile 1 = the 9 g-logits).  Streams x exactly once: HBM-bound.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void proj_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                   int c0, int c1, int rows, const float* __restrict__ u,
-                                                   const float* __restrict__ c, const float* __restrict__ v,
-                                                   float* __restrict__ ag) {
-    __shared__ float xs[256][33];
-    __shared__ float us[FGC_M][32];
-    __shared__ float vs[FGC_M][32];
+template <bool VEC4>
+__global__ __launch_bounds__(256) void proj_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                        int c0, int c1, int rows, const float* __restrict__ u,
+                                                        const float* __restrict__ c, const float* __restrict__ v,
+                                                        float* __restrict__ ag) {
+    __shared__ __attribute__((aligned(16))) float Bs[128 * 32];   // [k][32]
     const int cin = c0 + c1;
-    const int r0 = blockIdx.x * 256;
-    const int tid = threadIdx.x;
-    float a[FGC_M], g[FGC_M];
-#pragma unroll
-    for (int m = 0; m < FGC_M; ++m) {
-        a[m] = 0.f;
-        g[m] = 0.f;
+    const int kpad = (cin + 15) & ~15;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    for (int t = tid; t < kpad * 32; t += 256) {
+        const int k = t >> 5, col = t & 31;
+        float val = 0.f;
+        if (k < cin) {
+            if (col < FGC_M) val = u[col * cin + k];
+            else if (col >= 16 && col < 16 + FGC_M) val = v[(col - 16) * cin + k];
+        }
+        Bs[t] = val;
     }
-    for (int cb = 0; cb < cin; cb += 32) {
-        const int cw = min(32, cin - cb);
-        __syncthreads();
-        for (int t = tid; t < 256 * 32; t += 256) {
-            const int rr = t >> 5, cc = t & 31;
-            const int r = r0 + rr, ch = cb + cc;
-            float val = 0.f;
-            if (r < rows && cc < cw) val = ch < c0 ? x0[(size_t)r * c0 + ch] : x1[(size_t)r * c1 + (ch - c0)];
-            xs[rr][cc] = val;
-        }
-        for (int t = tid; t < FGC_M * 32; t += 256) {
-            const int m = t >> 5, cc = t & 31;
-            us[m][cc] = cc < cw ? u[m * cin + cb + cc] : 0.f;
-            vs[m][cc] = cc < cw ? v[m * cin + cb + cc] : 0.f;
-        }
-        __syncthreads();
-        for (int cc = 0; cc < cw; ++cc) {
-            const float xv = xs[tid][cc];
+    __syncthreads();
+    const float cbias = lr < FGC_M ? c[lr] : 0.f;
+    const int ntile = (rows + 15) >> 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+        const int row = min(tile * 16 + lr, rows - 1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < kpad; kb += 16) {
+            const int cb = kb + 4 * lq;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (VEC4) {
+                if (cb < c0) a = *reinterpret_cast<const f32x4*>(x0 + (size_t)row * c0 + cb);
+                else if (cb < cin) a = *reinterpret_cast<const f32x4*>(x1 + (size_t)row * c1 + (cb - c0));
+            } else {
 #pragma unroll
-            for (int m = 0; m < FGC_M; ++m) {
-                a[m] = fmaf(us[m][cc], xv, a[m]);
-                g[m] = fmaf(vs[m][cc], xv, g[m]);
+                for (int t = 0; t < 4; ++t) {
+                    const int ch = cb + t;
+                    if (ch < c0) a[t] = x0[(size_t)row * c0 + ch];
+                    else if (ch < cin) a[t] = x1[(size_t)row * c1 + (ch - c0)];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Bs[(cb + t) * 32 + lr], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Bs[(cb + t) * 32 + 16 + lr], acc1, 0, 0, 0);
             }
         }
-    }
-    const int r = r0 + tid;
-    if (r < rows) {
-        float* o = ag + (size_t)r * FGC_AG_LD;
+        // C layout: column = lr (logit index), row = lq*4 + reg
+        if (lr < 12) {
 #pragma unroll
-        for (int m = 0; m < FGC_M; ++m) {
-            o[m] = a[m] + c[m];
-            o[12 + m] = g[m];
+            for (int t = 0; t < 4; ++t) {
+                const int r = tile * 16 + lq * 4 + t;
+                if (r < rows) {
+                    ag[(size_t)r * FGC_AG_LD + lr] = lr < FGC_M ? acc0[t] + cbias : 0.f;
+                    ag[(size_t)r * FGC_AG_LD + 12 + lr] = lr < FGC_M ? acc1[t] : 0.f;
+                }
+            }
         }
-        o[9] = o[10] = o[11] = 0.f;
-        o[21] = o[22] = o[23] = 0.f;
     }
 }
 
@@ -270,8 +277,15 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
                        cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
     FGC_CHECK_LAUNCH("fgc_conv_fwd/pack");
     const int rows = d->src_rows > 0 ? d->src_rows : (d->n >> d->shift);
-    FGC_LAUNCH("proj_kernel", st, proj_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, d->x0, d->x1, d->c0, d->c1, rows, d->u,
-                       d->c, d->v, ag);
+    {
+        const int pg = std::min(cdiv(cdiv(rows, 16), 4), 1024);
+        if (conv_vec4_ok(d))
+            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true>), dim3(pg), dim3(256), 0, d->x0, d->x1, d->c0,
+                       d->c1, rows, d->u, d->c, d->v, ag);
+        else
+            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<false>), dim3(pg), dim3(256), 0, d->x0, d->x1, d->c0,
+                       d->c1, rows, d->u, d->c, d->v, ag);
+    }
     FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
 
     CoreParams p;
