@@ -52,7 +52,8 @@ struct CoreParams {
 struct Smem {
     float* ztile;   // [TILE][zstride]
     float* qbuf;    // [TILE][KMAX][QLD]  (slot 9 of each row: neighbour source row, already >> shift)
-    int* deg;       // [TILE] + 4 scratch ints (no static __shared__: keeps the dynamic base 16-B aligned)
+    int* deg;       // [TILE] degrees, 4 scratch ints, [TILE] first-edge ids (no static __shared__: keeps the
+                    // dynamic base 16-B aligned)
     float* extra;   // op specific
 };
 
@@ -63,12 +64,12 @@ __device__ __forceinline__ Smem carve(char* base, int zstride) {
     s.qbuf = reinterpret_cast<float*>(base + off);
     off += (size_t)TILE * KMAX * QLD * 4;
     s.deg = reinterpret_cast<int*>(base + off);
-    off += (TILE + 4) * 4;
+    off += (2 * TILE + 4) * 4;
     s.extra = reinterpret_cast<float*>(base + off);
     return s;
 }
 static inline size_t smem_core_bytes(int zstride) {
-    return (size_t)TILE * zstride * 4 + (size_t)TILE * KMAX * QLD * 4 + (TILE + 4) * 4;
+    return (size_t)TILE * zstride * 4 + (size_t)TILE * KMAX * QLD * 4 + (2 * TILE + 4) * 4;
 }
 
 // ---- phase S: per-edge soft assignment ------------------------------------------------------
@@ -94,7 +95,10 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
         ctr[4] = a1[0]; ctr[5] = a1[1]; ctr[6] = a1[2]; ctr[7] = a1[3];
         ctr[8] = ar[8];
     }
-    if (kl == 0) s.deg[node] = d;
+    if (kl == 0) {
+        s.deg[node] = d;
+        s.deg[TILE + 4 + node] = e0;
+    }
     const int kend = min(d, kbase + KMAX);
     // all neighbour ids first, then all their logit rows: two memory round trips for the (up to 3) edges of this
     // thread instead of two per edge
