@@ -459,22 +459,42 @@ class FacetDenoiser:
     # ------------------------------------------------------------------------------------------
     # public API
     # ------------------------------------------------------------------------------------------
+    def _upload(self, dst, host_array):
+        """Stream-ordered host -> device update of a small per-step input.  The source is a fresh PINNED tensor and
+        the copy is non_blocking: it is a DMA enqueued on the current stream (so it cannot overtake kernels of the
+        previous step that still read `dst`), and torch's caching host allocator keeps the pinned block alive until
+        the copy has run.  A plain pageable copy is not ordered against in-flight work on ROCm: with several steps
+        queued it changed the inputs of steps that had not executed yet."""
+        t = torch.from_numpy(np.ascontiguousarray(host_array)).pin_memory()
+        dst.copy_(t, non_blocking=True)
+
     def set_rotation(self, R):
         """R [3,3] (train.py:563-565); identity = no augmentation."""
-        self._mesh["B"]["R"].copy_(torch.as_tensor(np.asarray(R, dtype=np.float32).reshape(9)))
+        self._upload(self._mesh["B"]["R"], np.asarray(R, dtype=np.float32).reshape(9))
 
     def set_samples(self, sample_ind):
         """Indices of the rows the loss is evaluated on (train.py:561), any of the N0 padded rows."""
-        t = torch.as_tensor(np.asarray(sample_ind).astype(np.int32))
+        t = np.asarray(sample_ind).astype(np.int32)
         B = self._mesh["B"]
-        if t.numel() != B["sample_ind"].numel():
-            B["sample_ind"] = torch.empty(t.numel(), dtype=torch.int32, device=self.device)
+        if t.size != B["sample_ind"].numel():
+            B["sample_ind"] = torch.empty(t.size, dtype=torch.int32, device=self.device)
             self._graph_fb = None
-        B["sample_ind"].copy_(t)
+        self._upload(B["sample_ind"], t)
         if self.sharded:
             lo = self._mesh["own_lo"]
             loc = t[(t >= lo) & (t < lo + self._mesh["ns"][0])] - lo
-            B["sample_ind_local"] = loc.to(torch.int32).to(self.device)
+            buf = torch.empty(loc.size, dtype=torch.int32, device=self.device)
+            if loc.size:
+                self._upload(buf, loc.astype(np.int32))
+            B["sample_ind_local"] = buf
+
+    def set_step_inputs_device(self, sample_ind_dev, R_dev):
+        """Per-step inputs that are ALREADY on the device (e.g. a window of steps uploaded in one go): device-to-device
+        copies are kernels on the compute queue, ordered with hipGraph replays; host -> device DMAs between replays of a
+        captured graph were observed to race on this stack when many steps are queued."""
+        B = self._mesh["B"]
+        B["sample_ind"].copy_(sample_ind_dev)
+        B["R"].copy_(R_dev.reshape(9))
 
     def forward(self, rotate=False):
         """Normalised normals of the bound mesh: [N0,3] (padded, permuted order). Un-normalised output in buffers['y0']."""

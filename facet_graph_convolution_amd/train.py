@@ -59,7 +59,7 @@ def load_checkpoint(path, net):
 
 
 def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device="cuda", seed=0, log=print,
-             capture=True, validSet=None):
+             capture=False, validSet=None):
     """train.py:380-632.  trainSet / validSet: dataClasses.TrainingSet.  Returns (net, lossArray [iters/50, 2])."""
     meshes = []
     for i in range(len(trainSet.in_list)):
