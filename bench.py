@@ -241,7 +241,7 @@ def main():
             if layer in dims:
                 if "conv_fwd_kernel" in kern:
                     kind = "fwd"
-                elif "conv_bwd_logits_kernel" in kern:
+                elif "conv_bwd_logits" in kern:
                     kind = "bwd_logits"
                 elif "conv_bwd_data_kernel" in kern:
                     kind = "bwd_data"
@@ -264,8 +264,16 @@ def main():
         if dom:
             ms, key, cnt, avg_us, fl = dom
             ach = fl / (avg_us * 1e-6) / 1e12
+            # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
+            # gfx950 correction of MI355X_MICROARCH.md); null when the dominant kernel has no recorded pass
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "r1_traffic_dominant_kernel.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("kernel") == key and args.nu == 250 and args.nv == 200:
+                    traffic = tj["hbm_bytes_per_launch"]
             roofline = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                         "avg_kernel_us": round(avg_us, 2), "launch_flops": fl,
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3)}
 
