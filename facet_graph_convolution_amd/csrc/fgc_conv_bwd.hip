@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p,
     const Smem s = carve(smem_raw, p.zstride);
     float* dst = s.extra;                       // ds tile [TILE][ostride]
     float* red = dst + TILE * lp.ostride;       // [4][12] block reduction scratch
-    const int tile0 = blockIdx.x * TILE;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     constexpr int SLOTS = KMAX / LPN;           // edges owned per lane: k = slot*LPN + cl
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
     const Smem s = carve(smem_raw, p.zstride);
     float* dst = s.extra;                       // ds tile [TILE][ostride]
     float* red = dst + TILE * lp.ostride;       // [4][12]
-    const int tile0 = blockIdx.x * TILE;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
 
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
     float* dagt = s.extra;  // [TILE][24]: da | dg of the tile's nodes
-    const int tile0 = blockIdx.x * TILE;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
     const int tid = threadIdx.x;
     const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 
@@ -878,6 +878,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
+        if (g2.lpn == 8 && w8_supported(p, io->max_in_deg)) {
+            rc = launch_data_w8(p, ep, smem, st);
+            if (rc) return rc;
+        } else
         if (g2.lpn == 8 && vec4 && io->max_in_deg > 0 && io->max_in_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1')) {
             rc = launch_data_pc(p, ep, g2, st);
             if (rc) return rc;

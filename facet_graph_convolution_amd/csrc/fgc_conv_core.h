@@ -48,6 +48,17 @@ struct CoreParams {
     const float* Wp;         // packed B operand [passes*kpass/4][npad] float4
 };
 
+// ---- workgroup -> tile map ----------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its private 4 MB L2).  The node order
+// is spatially coherent, so tiles that are close in index gather overlapping neighbour rows: give every XCD a
+// CONTIGUOUS range of tiles, then those rows are fetched into one L2 and hit there for the neighbouring tiles,
+// instead of being fetched by all eight L2s from the Infinity Cache.  Bijective for any tile count.  Speed only.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---- LDS carve ---------------------------------------------------------------------------
 struct Smem {
     float* ztile;   // [TILE][zstride]

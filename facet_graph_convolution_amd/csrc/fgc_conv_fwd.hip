@@ -103,7 +103,7 @@ template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(CoreParams p, FwdEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
-    const int tile0 = blockIdx.x * TILE;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
     const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 
     const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
@@ -294,6 +294,7 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FwdEpilogue ep{d->b, d->bias_mask, d->act, d->alpha, y, y_pool};
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
+    if (g.lpn == 8 && w8_supported(p, d->max_deg)) return launch_fwd_w8(p, ep, smem, st);
     if (g.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1'))
         return launch_fwd_pc(p, ep, g, st);
     switch (g.lpn) {

@@ -28,6 +28,10 @@ struct DataEpilogue {
 };
 
 size_t pc_smem_bytes(const ConvGeom& g);
+// eight-wave kernels (fgc_conv_w8.hip)
+bool w8_supported(const CoreParams& p, int max_deg);
+int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, hipStream_t st);
+int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, hipStream_t st);
 int launch_fwd_pc(const CoreParams& p, const FwdEpilogue& ep, const ConvGeom& g, hipStream_t st);
 int launch_data_pc(const CoreParams& p, const DataEpilogue& ep, const ConvGeom& g, hipStream_t st);
 

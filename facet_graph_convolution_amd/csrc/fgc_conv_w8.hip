@@ -1,0 +1,351 @@
+// Eight-wave form of the fused graph-conv core (forward conv and backward-data conv).
+//
+// Same algorithm, LDS layout and tile (32 nodes) as fgc_conv_core.h, but a workgroup has 512 threads = 8 waves:
+// 16 lanes per node (float2 per lane in the gather, 18 accumulators instead of 36), two softmax edges per thread
+// instead of three, one column tile per wave in the MFMA phase.  Registers stay under 128 per thread, so with the
+// unchanged 75 KB of LDS two workgroups = 16 waves are resident per CU (4 per SIMD instead of 2): twice the waves to
+// cover the gather latency and to keep the matrix pipe busy across the phase barriers.
+// Used when the gathered width and the output width are multiples of 16 / powers of two (all network layers) and
+// no node has more than 24 edges; everything else takes the 4-wave kernels.
+#include <stdlib.h>
+
+#include "fgc_conv_pc.h"
+
+namespace fgc {
+
+constexpr int W8_THREADS = 512;
+constexpr int W8_LPN = 16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 load_chunk2(const CoreParams& p, int row, int cbase) {
+    // channels [cbase, cbase+2) of the concatenated source row (c0, c1 even; pointers 8-byte aligned)
+    const float* ptr = cbase < p.c0 ? p.src0 + (size_t)row * p.c0 + cbase
+                                    : p.src1 + (size_t)row * p.c1 + (cbase - p.c0);
+    f32x2 v = {0.f, 0.f};
+    if (cbase < p.cg) v = *reinterpret_cast<const f32x2*>(ptr);
+    return v;
+}
+
+template <bool DATA>
+__global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw, p.zstride);
+    float* dagt = s.extra;  // DATA: [TILE][24]
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    const int tid = threadIdx.x;
+    const int node = tid >> 4, kl = tid & 15;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+
+    // ---------------- phase S: per-edge soft assignment (edges kl and kl + 16 of this thread's node)
+    float dgsum[FGC_M];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) dgsum[m] = 0.f;
+    {
+        const int i = tile0 + node;
+        int d = 0, e0 = 0;
+        float ctr[FGC_M];
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) ctr[m] = 0.f;
+        if (i < p.n) {
+            e0 = p.rowptr[i];
+            d = min(p.rowptr[i + 1] - e0, KMAX);
+            const float* ar = p.ag + (size_t)(i >> p.ag_shift) * FGC_AG_LD + p.ctr_off;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+            ctr[0] = a0[0]; ctr[1] = a0[1]; ctr[2] = a0[2]; ctr[3] = a0[3];
+            ctr[4] = a1[0]; ctr[5] = a1[1]; ctr[6] = a1[2]; ctr[7] = a1[3];
+            ctr[8] = ar[8];
+        }
+        if (kl == 0) s.deg[node] = d;
+        int jj[2];
+        f32x4 g0[2], g1[2];
+        float g8[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = kl + 16 * t;
+            jj[t] = k < d ? p.col[e0 + k] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* gr = p.ag + (size_t)(jj[t] >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
+            g0[t] = *reinterpret_cast<const f32x4*>(gr);
+            g1[t] = *reinterpret_cast<const f32x4*>(gr + 4);
+            g8[t] = gr[8];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = kl + 16 * t;
+            if (k >= d) continue;
+            float l[FGC_M];
+            l[0] = ctr[0] + g0[t][0]; l[1] = ctr[1] + g0[t][1]; l[2] = ctr[2] + g0[t][2]; l[3] = ctr[3] + g0[t][3];
+            l[4] = ctr[4] + g1[t][0]; l[5] = ctr[5] + g1[t][1]; l[6] = ctr[6] + g1[t][2]; l[7] = ctr[7] + g1[t][3];
+            l[8] = ctr[8] + g8[t];
+            float mx = l[0];
+#pragma unroll
+            for (int m = 1; m < FGC_M; ++m) mx = fmaxf(mx, l[m]);
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                l[m] = expf(l[m] - mx);
+                sum += l[m];
+            }
+            const float inv = 1.0f / sum;
+            float* q = s.qbuf + ((size_t)node * KMAX + k) * QLD;
+            *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
+            *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
+            q[8] = l[8] * inv;
+            q[9] = __int_as_float(jj[t] >> p.shift);
+            if (DATA) {
+                const float* dr = de.dl + (size_t)p.eid[e0 + k] * FGC_DL_LD;
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dr);
+                const f32x4 d1 = *reinterpret_cast<const f32x4*>(dr + 4);
+                dgsum[0] += d0[0]; dgsum[1] += d0[1]; dgsum[2] += d0[2]; dgsum[3] += d0[3];
+                dgsum[4] += d1[0]; dgsum[5] += d1[1]; dgsum[6] += d1[2]; dgsum[7] += d1[3];
+                dgsum[8] += dr[8];
+            }
+        }
+        if (DATA) {  // dg_j = sum over in-edges of dl: reduce the 16 softmax lanes of the node
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                float v = dgsum[m];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                dgsum[m] = v;
+            }
+            if (kl == 0) {
+                float* t = dagt + node * 24;
+                if (i < p.n) {
+                    const float* da = de.dag + (size_t)i * FGC_AG_LD;
+#pragma unroll
+                    for (int m = 0; m < FGC_M; ++m) {
+                        t[m] = da[m];
+                        t[12 + m] = dgsum[m];
+                    }
+                    float* o = de.dag + (size_t)i * FGC_AG_LD + 12;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
+                    *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 24; ++m) t[m] = 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- MFMA tiling: wave w owns column tile (w % nct) and k-part (w / nct)
+    const int nct = p.npad >> 4;              // 1, 2, 4 or 8
+    const int kparts = 8 / nct;
+    const int ct = __builtin_amdgcn_readfirstlane(wave % nct);
+    const int kpart = __builtin_amdgcn_readfirstlane(wave / nct);
+    const int kg_total = p.kpass >> 4;
+    const int kg0 = __builtin_amdgcn_readfirstlane(kg_total * kpart / kparts);
+    const int kg1 = __builtin_amdgcn_readfirstlane(kg_total * (kpart + 1) / kparts);
+    const f32x4* Wp4 = reinterpret_cast<const f32x4*>(p.Wp);
+    f32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_gemm = !DATA || de.dx0 != nullptr;
+
+    const int cl = kl;
+    const int d = s.deg[node];
+    const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
+    for (int pass = 0; pass < p.passes; ++pass) {
+        // ---------------- phase A: z[m][2] = sum_k q[k][m] * x_j(k)[2]; every row is requested before the first FMA
+        f32x2 z[FGC_M];
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) z[m] = f32x2{0.f, 0.f};
+        const int cbase = pass * p.kc + 2 * cl;
+        for (int k0 = 0; k0 < d; k0 += RB) {
+            f32x2 xv[RB];
+#pragma unroll
+            for (int t = 0; t < RB; ++t) {
+                xv[t] = f32x2{0.f, 0.f};
+                if (k0 + t < d) xv[t] = load_chunk2(p, __float_as_int(qb[(k0 + t) * QLD + 9]), cbase);
+            }
+#pragma unroll
+            for (int t = 0; t < RB; ++t) {
+                if (k0 + t < d) {
+                    const float* q = qb + (k0 + t) * QLD;
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(q);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + 4);
+                    const float q8 = q[8];
+                    z[0] += q0[0] * xv[t]; z[1] += q0[1] * xv[t]; z[2] += q0[2] * xv[t]; z[3] += q0[3] * xv[t];
+                    z[4] += q1[0] * xv[t]; z[5] += q1[1] * xv[t]; z[6] += q1[2] * xv[t]; z[7] += q1[3] * xv[t];
+                    z[8] += q8 * xv[t];
+                }
+            }
+        }
+        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
+            const int j = tile0 + node;
+            if (j < p.n && cbase < p.cg) {
+                float* rr = de.r + (size_t)j * de.rld + cbase;
+#pragma unroll
+                for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(rr + m * p.cg) = z[m];
+            }
+            if (!want_gemm) continue;
+        }
+        if (pass > 0) __syncthreads();  // previous pass' MFMA reads of ztile are done
+        {
+            float* zr = s.ztile + (size_t)node * p.zstride + 2 * cl;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(zr + m * p.kc) = z[m];
+        }
+        __syncthreads();
+        // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
+        {
+            const size_t wrow0 = (size_t)pass * (p.kpass >> 2);
+            auto loadb = [&](int g) {
+                const int gg = min(g, kg1 - 1);
+                return Wp4[(wrow0 + gg * 4 + lq) * p.npad + ct * 16 + lr];
+            };
+            auto loada = [&](int g, f32x4 (&a)[RT]) {
+                const int gg = min(g, kg1 - 1);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + gg * 16 + lq * 4);
+            };
+            auto mm = [&](const f32x4 (&a)[RT], const f32x4& b) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r], 0, 0, 0);
+            };
+            f32x4 b0 = loadb(kg0), b1 = loadb(kg0 + 1), b2 = loadb(kg0 + 2), b3 = loadb(kg0 + 3);
+            f32x4 a0[RT], a1[RT];
+            int g = kg0;
+            loada(g, a0);
+            for (; g + 4 <= kg1; g += 4) {
+                loada(g + 1, a1);
+                mm(a0, b0);
+                b0 = loadb(g + 4);
+                loada(g + 2, a0);
+                mm(a1, b1);
+                b1 = loadb(g + 5);
+                loada(g + 3, a1);
+                mm(a0, b2);
+                b2 = loadb(g + 6);
+                loada(g + 4, a0);
+                mm(a1, b3);
+                b3 = loadb(g + 7);
+            }
+            if (g < kg1) {
+                loada(g + 1, a1);
+                mm(a0, b0);
+            }
+            if (g + 1 < kg1) {
+                loada(g + 2, a0);
+                mm(a1, b1);
+            }
+            if (g + 2 < kg1) mm(a0, b2);
+        }
+    }
+    if (!want_gemm) return;
+    __syncthreads();
+    // ---------------- accumulators -> LDS (aliases ztile), k-parts summed in fixed order by the epilogue
+    const int oldd = p.npad + 4;
+    float* otile = s.ztile;
+    {
+        float* base = otile + (size_t)kpart * TILE * oldd;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) base[(size_t)(r * 16 + lq * 4 + t) * oldd + ct * 16 + lr] = acc[r][t];
+    }
+    __syncthreads();
+    if (!DATA) {
+        for (int t = tid; t < (TILE / 4) * p.nout; t += W8_THREADS) {
+            const int pr = t / p.nout, o = t % p.nout;
+            float mx = -INFINITY;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = pr * 4 + q;
+                const int i = tile0 + row;
+                if (i >= p.n) continue;
+                float val = 0.f;
+                for (int kp = 0; kp < kparts; ++kp) val += otile[((size_t)kp * TILE + row) * oldd + o];
+                const int dd = s.deg[row];
+                // deg was clamped to KMAX for the edge loops; the true degree equals it here (host guarantees <= 24)
+                const float inv = dd > 0 ? 1.0f / (float)dd : 0.f;
+                val *= inv;
+                if (!fe.bias_mask || dd > 0) val += fe.bias[o];
+                if (fe.act) val = fmaxf(val, 0.f) - fe.alpha * fmaxf(-val, 0.f);
+                fe.y[(size_t)i * p.nout + o] = val;
+                mx = fmaxf(mx, val);
+                any = true;
+            }
+            if (fe.y_pool && any) fe.y_pool[(size_t)((tile0 >> 2) + pr) * p.nout + o] = mx;
+        }
+    } else {
+        const int group = 1 << de.shiftf;
+        const int nsrc = TILE / group;
+        for (int t = tid; t < nsrc * de.cin; t += W8_THREADS) {
+            const int sr = t / de.cin, c = t % de.cin;
+            float val = 0.f;
+            bool any = false;
+            for (int q = 0; q < group; ++q) {
+                const int row = sr * group + q;
+                if (tile0 + row >= p.n) continue;
+                any = true;
+                float g = 0.f;
+                for (int kp = 0; kp < kparts; ++kp) g += otile[((size_t)kp * TILE + row) * oldd + c];
+                const float* dg = dagt + row * 24;
+#pragma unroll
+                for (int m = 0; m < FGC_M; ++m) {
+                    g = fmaf(dg[m], de.u[m * de.cin + c], g);
+                    g = fmaf(dg[12 + m], de.v[m * de.cin + c], g);
+                }
+                val += g;
+            }
+            if (!any) continue;
+            const size_t srow = (size_t)((tile0 >> de.shiftf) + sr);
+            if (c < de.c0f) {
+                float* o = de.dx0 + srow * de.c0f + c;
+                *o = de.acc0 ? *o + val : val;
+            } else if (de.dx1) {
+                float* o = de.dx1 + srow * de.c1f + (c - de.c0f);
+                *o = de.acc1 ? *o + val : val;
+            }
+        }
+    }
+}
+
+bool w8_supported(const CoreParams& p, int max_deg) {
+    if (getenv("FGC_NO_W8") && getenv("FGC_NO_W8")[0] == '1') return false;
+    const int nct = p.npad >> 4;
+    if (!(nct == 1 || nct == 2 || nct == 4 || nct == 8)) return false;
+    if (max_deg <= 0 || max_deg > KMAX) return false;
+    if (p.kc != 32) return false;
+    if ((p.c0 & 1) || (p.c1 & 1)) return false;
+    if (((uintptr_t)p.src0 & 7) || (p.src1 && ((uintptr_t)p.src1 & 7))) return false;
+    return true;
+}
+
+template <bool DATA>
+static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA>), dim3(cdiv(p.n, TILE)),
+               dim3(W8_THREADS), smem, p, fe, de);
+    FGC_CHECK_LAUNCH("conv_w8_kernel");
+    return FGC_OK;
+}
+
+int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, hipStream_t st) {
+    DataEpilogue de{};
+    return launch_w8<false>(p, ep, de, smem, st);
+}
+int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, hipStream_t st) {
+    FwdEpilogue fe{};
+    return launch_w8<true>(p, fe, ep, smem, st);
+}
+
+}  // namespace fgc
