@@ -150,9 +150,10 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 // blockIdx.x, +gridDim.x, ...; parameter-gradient partials stay in registers over the walk and are
 // written once per workgroup as slabs (reduced in fixed order by reduce_slabs_kernel).
 // ---------------------------------------------------------------------------------------------
-constexpr int MLP_BWD_CTW = 4;   // column tiles per wave per workgroup (hcw = 4 waves * 4 * 16 = 256 columns)
-constexpr int MLP_BWD_MT = 2;    // cin tiles of 16 (cin <= 32)
-
+// MLP_BWD_MT = cin tiles of 16, MLP_BWD_CTW = column tiles per wave per workgroup (hcw = 4 waves * CTW * 16 columns).
+// <2,4> serves the 32-wide head of the network; <4,2> and <8,1> the 64/128-wide multi-scale heads (model.py:894-899,
+// 915-920), trading column width for the wider dx / dW1 accumulators.
+template <int MLP_BWD_MT, int MLP_BWD_CTW>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int n, int cin, int kpad, int hidden, int cout,
     const float* __restrict__ Wp, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
     float* xt = reinterpret_cast<float*>(smem_raw);                // [MLP_T][xs]
     float* dyt = xt + MLP_T * xs;                                   // [MLP_T][4]
     float* dht = dyt + MLP_T * 4;                                   // [4 waves][MLP_T][24]  (stride 24 == 8 mod 16)
-    float* dxp = dht + 4 * MLP_T * 24;                              // [4 waves][MLP_T][kpad+1]
+    float* dxp = dht + 4 * MLP_T * 24;                              // [4 waves][MLP_T][kpad+1]  ([1][..] when MT > 2)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int kg = kpad >> 4;
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(Wp);
@@ -265,20 +266,42 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
         }
         // reduce dx over the 4 waves (fixed order) and write this hidden-range's slab
         const int dxs = kpad + 1;
-        float* dxw = dxp + wave * MLP_T * dxs;
+        if constexpr (MLP_BWD_MT <= 2) {
+            float* dxw = dxp + wave * MLP_T * dxs;
 #pragma unroll
-        for (int r = 0; r < MLP_RT; ++r)
+            for (int r = 0; r < MLP_RT; ++r)
 #pragma unroll
-            for (int m = 0; m < MLP_BWD_MT; ++m)
+                for (int m = 0; m < MLP_BWD_MT; ++m)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dxw[(r * 16 + lq * 4 + t) * dxs + m * 16 + lr] = dxacc[r][m][t];
-        __syncthreads();
-        for (int t = threadIdx.x; t < MLP_T * cin; t += MLP_THREADS) {
-            const int r = t / cin, c = t % cin;
-            if (row0 + r < n) {
-                const float v = (dxp[(0 * MLP_T + r) * dxs + c] + dxp[(1 * MLP_T + r) * dxs + c]) +
-                                (dxp[(2 * MLP_T + r) * dxs + c] + dxp[(3 * MLP_T + r) * dxs + c]);
-                dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = v;
+                    for (int t = 0; t < 4; ++t) dxw[(r * 16 + lq * 4 + t) * dxs + m * 16 + lr] = dxacc[r][m][t];
+            __syncthreads();
+            for (int t = threadIdx.x; t < MLP_T * cin; t += MLP_THREADS) {
+                const int r = t / cin, c = t % cin;
+                if (row0 + r < n) {
+                    const float v = (dxp[(0 * MLP_T + r) * dxs + c] + dxp[(1 * MLP_T + r) * dxs + c]) +
+                                    (dxp[(2 * MLP_T + r) * dxs + c] + dxp[(3 * MLP_T + r) * dxs + c]);
+                    dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = v;
+                }
+            }
+        } else {
+            // wide inputs: one shared tile, the waves add into it one after the other (wave 0, 1, 2, 3)
+            for (int w = 0; w < 4; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int r = 0; r < MLP_RT; ++r)
+#pragma unroll
+                        for (int m = 0; m < MLP_BWD_MT; ++m)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                float* p = dxp + (r * 16 + lq * 4 + t) * dxs + m * 16 + lr;
+                                *p = (w == 0) ? dxacc[r][m][t] : *p + dxacc[r][m][t];
+                            }
+                }
+                __syncthreads();
+            }
+            for (int t = threadIdx.x; t < MLP_T * cin; t += MLP_THREADS) {
+                const int r = t / cin, c = t % cin;
+                if (row0 + r < n) dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = dxp[r * dxs + c];
             }
         }
     }
@@ -327,6 +350,7 @@ __global__ void colsum_stage1_kernel(const float* __restrict__ a, int rows, int 
 using namespace fgc;
 
 static int mlp_kpad(int cin) { return (cin + 15) / 16 * 16; }
+static int mlp_bwd_ctw(int cin) { return cin <= 32 ? 4 : (cin <= 64 ? 2 : 1); }   // see mlp_bwd_kernel
 static int mlp_bwd_gx(int n) {
     const int ntiles = cdiv(n, MLP_T);
     return ntiles < 128 ? ntiles : 128;
@@ -343,7 +367,7 @@ extern "C" size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t c
 
 extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout) {
     (void)cout;
-    const size_t gx = mlp_bwd_gx(n), gy = hidden / 256;
+    const size_t gx = mlp_bwd_gx(n), gy = hidden / (64 * mlp_bwd_ctw(cin));
     size_t b = align_up((size_t)mlp_kpad(cin) * hidden * 4, 256);
     b += align_up(gy * (size_t)n * cin * 4, 256);          // dx slabs
     b += align_up(gx * (size_t)cin * hidden * 4, 256);     // dW1 slabs
@@ -380,8 +404,7 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                            float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes,
                            void* stream) {
     FGC_CHECK_ARG(x && dy && W1 && b1 && W2 && dx && dW1 && db1 && dW2 && db2, "fgc_mlp_bwd: null pointer");
-    FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 16 * MLP_BWD_MT, "fgc_mlp_bwd: cin=%d must be in [1,%d]", cin,
-                  16 * MLP_BWD_MT);
+    FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 128, "fgc_mlp_bwd: n=%d cin=%d (cin must be in [1,128])", n, cin);
     FGC_CHECK_ARG(hidden > 0 && hidden % 256 == 0, "fgc_mlp_bwd: hidden=%d must be a multiple of 256", hidden);
     FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_bwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout),
@@ -389,7 +412,8 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                   fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));
     hipStream_t st = (hipStream_t)stream;
     const int kpad = mlp_kpad(cin);
-    const int gx = mlp_bwd_gx(n), gy = hidden / 256;
+    const int ctw = mlp_bwd_ctw(cin);
+    const int gx = mlp_bwd_gx(n), gy = hidden / (64 * ctw);
     char* w = (char*)workspace;
     float* Wp = (float*)w;
     w += align_up((size_t)kpad * hidden * 4, 256);
@@ -407,10 +431,17 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
 
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
-    const size_t smem = (size_t)(MLP_T * (kpad + 8) + MLP_T * 4 + 4 * MLP_T * 24 + 4 * MLP_T * (kpad + 1)) * 4;
-    hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    FGC_LAUNCH("mlp_bwd_kernel", st, mlp_bwd_kernel, dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy, n, cin, kpad, hidden, cout, Wp,
-                       W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);
+    const size_t smem = (size_t)(MLP_T * (kpad + 8) + MLP_T * 4 + 4 * MLP_T * 24 + (ctw == 4 ? 4 : 1) * MLP_T * (kpad + 1)) * 4;
+#define FGC_MLP_BWD_LAUNCH(MT, CTW)                                                                                       \
+    do {                                                                                                                  \
+        hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        FGC_LAUNCH("mlp_bwd_kernel", st, (mlp_bwd_kernel<MT, CTW>), dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy, n, cin,  \
+                   kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);                     \
+    } while (0)
+    if (ctw == 4) FGC_MLP_BWD_LAUNCH(2, 4);
+    else if (ctw == 2) FGC_MLP_BWD_LAUNCH(4, 2);
+    else FGC_MLP_BWD_LAUNCH(8, 1);
+#undef FGC_MLP_BWD_LAUNCH
     FGC_CHECK_LAUNCH("fgc_mlp_bwd");
     // fixed-order reductions
     int rc = reduce_slabs("reduce:mlp_dx", dx_slab, gy, (size_t)n * cin, cin, cin, dx, rtmp, st);

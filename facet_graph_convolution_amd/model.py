@@ -280,8 +280,6 @@ def get_model_reg_multi_scale(x, adjs, keep_prob, coarsening_steps=2, multiScale
     dconv3, _ = custom_conv2d(h_conv3_act, adjs[2], 128, 9)
     dconv3_act = lrelu(dconv3, alpha)
     if multiScale:
-        if dconv3_act.requires_grad:
-            raise NotImplementedError("training the multi-scale heads needs the 128/64-wide MLP backward (not built)")
         y_conv2 = _head(dconv3_act, 1024, out_channels_reg, alpha)
     upsamp2 = custom_upsampling(dconv3_act, steps=coarsening_steps)
     upconv2, _ = custom_conv2d(upsamp2, adjs[1], 64, 9)

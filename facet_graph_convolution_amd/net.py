@@ -287,7 +287,9 @@ class FacetDenoiser:
     # ------------------------------------------------------------------------------------------
     # enqueue helpers (no allocation, no sync).  The schedules are GENERATORS: they yield an exchange request
     # wherever a facet-sharded run must talk to its peers; an unsharded run just drains them.
-    #   ("rows", level, tensor, width_rows_own, parent)   halo rows of `tensor` (parent: rows of the coarse parents)
+    #   ("rows", level, tensor, parent)                    halo rows of `tensor` (parent: rows of the coarse parents)
+    #   ("rows_begin", level, tensor, parent, key) ... ("wait", key)   the same, split so that the kernels enqueued
+    #                                                      in between run while the rows travel
     #   ("edges", level)                                   d-logits of incoming cross-shard edges
     #   ("sum", tensor)                                    all-reduce
     # ------------------------------------------------------------------------------------------
@@ -315,16 +317,24 @@ class FacetDenoiser:
             B["xr"].copy_(B["x"])
         vals = self.params.values
         halo_before = {"conv2": [("p1", 1, False)], "conv3": [("p2", 2, False)], "dconv3": [("h3", 2, False)],
-                       "upconv2": [("d3", 1, True)], "dconv2": [("u2", 1, False), ("h2", 1, False)],
-                       "upconv1": [("d2", 0, True)], "dconv1": [("u1", 0, False), ("h1", 0, False)]}
+                       "upconv2": [("d3", 1, True)], "dconv2": [("u2", 1, False)],
+                       "upconv1": [("d2", 0, True)], "dconv1": [("u1", 0, False)]}
+        # the skip connections are consumed six / two layers later: their halos travel under the layers in between
+        early = {"conv1": ("h1", 0, "dconv1"), "conv2": ("h2", 1, "dconv2")}
+        wait_before = {v[2]: v[0] for v in early.values()}
         for lay in self.layers:
             if self.sharded:
                 for name, level, parent in halo_before.get(lay.name, []):
                     yield ("rows", level, B[name], parent)
+                if lay.name in wait_before:
+                    yield ("wait", wait_before[lay.name])
             self._tag("fwd:" + lay.name)
             d = M["descs"][lay.name]
             _lib.check(L.fgc_conv_fwd(C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]),
                                       _p(B[lay.pool]) if lay.pool else None, _p(ws), ws.numel(), st), lay.name)
+            if self.sharded and lay.name in early:
+                name, level, _ = early[lay.name]
+                yield ("rows_begin", level, B[name], False, name)
             if self.multi_scale and lay.name in ("dconv3", "dconv2"):
                 head, out = ("head2", "y2") if lay.name == "dconv3" else ("head1", "y1")
                 W1, b1, W2, b2 = vals[self.slot[head]:self.slot[head] + 4]
@@ -410,9 +420,12 @@ class FacetDenoiser:
             nloc = ns[lay.level] + M["nh"][lay.level]
             io.stages = 1       # s = dy * lrelu'(y) / deg on owned rows, then the halo rows of s from their owners
             _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/ds")
-            yield ("rows", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False)
+            # the halo rows of s are first read by the data kernel (stage 4): they travel under the d-logits kernel,
+            # which only reads the owned rows
+            yield ("rows_begin", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False, "ds")
             io.stages = 2       # d-logits of owned edges, then those of incoming cross-shard edges
             _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/logits")
+            yield ("wait", "ds")
             yield ("edges", lay.level)
             io.stages = 4
             _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/data")
@@ -427,7 +440,7 @@ class FacetDenoiser:
         if kind == "sum":
             return ("sum", req[1])
         g = M["graphs"][req[1]]
-        if kind == "rows":
+        if kind in ("rows", "rows_begin"):
             t, parent = req[2], req[3]
             tail = t.shape[0] - g.n_halo
             idx = g.send_parent_rows if parent else g.send_rows
@@ -443,8 +456,15 @@ class FacetDenoiser:
 
     def _drain(self, gen):
         """Run a schedule on this rank: no-op exchanges when unsharded, collectives through self.comm otherwise."""
+        pending = {}
         for req in gen:
+            if req[0] == "wait":
+                self.comm.finish(pending.pop(req[1]))
+                continue
             m = self._materialise(req)
+            if req[0] == "rows_begin":
+                pending[req[4]] = self.comm.all_to_all_rows_begin(m[1], m[2], m[3], m[4])
+                continue
             if m[0] == "sum":
                 self.comm.all_reduce_sum(m[1])
             else:

@@ -200,6 +200,22 @@ class DistComm:
         else:
             self.dist.all_to_all_single(recv, send, list(recv_counts), list(send_counts), group=self.group)
 
+    def all_to_all_rows_begin(self, send, send_counts, recv, recv_counts):
+        """Start the exchange and return a handle for `finish`: on RCCL the collective runs on the communicator's
+        own stream, so kernels enqueued between begin and finish overlap it (the skip-connection halos travel under
+        the encoder, the ds halos under the d-logits kernel).  `recv` must not be read, nor `send` reused, before
+        `finish`.  The host-staged gloo path exchanges synchronously here."""
+        if self.host_staged:
+            self.all_to_all_rows(send, send_counts, recv, recv_counts)
+            return None
+        work = self.dist.all_to_all_single(recv, send, list(recv_counts), list(send_counts), group=self.group,
+                                           async_op=True)
+        return (work, send, recv)       # keeps the buffers alive until the wait
+
+    def finish(self, handle):
+        if handle is not None:
+            handle[0].wait()            # the current stream waits for the collective; the host does not block
+
     def _gloo_a2a(self, r, s, recv_counts, send_counts):
         # gloo has no all_to_all_single on every build: P2P rounds instead
         so, ro = np.cumsum([0] + list(send_counts)), np.cumsum([0] + list(recv_counts))
@@ -265,6 +281,9 @@ def sim_run(nets, make_gen):
         if all(r is None for r in reqs):
             return
         assert all(r is not None for r in reqs), "shards disagree on the exchange schedule"
+        assert len({r[0] for r in reqs}) == 1, "shards disagree on the exchange schedule"
+        if reqs[0][0] == "wait":       # the exchange already happened at its "rows_begin"
+            continue
         mats = [n._materialise(r) for n, r in zip(nets, reqs)]
         if mats[0][0] == "sum":
             tot = mats[0][1].clone()

@@ -144,3 +144,24 @@ def test_facet_sharded_step_matches_single_gpu(golden_dir, tag, world):
             a, b = g.cpu().numpy(), gr.cpu().numpy()
             scale = max(np.abs(b).max(), 1e-3)
             assert np.abs(a - b).max() / scale < 1e-3, "grad %d" % i
+
+
+def _run_ranks(nproc, backend, port):
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGC_TOOL_BACKEND=backend, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "tools", "shard_gloo_2proc.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_two_process_sharded_step_over_gloo():
+    """One process per shard (two of them on this one GPU), exchanges through torch.distributed: the same DistComm a
+    multi-GPU run uses, host-staged because RCCL wants one device per rank."""
+    _run_ranks(2, "gloo", 29631)
+
+
+def test_rccl_code_path_world_of_one():
+    """backend 'nccl' (= RCCL): the async all_to_all_single / all_reduce calls of the sharded schedule, world size 1."""
+    _run_ranks(1, "nccl", 29632)

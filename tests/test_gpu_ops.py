@@ -25,12 +25,12 @@ def test_mlp_forward(n, cin):
     assert abs(part.sum().item() - ref.abs().sum().item()) < 1e-4 * ref.abs().sum().item()
 
 
-@pytest.mark.parametrize("n", [1000, 77, 5000])
-def test_mlp_backward(n):
+@pytest.mark.parametrize("n,cin", [(1000, 32), (77, 32), (5000, 32), (6, 32), (900, 64), (333, 128), (70, 48)])
+def test_mlp_backward(n, cin):
+    """cin = 32 is the network head; 64 / 128 are the multi-scale heads (model.py:894-899, 915-920)."""
     from facet_graph_convolution_amd import ops
     from oracle import model_ref as R
     rs = np.random.RandomState(n + 1)
-    cin = 32
     x = _t(rs.normal(size=(n, cin))).double().requires_grad_(True)
     ps = [_t(rs.normal(0, 0.05, (cin, 1024))), _t(rs.normal(0, 0.01, 1024)), _t(rs.normal(0, 0.05, (1024, 3))),
           _t(rs.normal(0, 0.01, 3))]

@@ -1,5 +1,7 @@
 """Developer check: 2 processes on ONE GPU, gloo (host-staged) exchange, real kernels; compares the sharded
-loss with the single-process run.  python -m torch.distributed.run --nproc-per-node 2 tools/shard_gloo_2proc.py"""
+loss with the single-process run.  python -m torch.distributed.run --nproc-per-node 2 tools/shard_gloo_2proc.py
+FGC_TOOL_BACKEND=nccl with --nproc-per-node 1 drives the RCCL code path (async all_to_all_single, all_reduce) on the
+one GPU of a test box: a world of one, so every exchange is empty, but the calls are the ones a multi-GPU run makes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
@@ -7,7 +9,12 @@ from bench import build_mesh
 from facet_graph_convolution_amd.net import FacetDenoiser
 from facet_graph_convolution_amd.shard import ShardPlan, DistComm, graphs_to_host_csr
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-dist.init_process_group("gloo")
+backend = os.environ.get("FGC_TOOL_BACKEND", "gloo")
+if backend == "nccl":
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 ds, F = build_mesh(60, 40, 0)
 plan = ShardPlan(graphs_to_host_csr(ds.adj_list[0]), rank, world)
