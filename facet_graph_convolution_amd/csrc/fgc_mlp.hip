@@ -351,6 +351,8 @@ using namespace fgc;
 
 static int mlp_kpad(int cin) { return (cin + 15) / 16 * 16; }
 static int mlp_bwd_ctw(int cin) { return cin <= 32 ? 4 : (cin <= 64 ? 2 : 1); }   // see mlp_bwd_kernel
+// the backward kernel's k extent is its template width (16 * MT = 128 / CTW): narrower inputs are zero padded up to it
+static int mlp_bwd_kpad(int cin) { return 128 / mlp_bwd_ctw(cin); }
 static int mlp_bwd_gx(int n) {
     const int ntiles = cdiv(n, MLP_T);
     return ntiles < 128 ? ntiles : 128;
@@ -368,7 +370,7 @@ extern "C" size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t c
 extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout) {
     (void)cout;
     const size_t gx = mlp_bwd_gx(n), gy = hidden / (64 * mlp_bwd_ctw(cin));
-    size_t b = align_up((size_t)mlp_kpad(cin) * hidden * 4, 256);
+    size_t b = align_up((size_t)mlp_bwd_kpad(cin) * hidden * 4, 256);
     b += align_up(gy * (size_t)n * cin * 4, 256);          // dx slabs
     b += align_up(gx * (size_t)cin * hidden * 4, 256);     // dW1 slabs
     b += align_up(gx * (size_t)hidden * 4, 256);           // db1 slabs
@@ -411,7 +413,7 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                   "fgc_mlp_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                   fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));
     hipStream_t st = (hipStream_t)stream;
-    const int kpad = mlp_kpad(cin);
+    const int kpad = mlp_bwd_kpad(cin);
     const int ctw = mlp_bwd_ctw(cin);
     const int gx = mlp_bwd_gx(n), gy = hidden / (64 * ctw);
     char* w = (char*)workspace;
