@@ -28,6 +28,8 @@ class ConvDesc(C.Structure):
         ("c0", C.c_int32), ("c1", C.c_int32), ("shift", C.c_int32), ("cout", C.c_int32),
         ("W0", C.c_void_p), ("b", C.c_void_p), ("u", C.c_void_p), ("c", C.c_void_p), ("v", C.c_void_p),
         ("bias_mask", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("src_rows", C.c_int32), ("max_deg", C.c_int32),
+        ("tile_list", C.c_void_p), ("n_tiles", C.c_int32), ("proj_row0", C.c_int32), ("proj_rows", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -39,12 +41,17 @@ class ConvBwdIO(C.Structure):
         ("dx0", C.c_void_p), ("dx1", C.c_void_p),
         ("accumulate0", C.c_int32), ("accumulate1", C.c_int32),
         ("dW0", C.c_void_p), ("db", C.c_void_p), ("du", C.c_void_p), ("dc", C.c_void_p), ("dv", C.c_void_p),
+        ("data_tile_list", C.c_void_p), ("n_data_tiles", C.c_int32), ("flags", C.c_int32),
     ]
+
+
+CONV_PACKED = 1
 
 
 _SIGS = {
     "fgc_last_error": (C.c_char_p, []),
     "fgc_version": (C.c_int, []),
+    "fgc_struct_size": (C.c_size_t, [C.c_int32]),
     "fgc_profile_enable": (C.c_int, [C.c_int]),
     "fgc_profile_tag": (C.c_int, [C.c_char_p]),
     "fgc_profile_collect": (C.c_int, [C.c_char_p, C.c_int32]),

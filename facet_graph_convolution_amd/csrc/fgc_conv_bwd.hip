@@ -471,7 +471,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
     float* dagt = s.extra;  // [TILE][24]: da | dg of the tile's nodes
-    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    const int tile0 = block_tile0(p);
     const int tid = threadIdx.x;
     const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 
@@ -776,7 +776,7 @@ static int launch_logits(const CoreParams& p, const LogitParams& lp, bool vec4, 
 
 template <int LPN>
 static int launch_data(const CoreParams& p, const DataEpilogue& ep, bool vec4, size_t smem, hipStream_t st) {
-    const int grid = cdiv(p.n, TILE);
+    const int grid = core_grid(p);
     if (vec4) {
         hipFuncSetAttribute((const void*)conv_bwd_data_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
@@ -812,7 +812,9 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const int opad = (cout + 15) / 16 * 16;
     const int ostride = opad + 8;
 
-    const int stages = io->stages ? io->stages : 7;
+    const int stages = io->stages ? io->stages : 15;
+    FGC_CHECK_ARG(io->data_tile_list == nullptr || (io->n_data_tiles >= 0 && io->n_data_tiles <= cdiv(d->n, TILE)),
+                  "fgc_conv_bwd: n_data_tiles=%d outside [0, %d]", io->n_data_tiles, cdiv(d->n, TILE));
     // s = dy*lrelu'(y)/deg, db partials
     if (stages & 1) {
         int cp2 = 1;
@@ -824,7 +826,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         if (rc) return rc;
     }
     // operand packing
-    if (stages & 6) {
+    if ((stages & 6) && !(io->flags & FGC_CONV_PACKED)) {
         const size_t tot = (size_t)g1.passes * opad * g1.kpass;
         FGC_LAUNCH("pack_logit_weight_kernel", st, pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, d->W0, w.Wq, cin, cout,
                            opad, g1.kc, g1.kpass, g1.passes);
@@ -870,10 +872,12 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         if (rc) return rc;
     }
     // K2
-    if (stages & 4) {
+    if ((stages & 4) && !(io->data_tile_list && io->n_data_tiles == 0)) {
         CoreParams p;
         fill_core_params(p, g2, d->n, io->trowptr, io->tcol, io->tedge, io->ds, nullptr, cout, 0, 0, cin, io->ag,
                          d->shift, 12, 0, w.Wpt);
+        p.tile_list = io->data_tile_list;
+        p.n_tiles = io->n_data_tiles;
         DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout, d->u, d->v, cin, d->c0, d->c1, d->shift,
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
@@ -882,7 +886,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             rc = launch_data_w8(p, ep, smem, st);
             if (rc) return rc;
         } else
-        if (g2.lpn == 8 && vec4 && io->max_in_deg > 0 && io->max_in_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1')) {
+        if (g2.lpn == 8 && vec4 && !p.tile_list && io->max_in_deg > 0 && io->max_in_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1')) {
             rc = launch_data_pc(p, ep, g2, st);
             if (rc) return rc;
         } else
@@ -894,7 +898,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         if (rc) return rc;
     }
     // K3: dW0 = r^T x ; [du; dv] = dag^T x
-    if (stages & 4) {
+    if (stages & 8) {
         const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0) && ((uintptr_t)io->dag % 16 == 0);
         const int P = FGC_M * cout;
         int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;

@@ -46,6 +46,8 @@ struct CoreParams {
     int ag_shift;            // row = node >> ag_shift
     int ctr_off, nbr_off;    // 0 (a) / 12 (g): which half the centre / the neighbour contributes
     const float* Wp;         // packed B operand [passes*kpass/4][npad] float4
+    const int* tile_list;    // tiles to compute (NULL = all cdiv(n, TILE) of them); the grid has one block per entry
+    int n_tiles;
 };
 
 // ---- workgroup -> tile map ----------------------------------------------------------------
@@ -58,6 +60,13 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
     const int xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// first node of this workgroup's tile
+__device__ __forceinline__ int block_tile0(const CoreParams& p) {
+    const int t = xcd_tile(blockIdx.x, gridDim.x);
+    return (p.tile_list ? p.tile_list[t] : t) * TILE;
+}
+static inline int core_grid(const CoreParams& p) { return p.tile_list ? p.n_tiles : cdiv(p.n, TILE); }
 
 // ---- LDS carve ---------------------------------------------------------------------------
 struct Smem {

@@ -103,7 +103,7 @@ template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(CoreParams p, FwdEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
-    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    const int tile0 = block_tile0(p);
     const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 
     const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
@@ -227,6 +227,8 @@ void fill_core_params(CoreParams& p, const ConvGeom& g, int n, const int* rowptr
     p.ctr_off = ctr_off;
     p.nbr_off = nbr_off;
     p.Wp = Wp;
+    p.tile_list = nullptr;
+    p.n_tiles = 0;
 }
 
 size_t conv_smem_bytes(const ConvGeom& g, size_t extra) {
@@ -244,7 +246,7 @@ size_t conv_smem_bytes(const ConvGeom& g, size_t extra) {
 
 template <int LPN>
 static int launch_fwd(const CoreParams& p, const FwdEpilogue& ep, bool vec4, size_t smem, hipStream_t st) {
-    const int grid = cdiv(p.n, TILE);
+    const int grid = core_grid(p);
     if (vec4) {
         hipFuncSetAttribute((const void*)conv_fwd_kernel<LPN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
@@ -271,31 +273,45 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FGC_CHECK_ARG((uintptr_t)workspace % 16 == 0 && (uintptr_t)ag % 16 == 0, "fgc_conv_fwd: workspace/ag need 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     float* Wp = (float*)workspace;
-
-    const size_t tot = packed_floats(g);
-    FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, d->W0, Wp, cin, d->cout,
-                       cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
-    FGC_CHECK_LAUNCH("fgc_conv_fwd/pack");
     const int rows = d->src_rows > 0 ? d->src_rows : (d->n >> d->shift);
-    {
-        const int pg = std::min(cdiv(cdiv(rows, 16), 4), 1024);
-        if (conv_vec4_ok(d))
-            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true>), dim3(pg), dim3(256), 0, d->x0, d->x1, d->c0,
-                       d->c1, rows, d->u, d->c, d->v, ag);
-        else
-            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<false>), dim3(pg), dim3(256), 0, d->x0, d->x1, d->c0,
-                       d->c1, rows, d->u, d->c, d->v, ag);
+    const int prow0 = d->proj_rows ? d->proj_row0 : 0;
+    const int prows = d->proj_rows ? (d->proj_rows < 0 ? 0 : d->proj_rows) : rows;
+    FGC_CHECK_ARG(prow0 >= 0 && prow0 + prows <= rows && (d->proj_rows != 0 || d->proj_row0 == 0),
+                  "fgc_conv_fwd: logits rows [%d, %d) outside the %d source rows", prow0, prow0 + prows, rows);
+    FGC_CHECK_ARG(d->tile_list == nullptr || (d->n_tiles >= 0 && d->n_tiles <= cdiv(d->n, TILE)),
+                  "fgc_conv_fwd: n_tiles=%d outside [0, %d]", d->n_tiles, cdiv(d->n, TILE));
+
+    if (!(d->flags & FGC_CONV_PACKED)) {
+        const size_t tot = packed_floats(g);
+        FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, d->W0, Wp, cin,
+                   d->cout, cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
+        FGC_CHECK_LAUNCH("fgc_conv_fwd/pack");
     }
-    FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
+    if (prows > 0) {
+        const int pg = std::min(cdiv(cdiv(prows, 16), 4), 1024);
+        const float* px0 = d->x0 + (size_t)prow0 * d->c0;
+        const float* px1 = d->x1 ? d->x1 + (size_t)prow0 * d->c1 : nullptr;
+        float* pag = ag + (size_t)prow0 * FGC_AG_LD;
+        if (conv_vec4_ok(d))
+            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
+                       prows, d->u, d->c, d->v, pag);
+        else
+            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<false>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
+                       prows, d->u, d->c, d->v, pag);
+        FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
+    }
+    if (d->tile_list && d->n_tiles == 0) return FGC_OK;
 
     CoreParams p;
     fill_core_params(p, g, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, d->cout, ag,
                      d->shift, 0, 12, Wp);
+    p.tile_list = d->tile_list;
+    p.n_tiles = d->n_tiles;
     FwdEpilogue ep{d->b, d->bias_mask, d->act, d->alpha, y, y_pool};
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
     if (g.lpn == 8 && w8_supported(p, d->max_deg)) return launch_fwd_w8(p, ep, smem, st);
-    if (g.lpn == 8 && vec4 && d->max_deg > 0 && d->max_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1'))
+    if (g.lpn == 8 && vec4 && !p.tile_list && d->max_deg > 0 && d->max_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1'))
         return launch_fwd_pc(p, ep, g, st);
     switch (g.lpn) {
         case 2: return launch_fwd<2>(p, ep, vec4, smem, st);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, Fw
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
     float* dagt = s.extra;  // DATA: [TILE][24]
-    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    const int tile0 = block_tile0(p);
     const int tid = threadIdx.x;
     const int node = tid >> 4, kl = tid & 15;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -333,7 +333,7 @@ static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilo
         hipFuncSetAttribute((const void*)conv_w8_kernel<DATA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA>), dim3(cdiv(p.n, TILE)),
+    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA>), dim3(core_grid(p)),
                dim3(W8_THREADS), smem, p, fe, de);
     FGC_CHECK_LAUNCH("conv_w8_kernel");
     return FGC_OK;

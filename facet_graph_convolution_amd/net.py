@@ -19,6 +19,7 @@ Design (MI355X-first, nothing traced or compiled at run time):
   * the whole forward+backward enqueue is capturable into a hipGraph (``capture=True``).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -128,6 +129,9 @@ class FacetDenoiser:
         self._graph_fb = None
         self.profile = False   # when True every enqueue is labelled for fgc_profile_collect
         self.comm = None       # exchange back end of a facet-sharded run (shard.DistComm)
+        # facet-sharded runs: compute the interior tiles of a layer while its halo rows travel (FGC_NO_OVERLAP=1: the
+        # whole layer after a blocking exchange, for A/B timing)
+        self.overlap = os.environ.get("FGC_NO_OVERLAP", "0") != "1"
         # parameter slots
         k = 0
         self.slot = {}
@@ -289,7 +293,7 @@ class FacetDenoiser:
     # wherever a facet-sharded run must talk to its peers; an unsharded run just drains them.
     #   ("rows", level, tensor, parent)                    halo rows of `tensor` (parent: rows of the coarse parents)
     #   ("rows_begin", level, tensor, parent, key) ... ("wait", key)   the same, split so that the kernels enqueued
-    #                                                      in between run while the rows travel
+    #   ("edges_begin", level, key)                ... ("wait", key)   in between run while the rows travel
     #   ("edges", level)                                   d-logits of incoming cross-shard edges
     #   ("sum", tensor)                                    all-reduce
     # ------------------------------------------------------------------------------------------
@@ -322,16 +326,38 @@ class FacetDenoiser:
         # the skip connections are consumed six / two layers later: their halos travel under the layers in between
         early = {"conv1": ("h1", 0, "dconv1"), "conv2": ("h2", 1, "dconv2")}
         wait_before = {v[2]: v[0] for v in early.values()}
+        split = self.sharded and self.overlap
         for lay in self.layers:
-            if self.sharded:
-                for name, level, parent in halo_before.get(lay.name, []):
-                    yield ("rows", level, B[name], parent)
+            d = M["descs"][lay.name]
+            args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(ws),
+                    ws.numel(), st)
+            reqs = halo_before.get(lay.name, []) if self.sharded else []
+            if split and reqs:
+                # interior tiles (they gather owned rows only) run while the halo rows travel; then the rest
+                for name, level, parent in reqs:
+                    yield ("rows_begin", level, B[name], parent, name)
+                g = M["graphs"][lay.level]
+                own_src = d.n >> d.shift
+                self._tag("fwd:" + lay.name)
+                d.tile_list, d.n_tiles = g.tiles["tiles_int"][0].data_ptr(), g.tiles["tiles_int"][1]
+                d.proj_row0, d.proj_rows, d.flags = 0, own_src, 0
+                _lib.check(L.fgc_conv_fwd(*args), lay.name)
+                for name, level, parent in reqs:
+                    yield ("wait", name)
                 if lay.name in wait_before:
                     yield ("wait", wait_before[lay.name])
-            self._tag("fwd:" + lay.name)
-            d = M["descs"][lay.name]
-            _lib.check(L.fgc_conv_fwd(C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]),
-                                      _p(B[lay.pool]) if lay.pool else None, _p(ws), ws.numel(), st), lay.name)
+                d.tile_list, d.n_tiles = g.tiles["tiles_bnd"][0].data_ptr(), g.tiles["tiles_bnd"][1]
+                d.proj_row0, d.proj_rows = own_src, (d.src_rows - own_src) or -1
+                d.flags = _lib.CONV_PACKED
+                _lib.check(L.fgc_conv_fwd(*args), lay.name)
+                d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, 0
+            else:
+                for name, level, parent in reqs:
+                    yield ("rows", level, B[name], parent)
+                if self.sharded and lay.name in wait_before:
+                    yield ("wait", wait_before[lay.name])
+                self._tag("fwd:" + lay.name)
+                _lib.check(L.fgc_conv_fwd(*args), lay.name)
             if self.sharded and lay.name in early:
                 name, level, _ = early[lay.name]
                 yield ("rows_begin", level, B[name], False, name)
@@ -418,17 +444,35 @@ class FacetDenoiser:
             lay = next(l for l in self.layers if l.name == name)
             cout = d.cout
             nloc = ns[lay.level] + M["nh"][lay.level]
-            io.stages = 1       # s = dy * lrelu'(y) / deg on owned rows, then the halo rows of s from their owners
-            _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/ds")
-            # the halo rows of s are first read by the data kernel (stage 4): they travel under the d-logits kernel,
-            # which only reads the owned rows
+            g = M["graphs"][lay.level]
+            call = lambda what: _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st),
+                                           name + " bwd/" + what)
+            io.stages, io.flags = 1, 0   # s = dy * lrelu'(y) / deg on owned rows
+            call("ds")
+            # the halo rows of s (from their owners) are first read by the data kernel: they travel under the
+            # d-logits kernel, which only reads the owned rows
             yield ("rows_begin", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False, "ds")
-            io.stages = 2       # d-logits of owned edges, then those of incoming cross-shard edges
-            _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/logits")
-            yield ("wait", "ds")
-            yield ("edges", lay.level)
-            io.stages = 4
-            _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd/data")
+            io.stages = 2               # d-logits of owned edges (packs the operands of stages 2 and 4)
+            call("logits")
+            if self.overlap:
+                # d-logits of incoming cross-shard edges travel under the data kernel of the interior tiles
+                # (all in-edges from owned rows); boundary tiles and the weight gradients follow
+                yield ("edges_begin", lay.level, "dl")
+                io.stages, io.flags = 4, _lib.CONV_PACKED
+                io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_int"][0].data_ptr(), g.tiles["ttiles_int"][1]
+                call("data/interior")
+                yield ("wait", "ds")
+                yield ("wait", "dl")
+                io.stages = 4 | 8
+                io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_bnd"][0].data_ptr(), g.tiles["ttiles_bnd"][1]
+                call("data/boundary")
+                io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
+            else:
+                yield ("wait", "ds")
+                yield ("edges", lay.level)
+                io.stages, io.flags = 4 | 8, _lib.CONV_PACKED
+                call("data")
+                io.flags = 0
         if self.sharded:
             yield ("sum", self.params.grad)     # every rank summed its own facets: one flat all-reduce
 
@@ -447,7 +491,7 @@ class FacetDenoiser:
             nsend = sum(g.send_counts)
             send = ops.gather_rows(t, idx[:nsend]) if nsend else t[:0]
             return ("a2a", send, g.send_counts, t[tail:], g.recv_counts)
-        if kind == "edges":
+        if kind in ("edges", "edges_begin"):
             dl = M["B"]["dl"][:(g.nnz + g.n_cross_in) * DL_LD].view(-1, DL_LD)
             nsend = sum(g.cross_send_counts)
             send = ops.gather_rows(dl, g.send_edges[:nsend]) if nsend else dl[:0]
@@ -462,8 +506,8 @@ class FacetDenoiser:
                 self.comm.finish(pending.pop(req[1]))
                 continue
             m = self._materialise(req)
-            if req[0] == "rows_begin":
-                pending[req[4]] = self.comm.all_to_all_rows_begin(m[1], m[2], m[3], m[4])
+            if req[0].endswith("_begin"):
+                pending[req[-1]] = self.comm.all_to_all_rows_begin(m[1], m[2], m[3], m[4])
                 continue
             if m[0] == "sum":
                 self.comm.all_reduce_sum(m[1])

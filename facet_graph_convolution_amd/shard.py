@@ -33,6 +33,18 @@ class LevelPlan:
     pass
 
 
+TILE_ROWS = 32   # csrc/fgc_conv_core.h TILE
+
+
+def _split_tiles(rowptr, edge_is_remote, n_own):
+    """(interior, boundary) tile indices of a local CSR: a tile is boundary if any edge of its rows is remote."""
+    ntiles = (n_own + TILE_ROWS - 1) // TILE_ROWS
+    row_of_edge = np.repeat(np.arange(n_own, dtype=np.int64), np.diff(rowptr))
+    bnd = np.zeros(ntiles, dtype=bool)
+    bnd[row_of_edge[np.asarray(edge_is_remote, dtype=bool)] // TILE_ROWS] = True
+    return np.nonzero(~bnd)[0].astype(np.int32), np.nonzero(bnd)[0].astype(np.int32)
+
+
 def build_level_plan(rowptr, col, lo_hi, rank):
     """Plan of one graph level for `rank`.  rowptr/col: GLOBAL CSR (host numpy), lo_hi: list of (lo, hi) per rank."""
     world = len(lo_hi)
@@ -79,6 +91,9 @@ def build_level_plan(rowptr, col, lo_hi, rank):
     up[is_h] = 4 * (P.n_own // 4 + (loc[is_h] - P.n_own))
     P.col_up = up.astype(np.int32)
     P.max_deg = int(np.diff(P.rowptr).max()) if P.n_own else 0
+    # 32-row tiles (the conv kernels' workgroup granule) that gather owned rows only / that touch the halo: the first
+    # kind runs while the halo rows are still travelling
+    P.tiles_int, P.tiles_bnd = _split_tiles(P.rowptr, loc >= P.n_own, P.n_own)
 
     # rows of mine that peer q needs, in q's halo order (ascending global id)
     P.send_rows = []
@@ -117,6 +132,7 @@ def build_level_plan(rowptr, col, lo_hi, rank):
     P.tcol = tcol_all[tkey].astype(np.int32)
     P.tedge = tedge_all[tkey].astype(np.int32)
     P.max_in_deg = int(np.diff(P.trowptr).max()) if P.n_own else 0
+    P.ttiles_int, P.ttiles_bnd = _split_tiles(P.trowptr, P.tcol >= P.n_own, P.n_own)
     # my outgoing cross edges to peer q, in q's storage order (target, source, eid)
     P.send_edges = []
     o_src, o_dst, o_eid = src[e0:e1], out_dst, eid[e0:e1]
@@ -167,6 +183,8 @@ class LocalGraph:
         self.col = torch.from_numpy(pad(P.col).copy()).to(dev)
         self.col_up = torch.from_numpy(pad(P.col_up).copy()).to(dev)
         self._t = tuple(torch.from_numpy(pad(a).copy()).to(dev) for a in (P.trowptr, P.tcol, P.tedge))
+        self.tiles = {k: (torch.from_numpy(pad(getattr(P, k)).copy()).to(dev), len(getattr(P, k)))
+                      for k in ("tiles_int", "tiles_bnd", "ttiles_int", "ttiles_bnd")}
         self.send_rows = torch.from_numpy(pad(np.concatenate(P.send_rows)).astype(np.int32)).to(dev)
         self.send_parent_rows = torch.from_numpy(pad(np.concatenate(P.send_rows) // 4).astype(np.int32)).to(dev)
         self.send_counts, self.recv_counts = list(P.send_counts), list(P.recv_counts)
@@ -282,7 +300,7 @@ def sim_run(nets, make_gen):
             return
         assert all(r is not None for r in reqs), "shards disagree on the exchange schedule"
         assert len({r[0] for r in reqs}) == 1, "shards disagree on the exchange schedule"
-        if reqs[0][0] == "wait":       # the exchange already happened at its "rows_begin"
+        if reqs[0][0] == "wait":       # the exchange already happened at its "..._begin"
             continue
         mats = [n._materialise(r) for n, r in zip(nets, reqs)]
         if mats[0][0] == "sum":

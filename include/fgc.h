@@ -42,6 +42,9 @@ extern "C" {
 
 const char* fgc_last_error(void);
 int fgc_version(void);
+/* sizeof the descriptor structs as this library was compiled (which = 0: fgc_conv_desc, 1: fgc_conv_bwd_io; else 0):
+ * lets a foreign-language binding check its mirror of the layouts before the first call */
+size_t fgc_struct_size(int32_t which);
 
 /* Optional per-kernel timing (hipEvents around every launch of the library; off by default, not
  * capturable into a hipGraph while on).  fgc_profile_collect synchronises and writes one line
@@ -136,7 +139,20 @@ typedef struct fgc_conv_desc {
                                source tensors carry halo rows behind the owned ones (facet sharding) */
     int32_t max_deg;        /* max_i deg(i) if the caller knows it, else 0.  <= 24 (every reference K-list) enables
                                the producer/consumer kernels; 0 or larger falls back to the edge-chunking path */
+    /* Partial forward calls (all zero = the whole layer in one call).  A facet-sharded caller computes the tiles
+     * that gather owned rows only while the halo rows are still travelling, then the rest:
+     *   call 1: tile_list = interior tiles, proj_rows = owned source rows
+     *   call 2: tile_list = boundary tiles, proj_row0 = owned source rows, proj_rows = halo rows, FGC_CONV_PACKED
+     * fgc_conv_bwd ignores these four fields (its split is in fgc_conv_bwd_io). */
+    const int32_t* tile_list; /* device, [n_tiles]: indices of the 32-row output tiles to compute; NULL = all */
+    int32_t n_tiles;          /* may be 0 with a non-NULL list: no conv launch, logits only */
+    int32_t proj_row0;        /* assignment logits are computed for source rows [proj_row0, proj_row0 + proj_rows) */
+    int32_t proj_rows;        /* 0 = all src_rows (proj_row0 must be 0), < 0 = none */
+    int32_t flags;            /* FGC_CONV_PACKED */
 } fgc_conv_desc;
+
+/* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
+#define FGC_CONV_PACKED 1
 
 /* bytes of scratch the conv entry points need for this descriptor (packed weights) */
 size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d);
@@ -160,9 +176,10 @@ typedef struct fgc_conv_bwd_io {
     const int32_t* tedge;   /* [nnz] */
     int32_t max_in_deg;     /* max in-degree of the transposed graph if known, else 0 (see max_deg) */
     int32_t stages;         /* 0 = whole backward.  Otherwise a bit mask, so that a facet-sharded caller can exchange
-                               halo rows between the pieces: 1 = ds/db, 2 = logits (dl, da, dc), 4 = data + weight
-                               gradients (r, dg, dx, dW0, du, dv).  ds then has rows for halo sources behind the n
-                               owned ones, and dl rows for incoming cross-shard edges behind the nnz owned ones. */
+                               halo rows between the pieces: 1 = ds/db, 2 = logits (dl, da, dc), 4 = data kernel
+                               (r, dg, dx) over data_tile_list, 8 = weight gradients (dW0, du, dv; needs every r and
+                               dg row).  ds then has rows for halo sources behind the n owned ones, and dl rows for
+                               incoming cross-shard edges behind the nnz owned ones. */
     const float* ag;        /* saved by forward */
     const float* y;         /* forward output (post activation) */
     const float* dy;        /* [n, cout] */
@@ -178,6 +195,10 @@ typedef struct fgc_conv_bwd_io {
     float* du;
     float* dc;
     float* dv;
+    const int32_t* data_tile_list; /* device, [n_data_tiles]: 32-row tiles stage 4 computes; NULL = all.  Tiles whose
+                                      in-edges all come from owned rows need neither halo rows of ds nor remote dl */
+    int32_t n_data_tiles;
+    int32_t flags;                 /* FGC_CONV_PACKED: an earlier stage call already packed the operands */
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);

@@ -26,6 +26,9 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(L, n), "libfgc.so does not export %s" % n
     assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
     assert _lib.lib().fgc_version() >= 100
+    # the ctypes mirrors of the descriptor structs have the layout the library was compiled with
+    assert _lib.lib().fgc_struct_size(0) == C.sizeof(_lib.ConvDesc)
+    assert _lib.lib().fgc_struct_size(1) == C.sizeof(_lib.ConvBwdIO)
 
 
 def test_error_reporting_across_the_boundary():

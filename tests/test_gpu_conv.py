@@ -145,3 +145,69 @@ def test_conv_backward_fused_addressing_matches_oracle(mode):
     for a, b, name in zip(grads, gp_ref, ["dW0", "db", "du", "dc", "dv"]):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=5e-6 * max(1.0, b.abs().max().item()),
                                    err_msg=name)
+
+
+def test_partial_calls_compose_to_the_whole_layer(golden_dir):
+    """fgc_conv_desc.tile_list / proj_rows / FGC_CONV_PACKED and fgc_conv_bwd_io.data_tile_list / stages: a layer
+    computed as two partial calls (what a facet-sharded run does around its halo exchange) is bit-identical to the
+    single call, forward and backward."""
+    import ctypes as C
+    from facet_graph_convolution_amd import ops, _lib
+    from facet_graph_convolution_amd.graph import FacetGraph
+    from facet_graph_convolution_amd.ops import make_conv_desc, ptr, stream_ptr
+    z = np.load(os.path.join(golden_dir, "conv_c1_coarsened.npz"))
+    dev = torch.device("cuda:0")
+    x = torch.tensor(z["x"][0], device=dev)
+    g = FacetGraph(z["adj"], dev)
+    n, cin, cout = g.n, x.shape[1], int(z["cout"])
+    params = _params(cin, cout, int(z["seed"]), dev)
+    L = _lib.lib()
+    y_ref, _, ag_ref = ops.conv_fwd(g, x, None, 0, params)
+    dy = torch.tensor(np.random.RandomState(3).normal(size=(n, cout)).astype(np.float32), device=dev)
+    dx_ref, _, grads_ref = ops.conv_bwd(g, x, None, 0, params, ag_ref, y_ref, dy)
+
+    ntiles = (n + 31) // 32
+    rs = np.random.RandomState(4)
+    first = np.sort(rs.choice(ntiles, ntiles // 3, replace=False)).astype(np.int32)
+    second = np.setdiff1d(np.arange(ntiles, dtype=np.int32), first).astype(np.int32)
+    lists = [torch.tensor(a, device=dev) for a in (first, second)]
+    d = make_conv_desc(g, x, None, 0, params, True, 0, 0.1)
+    ws = torch.empty(max(L.fgc_conv_workspace_bytes(C.byref(d)), L.fgc_conv_bwd_workspace_bytes(C.byref(d))) + 256,
+                     dtype=torch.uint8, device=dev)
+    ag = torch.full((n, 24), float("nan"), device=dev)
+    y = torch.full((n, cout), float("nan"), device=dev)
+    split_row = 700
+    # call 1: every logit row + the first tile list; call 2: no logits, the other tiles, operands still packed
+    for tl, pr, fl in [(lists[0], 0, 0), (lists[1], -1, 1)]:
+        d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = tl.data_ptr(), tl.numel(), 0, pr, fl
+        _lib.check(L.fgc_conv_fwd(C.byref(d), ptr(ag), ptr(y), None, ptr(ws), ws.numel(), stream_ptr()), "partial fwd")
+    assert torch.equal(y, y_ref) and torch.equal(ag, ag_ref)
+    # logits in two row ranges
+    ag2 = torch.full((n, 24), float("nan"), device=dev)
+    empty = torch.zeros(1, dtype=torch.int32, device=dev)
+    for r0, nr, fl in [(0, split_row, 0), (split_row, n - split_row, 1)]:
+        d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = empty.data_ptr(), 0, r0, nr, fl
+        _lib.check(L.fgc_conv_fwd(C.byref(d), ptr(ag2), ptr(y), None, ptr(ws), ws.numel(), stream_ptr()), "logits only")
+    assert torch.equal(ag2, ag_ref)
+    d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, 0
+
+    # backward: stages 1, 2, then the data kernel over two tile lists, then the weight gradients
+    trow, tcol, tedge = g.transposed()
+    f32 = dict(dtype=torch.float32, device=dev)
+    io = _lib.ConvBwdIO()
+    io.trowptr, io.tcol, io.tedge, io.max_in_deg = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr(), g.max_in_deg
+    bufs = dict(ds=torch.empty(n, cout, **f32), dl=torch.empty(g.nnz, 12, **f32), dag=torch.empty(n, 24, **f32),
+                r=torch.empty(n, 9 * cout, **f32), dx=torch.full((n, cin), float("nan"), **f32))
+    grads = [torch.empty_like(p) for p in params]
+    io.ag, io.y, io.dy = ag_ref.data_ptr(), y_ref.data_ptr(), dy.data_ptr()
+    io.ds, io.dl, io.dag, io.r = (bufs[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
+    io.dx0 = bufs["dx"].data_ptr()
+    io.dW0, io.db, io.du, io.dc, io.dv = [t.data_ptr() for t in grads]
+    for stages, tl, fl in [(1, None, 0), (2, None, 0), (4, lists[1], 1), (4 | 8, lists[0], 1)]:
+        io.stages, io.flags = stages, fl
+        io.data_tile_list, io.n_data_tiles = (tl.data_ptr(), tl.numel()) if tl is not None else (None, 0)
+        _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "partial bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(bufs["dx"], dx_ref)
+    for a, b in zip(grads, grads_ref):
+        assert torch.equal(a, b)

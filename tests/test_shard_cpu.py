@@ -38,6 +38,15 @@ def test_plan_is_consistent(golden_dir, world):
                 own = loc < P.n_own
                 assert np.array_equal(up[own], loc[own])
                 assert np.array_equal(up[~own] // 4, P.n_own // 4 + (loc[~own] - P.n_own))
+            # interior / boundary tiles: a partition of the 32-row tiles; interior ones touch owned rows only
+            for rp, cc, ti, tb in ((P.rowptr, P.col, P.tiles_int, P.tiles_bnd),
+                                   (P.trowptr, P.tcol, P.ttiles_int, P.ttiles_bnd)):
+                ntiles = (P.n_own + 31) // 32
+                assert np.array_equal(np.sort(np.concatenate([ti, tb])), np.arange(ntiles))
+                for t in ti:
+                    assert (cc[rp[32 * t]:rp[min(32 * t + 32, P.n_own)]] < P.n_own).all()
+                for t in tb:
+                    assert (cc[rp[32 * t]:rp[min(32 * t + 32, P.n_own)]] >= P.n_own).any()
             # what peers send me, in their order, is exactly my halo
             got = []
             for q in range(world):
