@@ -710,8 +710,8 @@ struct BwdWorkspace {
     float* Wpt;       // data-gradient operand
     float* db_part;   // [nb][cout]
     float* dc_part;   // [tiles][12]
-    float* slab;      // gemm_tn partials
-    float* duv;       // [24, cin]
+    float* slab;      // gemm_tn partials of dW0
+    float* slab_uv;   // gemm_tn partials of [du; dv]
     float* rtmp;      // scratch of the fixed-order reductions
     size_t bytes;
     int nb_db, rows_per_db;
@@ -739,11 +739,9 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.dc_part = take((size_t)cdiv(d->n, TILE) * 12);
     w.splitW = tn_splits(FGC_M * d->cout, cin, d->n);
     w.splitUV = tn_splits(24, cin, d->n);
-    const size_t s1 = (size_t)w.splitW * FGC_M * d->cout * cin;
-    const size_t s2 = (size_t)w.splitUV * 24 * cin;
-    w.slab = take(s1 > s2 ? s1 : s2);
-    w.duv = take((size_t)24 * cin);
-    w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + reduce_tmp_floats(w.splitUV, (size_t)24 * cin) +
+    w.slab = take((size_t)w.splitW * FGC_M * d->cout * cin);
+    w.slab_uv = take((size_t)w.splitUV * 24 * cin);
+    w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitUV, (size_t)FGC_M * cin) +
                   reduce_tmp_floats(cdiv(d->n, TILE), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
     w.bytes = off;
     return w;
@@ -821,9 +819,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         while (cp2 < cout) cp2 <<= 1;
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
                    d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
-        FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");
-        rc = reduce_slabs("reduce:db", w.db_part, w.nb_db, (size_t)cout, cout, cout, io->db, w.rtmp, st);
-        if (rc) return rc;
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");   // db partials are summed with the other parameter gradients (stage 8)
     }
     // operand packing
     if ((stages & 6) && !(io->flags & FGC_CONV_PACKED)) {
@@ -867,9 +863,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             case 4: rc = launch_logits<4>(p, lp, vec4, smem, st); break;
             default: rc = launch_logits<8>(p, lp, vec4, smem, st); break;
         }
-        if (rc) return rc;
-        rc = reduce_slabs("reduce:dc", w.dc_part, cdiv(d->n, TILE), (size_t)12, 12, FGC_M, io->dc, w.rtmp, st);
-        if (rc) return rc;
+        if (rc) return rc;   // dc partials: stage 8
     }
     // K2
     if ((stages & 4) && !(io->data_tile_list && io->n_data_tiles == 0)) {
@@ -909,25 +903,26 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         else FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<false>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
                         d->c0, d->c1, d->shift, d->n, rps, w.slab);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
-        rc = reduce_slabs("reduce:dW", w.slab, ns, (size_t)P * cin, cin, cin, io->dW0, w.rtmp, st);
-        if (rc) return rc;
+        const int nsW = ns;
         rps = cdiv(cdiv(d->n, w.splitUV), 4) * 4;
         ns = cdiv(d->n, rps);
         const dim3 g2(cdiv(cin, 64), ns);
         if (v4) FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<true>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
-                           d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+                           d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
         else FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<false>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
-                        d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+                        d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/duv");
-        rc = reduce_slabs("reduce:duv", w.slab, ns, (size_t)24 * cin, cin, cin, w.duv, w.rtmp, st);
+        // every parameter gradient of the layer in two launches (fixed summation order).  The db / dc partials were
+        // left in the workspace by stages 1 and 2: a staged caller keeps the workspace untouched between its calls.
+        const RedJob jobs[5] = {
+            {w.slab, (size_t)P * cin, nsW, P * cin, cin, cin, io->dW0},
+            {w.slab_uv, (size_t)24 * cin, ns, FGC_M * cin, cin, cin, io->du},
+            {w.slab_uv + (size_t)12 * cin, (size_t)24 * cin, ns, FGC_M * cin, cin, cin, io->dv},
+            {w.db_part, (size_t)cout, w.nb_db, cout, cout, cout, io->db},
+            {w.dc_part, (size_t)12, cdiv(d->n, TILE), 12, 12, FGC_M, io->dc},
+        };
+        rc = reduce_jobs("reduce:params", jobs, 5, w.rtmp, st);
         if (rc) return rc;
-        if (hipMemcpyAsync(io->du, w.duv, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(io->dv, w.duv + (size_t)12 * cin, (size_t)FGC_M * cin * 4, hipMemcpyDeviceToDevice, st) !=
-                hipSuccess) {
-            fgc::set_error("fgc_conv_bwd: copy of du/dv failed");
-            return FGC_EHIP;
-        }
-        FGC_CHECK_LAUNCH("fgc_conv_bwd/duv");
     }
     return FGC_OK;
 }

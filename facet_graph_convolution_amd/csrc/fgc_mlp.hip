@@ -376,7 +376,8 @@ extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hi
     b += align_up(gx * (size_t)hidden * 4, 256);           // db1 slabs
     b += align_up(gx * (size_t)hidden * 4 * 4, 256);       // dW2 slabs
     b += align_up((size_t)1024 * 4 * 4, 256);              // db2 partials
-    b += align_up(reduce_tmp_floats(1024, 4) * 4 + reduce_tmp_floats((int)gx, (size_t)cin * hidden) * 4 + 256, 256);
+    b += align_up((reduce_tmp_floats(1024, 4) + reduce_tmp_floats((int)gx, (size_t)cin * hidden) +
+                   reduce_tmp_floats((int)gx, (size_t)hidden * 5)) * 4 + 256, 256);
     return b;
 }
 
@@ -445,23 +446,20 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     else FGC_MLP_BWD_LAUNCH(8, 1);
 #undef FGC_MLP_BWD_LAUNCH
     FGC_CHECK_LAUNCH("fgc_mlp_bwd");
-    // fixed-order reductions
-    int rc = reduce_slabs("reduce:mlp_dx", dx_slab, gy, (size_t)n * cin, cin, cin, dx, rtmp, st);
+    // db2 = column sums of dy (stage 1 here, summed with the other partials below)
+    const int nb = n < 1024 * 64 ? cdiv(n, 64) : 1024;
+    const int rpb = cdiv(n, nb);
+    FGC_LAUNCH("colsum_stage1_kernel", st, colsum_stage1_kernel, dim3(nb), dim3(64), 0, dy, n, cout, rpb, db2_part);
+    // fixed-order reductions, all five in two launches
+    const RedJob jobs[5] = {
+        {dx_slab, (size_t)n * cin, gy, n * cin, cin, cin, dx},
+        {dW1_slab, (size_t)cin * hidden, gx, cin * hidden, hidden, hidden, dW1},
+        {db1_slab, (size_t)hidden, gx, hidden, hidden, hidden, db1},
+        {dW2_slab, (size_t)hidden * 4, gx, hidden * 4, 4, cout, dW2},
+        {db2_part, (size_t)cout, nb, cout, cout, cout, db2},
+    };
+    const int rc = reduce_jobs("reduce:mlp", jobs, 5, rtmp, st);
     if (rc) return rc;
-    rc = reduce_slabs("reduce:mlp_dW1", dW1_slab, gx, (size_t)cin * hidden, hidden, hidden, dW1, rtmp, st);
-    if (rc) return rc;
-    rc = reduce_slabs("reduce:mlp_db1", db1_slab, gx, (size_t)hidden, hidden, hidden, db1, rtmp, st);
-    if (rc) return rc;
-    rc = reduce_slabs("reduce:mlp_dW2", dW2_slab, gx, (size_t)hidden * 4, 4, cout, dW2, rtmp, st);
-    if (rc) return rc;
-    // db2 = column sums of dy
-    {
-        const int nb = n < 1024 * 64 ? cdiv(n, 64) : 1024;
-        const int rpb = cdiv(n, nb);
-        FGC_LAUNCH("colsum_stage1_kernel", st, colsum_stage1_kernel, dim3(nb), dim3(64), 0, dy, n, cout, rpb, db2_part);
-        rc = reduce_slabs("reduce:mlp_db2", db2_part, nb, (size_t)cout, cout, cout, db2, rtmp, st);
-        if (rc) return rc;
-    }
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/reduce");
     return FGC_OK;
 }

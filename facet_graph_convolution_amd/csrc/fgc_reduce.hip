@@ -1,5 +1,7 @@
 // Fixed-order slab reduction: workgroup = 64 columns x 4 slab lanes; each lane sums every 4th slab of its group
 // of up to 64, the 4 lane partials are combined in a fixed order; groups are reduced recursively.
+#include <algorithm>
+
 #include "fgc_reduce.h"
 
 namespace fgc {
@@ -36,6 +38,110 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const float* __restri
             out[(size_t)blockIdx.y * count + j] = v;
         }
     }
+}
+
+struct RedJobs {
+    RedJob job[RED_MAX_JOBS];
+    float* stage_out[RED_MAX_JOBS];   // where this stage writes (tmp, or the job's out when `fin`)
+    int fin[RED_MAX_JOBS];
+    int block0[RED_MAX_JOBS + 1];     // first workgroup of each job
+    int xblocks[RED_MAX_JOBS];        // workgroups along the element axis
+    int group[RED_MAX_JOBS];          // slabs per workgroup (RED_GROUP unless the job has more than RED_GROUP^2 slabs)
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobs J) {
+    __shared__ float part[4][64];
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < RED_MAX_JOBS; ++t)
+        if (t < J.njobs && (int)blockIdx.x >= J.block0[t]) q = t;
+    const RedJob& job = J.job[q];
+    const int b = blockIdx.x - J.block0[q];
+    const int bx = b % J.xblocks[q], by = b / J.xblocks[q];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = bx * 64 + col;
+    const int s0 = by * J.group[q];
+    const int s1 = min(job.nslabs, s0 + J.group[q]);
+    const float* slab = job.slab;
+    const size_t stride = job.stride;
+    float acc = 0.f;
+    if (j < job.count) {
+        int s = s0 + sl;
+        for (; s + 12 < s1; s += 16) {  // 4 independent loads in flight
+            const float a = slab[(size_t)s * stride + j], bb = slab[(size_t)(s + 4) * stride + j],
+                        c = slab[(size_t)(s + 8) * stride + j], d = slab[(size_t)(s + 12) * stride + j];
+            acc += a;
+            acc += bb;
+            acc += c;
+            acc += d;
+        }
+        for (; s < s1; s += 4) acc += slab[(size_t)s * stride + j];
+    }
+    part[sl][col] = acc;
+    __syncthreads();
+    if (sl == 0 && j < job.count) {
+        const float v = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+        float* out = J.stage_out[q];
+        if (J.fin[q]) {
+            const int c = j % job.in_ld;
+            if (c < job.out_ld) out[(size_t)(j / job.in_ld) * job.out_ld + c] = v;
+        } else {
+            out[(size_t)by * job.count + j] = v;
+        }
+    }
+}
+
+int reduce_jobs(const char* what, const RedJob* jobs, int njobs, float* tmp, hipStream_t st) {
+    if (njobs <= 0) return FGC_OK;
+    if (njobs > RED_MAX_JOBS) {
+        set_error("reduce_jobs: %d jobs (max %d)", njobs, RED_MAX_JOBS);
+        return FGC_EINVAL;
+    }
+    RedJobs A, B;
+    A.njobs = njobs;
+    B.njobs = 0;
+    int nb = 0, nb2 = 0;
+    float* t = tmp;
+    for (int q = 0; q < njobs; ++q) {
+        const RedJob& j = jobs[q];
+        // two stages always suffice: very long slab lists get proportionally larger groups
+        const int group = std::max(RED_GROUP, (j.nslabs + RED_GROUP - 1) / RED_GROUP);
+        const int groups = (j.nslabs + group - 1) / group;
+        if (j.nslabs <= 0 || j.count <= 0) {
+            set_error("reduce_jobs: job %d has %d slabs of %d elements", q, j.nslabs, j.count);
+            return FGC_EINVAL;
+        }
+        A.job[q] = j;
+        A.xblocks[q] = (j.count + 63) / 64;
+        A.block0[q] = nb;
+        nb += A.xblocks[q] * groups;
+        A.group[q] = group;
+        A.fin[q] = groups == 1;
+        A.stage_out[q] = groups == 1 ? j.out : t;
+        if (groups > 1) {
+            const int k = B.njobs++;
+            B.job[k] = j;
+            B.job[k].slab = t;
+            B.job[k].stride = (size_t)j.count;
+            B.job[k].nslabs = groups;
+            B.xblocks[k] = A.xblocks[q];
+            B.block0[k] = nb2;
+            nb2 += B.xblocks[k];
+            B.group[k] = RED_GROUP;
+            B.fin[k] = 1;
+            B.stage_out[k] = j.out;
+            t += (size_t)groups * j.count;
+        }
+    }
+    A.block0[njobs] = nb;
+    FGC_LAUNCH(what, st, reduce_jobs_kernel, dim3(nb), dim3(256), 0, A);
+    if (B.njobs) {
+        B.block0[B.njobs] = nb2;
+        FGC_LAUNCH(what, st, reduce_jobs_kernel, dim3(nb2), dim3(256), 0, B);
+    }
+    FGC_CHECK_LAUNCH("reduce_jobs");
+    return FGC_OK;
 }
 
 int reduce_slabs(const char* what, const float* slab, int nslabs, size_t count, int in_ld, int out_ld, float* out,
