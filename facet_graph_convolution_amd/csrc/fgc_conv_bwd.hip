@@ -464,6 +464,205 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1, matrix-core form with deep gathers (every 32-channel pass comes from ONE source: cg % 32 == 0 and the concat
+// boundary on a pass boundary; degree <= 16 handled on the fast path, 17..24 by a second edge tile).
+// Same math and summation order as conv_bwd_logits_mfma_kernel.  What changes is when memory is asked for: the
+// neighbour rows of ALL 8 nodes of a wave (the B fragments of the per-edge products) are requested with buffer
+// loads at the top of the pass, so their latency runs under the dz GEMM instead of once per node, and the packed-
+// weight fragments of the dz GEMM are requested one k-group ahead.  LDS limits residency to 2 waves per SIMD, so
+// the 256-VGPR budget is there to be used.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw, p.zstride);
+    float* dst = s.extra;                       // ds tile [TILE][ostride]
+    float* red = dst + TILE * lp.ostride;       // [4][12]
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+
+    for (int t = tid; t < TILE * lp.opad; t += NTHREADS) {
+        const int r = t / lp.opad, o = t % lp.opad;
+        const int i = tile0 + r;
+        dst[r * lp.ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
+    }
+    const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
+    // edges 0..15 of every node in sweep 0; a second sweep (block-uniform, rare) for nodes with 17..24 edges.  The
+    // per-edge work is independent across edges, so a sweep is the whole computation for its 16 edge slots.
+    const int nsweeps = __syncthreads_or(dmine > 16) ? 2 : 1;
+
+    const int nct = p.kpass >> 4;   // 18
+    const int okg = lp.opad >> 4;
+    const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
+    int dn[NPW];
+#pragma unroll
+    for (int nn = 0; nn < NPW; ++nn) dn[nn] = __builtin_amdgcn_readfirstlane(min(s.deg[wave * NPW + nn], KMAX));
+    const int mrow = lr < FGC_M ? lr : FGC_M - 1;  // rows 9..15 of the product are never read
+    f32x4 dcacc = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int sweep = 0; sweep < nsweeps; ++sweep) {
+        const int ebase = sweep * 16;
+        // row id of this lane's edge slot (clamped into the node's list) for each node of the wave
+        int rowid[NPW];
+        f32x4 dq[NPW];
+#pragma unroll
+        for (int nn = 0; nn < NPW; ++nn) {
+            const int node = wave * NPW + nn;
+            const int e = max(min(ebase + lr, dn[nn] - 1), 0);
+            rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[((size_t)node * KMAX + e) * QLD + 9]) : 0;
+            dq[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int pass = 0; pass < p.passes; ++pass) {
+            const int cpass = pass * p.kc;
+            const bool first = cpass < p.c0;                                            // block-uniform
+            const float* base = first ? p.src0 : p.src1;
+            const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * 4u;
+            const unsigned laneoff = (unsigned)((first ? cpass : cpass - p.c0) + 4 * lq) * 4u;
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+            // ---- B fragments (neighbour rows) of the wave's nodes, in two halves of 4 nodes = 8 x dwordx4 per lane:
+            // the first half is requested here and lands under the dz GEMM, the second half after the GEMM and
+            // lands under the barrier, the dz store and the first half's MFMAs
+            constexpr int H = NPW / 2;
+            f32x4 bxa[H][2], bxb[H][2];
+            auto gather = [&](int n0, f32x4 (&bx)[H][2]) {
+#pragma unroll
+                for (int nn = 0; nn < H; ++nn) {
+                    const unsigned off = __umul24((unsigned)rowid[n0 + nn], rowbytes) + laneoff;
+                    bx[nn][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                    bx[nn][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64u, 0, 0));
+                }
+            };
+            gather(0, bxa);
+            // ---- dz tile = ds tile x Wq[pass] (f32 MFMA) -> LDS
+            {
+                f32x4 acc[RT][K1_CTW];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < K1_CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto loadw = [&](int g, f32x4 (&b)[K1_CTW]) {
+                    const int gg = min(g, okg - 1);
+#pragma unroll
+                    for (int c = 0; c < K1_CTW; ++c) {
+                        const int ct = min(wave + c * 4, nct - 1);
+                        b[c] = Wq4[((size_t)pass * (lp.opad >> 2) + gg * 4 + lq) * p.kpass + ct * 16 + lr];
+                    }
+                };
+                auto mmw = [&](int g, const f32x4 (&b)[K1_CTW]) {
+                    f32x4 a[RT];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * lp.ostride + g * 16 + lq * 4);
+#pragma unroll
+                    for (int c = 0; c < K1_CTW; ++c)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int r = 0; r < RT; ++r)
+                                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+                };
+                for (int g = 0; g < okg; ++g) {
+                    f32x4 w0[K1_CTW];
+                    loadw(g, w0);
+                    mmw(g, w0);
+                }
+                gather(H, bxb);
+                if (pass > 0 || sweep > 0) __syncthreads();  // the previous readers of ztile are done
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c) {
+                    const int ct = wave + c * 4;
+                    if (ct >= nct) continue;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            s.ztile[(size_t)(r * 16 + lq * 4 + t) * p.zstride + ct * 16 + lr] = acc[r][c][t];
+                }
+            }
+            __syncthreads();
+            // ---- per node: dq += dz_i (9 x 32) . X_i (32 x 16 edge slots)
+            auto products = [&](int n0, const f32x4 (&bx)[H][2]) {
+#pragma unroll
+                for (int nn = 0; nn < H; ++nn) {
+                    const int node = wave * NPW + n0 + nn;
+                    const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(zr + 16);
+                    f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {  // two independent accumulation chains
+                        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], bx[nn][0][t], t0, 0, 0, 0);
+                        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], bx[nn][1][t], t1, 0, 0, 0);
+                    }
+                    dq[n0 + nn] += t0 + t1;
+                }
+            };
+            products(0, bxa);
+            products(H, bxb);
+        }
+
+        // ---- softmax backward of this sweep's edge slots: lane (edge = ebase + lr, m0 = 4*lq) holds dq[m0..m0+3]
+#pragma unroll
+        for (int nn = 0; nn < NPW; ++nn) {
+            const int node = wave * NPW + nn;
+            const int i = tile0 + node;
+            const int d = dn[nn];
+            if (i >= p.n) continue;                    // wave-uniform
+            if (d <= ebase) {                          // wave-uniform; an isolated node still owns a dag row
+                if (sweep == 0 && lr == 0 && lq < 3)
+                    *reinterpret_cast<f32x4*>(lp.dag + (size_t)i * FGC_AG_LD + 4 * lq) = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+            const int e0 = s.deg[TILE + 4 + node];     // first edge id, left in LDS by the softmax phase
+            const int edge = ebase + lr;
+            const bool ok = edge < d;
+            const float* qr = s.qbuf + ((size_t)node * KMAX + min(edge, d - 1)) * QLD;
+            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
+            else if (lq == 2) q[0] = qr[8];
+            f32x4 g = dq[nn];
+            if (lq == 2) { g[1] = 0.f; g[2] = 0.f; g[3] = 0.f; }
+            if (lq == 3) g = f32x4{0.f, 0.f, 0.f, 0.f};
+            float dot = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+            f32x4 da;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) da[t] = ok ? q[t] * (g[t] - dot) : 0.f;
+            if (ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = da;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = da[t];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                da[t] = v;
+            }
+            dcacc += da;                               // dc = sum over nodes and edges of dl
+            if (lr == 0 && lq < 3) {
+                float* o = lp.dag + (size_t)i * FGC_AG_LD + 4 * lq;
+                // second sweep: add to what this same thread stored in the first
+                if (sweep > 0) da += *reinterpret_cast<const f32x4*>(o);
+                *reinterpret_cast<f32x4*>(o) = da;
+            }
+        }
+    }
+    // dc partial of this workgroup: lanes lr == 0 hold the per-wave sums (m0 = 4*lq)
+    __syncthreads();
+    if (lr == 0 && lq < 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[wave * 12 + 4 * lq + t] = dcacc[t];
+    }
+    __syncthreads();
+    if (tid < 12) {
+        const float v = tid < FGC_M ? (red[tid] + red[12 + tid]) + (red[24 + tid] + red[36 + tid]) : 0.f;
+        lp.dc_part[(size_t)blockIdx.x * 12 + tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2: data gradient = forward core over the transposed graph
 // ---------------------------------------------------------------------------------------------
 template <int LPN, bool VEC4>
@@ -849,7 +1048,16 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr = true;
             }
-            if (vec4)
+            const bool deep = vec4 && cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) &&
+                              (size_t)d->n * 4 * 128 < 0xFFFFFFFFull &&
+                              !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+            if (deep) {
+                // (__syncthreads_or owns 256 B of static LDS: ask for exactly what this launch needs)
+                hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem);
+                FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, conv_bwd_logits_deep_kernel, dim3(cdiv(d->n, TILE)),
+                           dim3(NTHREADS), smem, p, lp);
+            } else if (vec4)
                 FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, (conv_bwd_logits_mfma_kernel<true>),
                            dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);
             else

@@ -26,8 +26,35 @@ __device__ __forceinline__ f32x2 load_chunk2(const CoreParams& p, int row, int c
     return v;
 }
 
-template <bool DATA>
-__global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+// N edge slots of one node: row ids (with q[8]) -> N buffer loads -> N x 9 packed FMAs.  Unconditional.
+template <int N>
+__device__ __forceinline__ void edge_batch(__amdgpu_buffer_rsrc_t rsrc, unsigned rowbytes, unsigned laneoff,
+                                           const float* qk, f32x2 (&z)[FGC_M]) {
+    f32x2 q89[N], xv[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) q89[t] = *reinterpret_cast<const f32x2*>(qk + t * QLD + 8);   // q[8], row id
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const unsigned off = __umul24((unsigned)__float_as_int(q89[t][1]), rowbytes) + laneoff;
+        xv[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk + t * QLD);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(qk + t * QLD + 4);
+        z[0] += q0[0] * xv[t]; z[1] += q0[1] * xv[t]; z[2] += q0[2] * xv[t]; z[3] += q0[3] * xv[t];
+        z[4] += q1[0] * xv[t]; z[5] += q1[1] * xv[t]; z[6] += q1[2] * xv[t]; z[7] += q1[3] * xv[t];
+        z[8] += q89[t][0] * xv[t];
+    }
+}
+
+// FAST: every pass gathers 32 valid channels from ONE source (cg % 32 == 0 and the concat boundary on a pass boundary:
+// all network layers except conv1).  Then the edge loop is branch-free: qbuf is padded with zero-weight edges up to
+// the wave's largest degree rounded up to 8, all lanes run the same (scalar) trip count, rows are fetched with
+// buffer loads whose 32-bit offset is one v_mad_u32_u24 from the row id, and the row id travels with q[8] in one
+// ds_read_b64.  The generic form keeps per-lane degree tests (exec masking) and 64-bit addressing.
+template <bool DATA, bool FAST>
+__global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
     float* dagt = s.extra;  // DATA: [TILE][24]
@@ -37,6 +64,7 @@ __global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, Fw
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
 
     // ---------------- phase S: per-edge soft assignment (edges kl and kl + 16 of this thread's node)
+    int dwave = 0;  // FAST: wave-uniform trip count of the edge loop
     float dgsum[FGC_M];
 #pragma unroll
     for (int m = 0; m < FGC_M; ++m) dgsum[m] = 0.f;
@@ -57,6 +85,12 @@ __global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, Fw
             ctr[8] = ar[8];
         }
         if (kl == 0) s.deg[node] = d;
+        if (FAST) {  // largest degree among the 4 nodes of this wave, rounded up to a whole batch of 8 edge slots
+            const int dmax = max(max(__builtin_amdgcn_readlane(d, 0), __builtin_amdgcn_readlane(d, 16)),
+                                 max(__builtin_amdgcn_readlane(d, 32), __builtin_amdgcn_readlane(d, 48)));
+            dwave = dmax;
+        }
+        const int dfill = (dwave + 7) & ~7;
         int jj[2];
         f32x4 g0[2], g1[2];
         float g8[2];
@@ -75,7 +109,16 @@ __global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, Fw
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int k = kl + 16 * t;
-            if (k >= d) continue;
+            if (k >= d) {
+                if (FAST && k < dfill) {  // zero-weight slot pointing at a valid row
+                    float* q = s.qbuf + ((size_t)node * KMAX + k) * QLD;
+                    *reinterpret_cast<f32x4*>(q) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(q + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    q[8] = 0.f;
+                    q[9] = __int_as_float(0);
+                }
+                continue;
+            }
             float l[FGC_M];
             l[0] = ctr[0] + g0[t][0]; l[1] = ctr[1] + g0[t][1]; l[2] = ctr[2] + g0[t][2]; l[3] = ctr[3] + g0[t][3];
             l[4] = ctr[4] + g1[t][0]; l[5] = ctr[5] + g1[t][1]; l[6] = ctr[6] + g1[t][2]; l[7] = ctr[7] + g1[t][3];
@@ -159,6 +202,25 @@ __global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, Fw
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) z[m] = f32x2{0.f, 0.f};
         const int cbase = pass * p.kc + 2 * cl;
+        if (FAST) {
+            const bool first = pass * p.kc < p.c0;                                   // wave-uniform
+            const float* base = first ? p.src0 : p.src1;
+            const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * 4u;
+            const unsigned laneoff = (unsigned)(first ? cbase : cbase - p.c0) * 4u;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+            // whole batches of 8 edge slots, then the remainder rounded up to a pair (its own straight-line code:
+            // every row of a batch is requested before the first FMA, and nothing in a batch is conditional)
+            int k0 = 0;
+            for (; k0 + 8 <= dwave; k0 += 8) edge_batch<8>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+            const int rem = dwave - k0;
+            if (rem > 4) {
+                if (rem > 6) edge_batch<8>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+                else edge_batch<6>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+            } else if (rem > 0) {
+                if (rem > 2) edge_batch<4>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+                else edge_batch<2>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+            }
+        } else
         for (int k0 = 0; k0 < d; k0 += RB) {
             f32x2 xv[RB];
 #pragma unroll
@@ -178,8 +240,7 @@ __global__ __launch_bounds__(W8_THREADS, 2) void conv_w8_kernel(CoreParams p, Fw
                     z[8] += q8 * xv[t];
                 }
             }
-        }
-        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
+        }        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
             const int j = tile0 + node;
             if (j < p.n && cbase < p.cg) {
                 float* rr = de.r + (size_t)j * de.rld + cbase;
@@ -326,17 +387,27 @@ bool w8_supported(const CoreParams& p, int max_deg) {
     return true;
 }
 
-template <bool DATA>
-static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
+static bool w8_fast(const CoreParams& p) {
+    if (getenv("FGC_NO_W8FAST") && getenv("FGC_NO_W8FAST")[0] == '1') return false;
+    return p.cg % 32 == 0 && (p.c1 == 0 || p.c0 % 32 == 0) && (size_t)p.n * 4 * 128 < 0xFFFFFFFFull;
+}
+
+template <bool DATA, bool FAST>
+static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA>), dim3(core_grid(p)),
+    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST>), dim3(core_grid(p)),
                dim3(W8_THREADS), smem, p, fe, de);
     FGC_CHECK_LAUNCH("conv_w8_kernel");
     return FGC_OK;
+}
+
+template <bool DATA>
+static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
+    return w8_fast(p) ? launch_w8f<DATA, true>(p, fe, de, smem, st) : launch_w8f<DATA, false>(p, fe, de, smem, st);
 }
 
 int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, hipStream_t st) {
