@@ -299,6 +299,50 @@ extern "C" int fgc_faces_large_adj(const uint32_t* F, int32_t nf, int32_t nv, in
     return FGC_OK;
 }
 
+// utils.py:91-183.  Faces in order; (v1,v2) and (v1,v3) are searched among v1's edges, (v2,v3) among v2's; a found
+// edge takes this face as its second face, a missing one is created in the order 12, 13, 23.
+extern "C" int fgc_edge_map(const uint32_t* F, int32_t nf, int32_t nv, int32_t max_edges, int32_t* e_map,
+                            int32_t* n_edges, int32_t* v_e_map) {
+    FGC_CHECK_ARG(F && e_map && n_edges && v_e_map && nf > 0 && nv > 0 && max_edges > 0, "fgc_edge_map: bad arguments");
+    for (size_t t = 0; t < (size_t)nf * 12; ++t) e_map[t] = -1;
+    for (size_t t = 0; t < (size_t)nv * max_edges; ++t) v_e_map[t] = -1;
+    std::vector<int> cnt(nv, 0);
+    int eind = 0;
+    auto has = [&](int ce, int v) { return e_map[4 * (size_t)ce] == v || e_map[4 * (size_t)ce + 1] == v; };
+    for (int f = 0; f < nf; ++f) {
+        const int v[3] = {(int)F[3 * f], (int)F[3 * f + 1], (int)F[3 * f + 2]};
+        for (int t = 0; t < 3; ++t)
+            FGC_CHECK_ARG(v[t] >= 0 && v[t] < nv, "fgc_edge_map: face %d references vertex %d >= %d", f, v[t], nv);
+        bool e12 = false, e13 = false, e23 = false;
+        for (int ne = 0; ne < cnt[v[0]]; ++ne) {
+            const int ce = v_e_map[(size_t)v[0] * max_edges + ne];
+            if (has(ce, v[1])) { e12 = true; e_map[4 * (size_t)ce + 3] = f; }
+            if (has(ce, v[2])) { e13 = true; e_map[4 * (size_t)ce + 3] = f; }
+        }
+        for (int ne = 0; ne < cnt[v[1]]; ++ne) {
+            const int ce = v_e_map[(size_t)v[1] * max_edges + ne];
+            if (has(ce, v[2])) { e23 = true; e_map[4 * (size_t)ce + 3] = f; }
+        }
+        const int pairs[3][2] = {{v[0], v[1]}, {v[0], v[2]}, {v[1], v[2]}};
+        const bool found[3] = {e12, e13, e23};
+        for (int k = 0; k < 3; ++k) {
+            if (found[k]) continue;
+            const int a = pairs[k][0], b = pairs[k][1];
+            FGC_CHECK_ARG(cnt[a] < max_edges && cnt[b] < max_edges,
+                          "fgc_edge_map: vertex %d has more than %d edges (utils.py:103 sizes the table)",
+                          cnt[a] < max_edges ? b : a, max_edges);
+            e_map[4 * (size_t)eind] = a;
+            e_map[4 * (size_t)eind + 1] = b;
+            e_map[4 * (size_t)eind + 2] = f;
+            v_e_map[(size_t)a * max_edges + cnt[a]++] = eind;
+            v_e_map[(size_t)b * max_edges + cnt[b]++] = eind;
+            ++eind;
+        }
+    }
+    *n_edges = eind;
+    return FGC_OK;
+}
+
 extern "C" int fgc_metis_one_level(const int32_t* rr, const int32_t* cc, const float* vv, int64_t nnz,
                                    const int64_t* rid, const float* weights, int32_t N, int32_t* cluster_id,
                                    double* total_assoc) {

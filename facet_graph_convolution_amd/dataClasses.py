@@ -6,6 +6,7 @@ Same attribute names and per-mesh list layout:
     adj_list[i][l]  int64   [1, N_l, 23]  one-indexed K-lists of the 3 graph levels (binary-tree order)
     gt_list[i]      float64 [1, N0, 3]    ground-truth normals (training sets)
     num_faces[i], patch_indices[i], permutations[i] (= inv_perm(newToOld))
+    edge_map int32 [1, E, 4], v_e_map int32 [1, V, MAX_EDGES]  (getEdgeMap, for the vertex update)
 
 Differences, by design: the adjacency / coarsening loops run natively (libfgc host routines) and a mesh is
 kept whole: the reference cuts meshes above MAX_PATCH_SIZE = 20 000 faces into BFS patches only because one
@@ -15,7 +16,7 @@ mode is listed as a follow-up.
 import numpy as np
 
 from . import utils
-from .settings import K_faces, COARSENING_STEPS, COARSENING_LVLS, MIN_PATCH_SIZE
+from .settings import K_faces, COARSENING_STEPS, COARSENING_LVLS, MIN_PATCH_SIZE, MAX_EDGES
 
 
 class PreprocessedData(object):
@@ -40,6 +41,13 @@ class PreprocessedData(object):
         V0 = np.asarray(V0, dtype=np.float32)
         faces0 = np.asarray(faces0)
         facesNum = faces0.shape[0]
+        # dataClasses.py:40-42: edge tables for the vertex update that follows inference
+        try:
+            self.edge_map, self.v_e_map = utils.getEdgeMap(faces0, maxEdges=MAX_EDGES)
+            self.edge_map = np.expand_dims(self.edge_map, axis=0)
+            self.v_e_map = np.expand_dims(self.v_e_map, axis=0)
+        except RuntimeError:        # a vertex with more than MAX_EDGES edges: the reference dies here with an
+            self.edge_map = self.v_e_map = None   # IndexError; normals can still be inferred, only the vertex update cannot
         if facesNum > self.maxSize:
             raise NotImplementedError(
                 "patch mode (dataClasses.py:76-171) is not built: meshes are processed whole on MI355X; "

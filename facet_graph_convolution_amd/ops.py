@@ -287,3 +287,16 @@ def scatter_add_rows(src, idx, dst):
     check(_lib.lib().fgc_scatter_add_rows(ptr(src), ptr(idx), idx.numel(), src.shape[1], ptr(dst), stream_ptr()),
           "fgc_scatter_add_rows")
     return dst
+
+
+def vertex_update(x, normals, e_map, v_e_map, iters, lmbd=1.0 / 18):
+    """update_position2 (train.py:1467-1557) on [V,3] positions; e_map int32 [E,4], v_e_map int32 [V,max_edges]."""
+    _req_cuda(x, normals, e_map, v_e_map)
+    x, normals = _f32c(x), _f32c(normals)
+    e_map = e_map.to(torch.int32).contiguous()
+    v_e_map = v_e_map.to(torch.int32).contiguous()
+    out, tmp = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().fgc_vertex_update(ptr(x), ptr(out), ptr(tmp), x.shape[0], ptr(normals), normals.shape[0],
+                                       ptr(e_map), e_map.shape[0], ptr(v_e_map), v_e_map.shape[1], int(iters),
+                                       float(lmbd), stream_ptr()), "fgc_vertex_update")
+    return out

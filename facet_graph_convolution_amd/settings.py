@@ -6,3 +6,4 @@ MAX_PATCH_SIZE = 20000      # settings.py:20 (reference only; meshes are kept wh
 MIN_PATCH_SIZE = 2000       # settings.py:22
 SAVEITER = 5000             # settings.py:30
 NUM_ITERATIONS = 300000     # settings.py:33
+MAX_EDGES = 20              # dataClasses.py:40 (getEdgeMap(faces0, maxEdges = 20)); train.py:44 reads it off v_e_map

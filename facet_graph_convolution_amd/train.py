@@ -104,9 +104,22 @@ def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device
     return net, lossArray
 
 
-def inferNetOld(inputMesh, net_or_checkpoint, device="cuda"):
-    """train.py:29-144 up to the denoised normals (the vertex update that follows is outside this path).
-    inputMesh: dataClasses.InferenceMesh.  Returns predicted unit normals [F, 3] (numpy) in face order."""
+def update_position2(x, face_normals, edge_map, v_edges, iter_num=20, max_edges=20):
+    """train.py:1467-1557, same argument layout on torch GPU tensors: x [1,V,3], face_normals [1,F,3], edge_map
+    int [1,E,4], v_edges int [1,V,max_edges] (-1 = unused slot); returns the updated positions [1,V,3].
+    lambda = 1/18 as in the reference (:1469)."""
+    from . import ops
+    if v_edges.shape[-1] != max_edges:
+        raise ValueError("v_edges has %d slots per vertex, max_edges says %d" % (v_edges.shape[-1], max_edges))
+    out = ops.vertex_update(x.reshape(-1, 3), face_normals.reshape(-1, 3), edge_map.reshape(-1, 4),
+                            v_edges.reshape(-1, max_edges), iter_num)
+    return out.unsqueeze(0)
+
+
+def inferNetOld(inputMesh, net_or_checkpoint, device="cuda", update_vertices=False):
+    """train.py:29-144.  inputMesh: dataClasses.InferenceMesh.  Returns the predicted unit normals [F, 3] (numpy, face
+    order); with update_vertices=True the reference's full return value (outPoints [V,3], predicted_normals): the
+    vertex positions after 60 iterations of update_position2 on those normals (train.py:129-139)."""
     if isinstance(net_or_checkpoint, FacetDenoiser):
         net = net_or_checkpoint
     else:
@@ -117,5 +130,15 @@ def inferNetOld(inputMesh, net_or_checkpoint, device="cuda"):
         net.bind_mesh(inputMesh.in_list[i], inputMesh.adj_list[i])
         pred = net.infer_normals(inputMesh.permutations[i], inputMesh.num_faces[i])
         out = pred if out is None else out
+    if update_vertices:
+        if getattr(inputMesh, "edge_map", None) is None:
+            raise RuntimeError("the mesh has a vertex with more than MAX_EDGES edges: no edge tables, no vertex update")
+        dev = out.device
+        xp = torch.as_tensor(inputMesh.vertices, dtype=torch.float32, device=dev)
+        pts = update_position2(xp, out.unsqueeze(0), torch.as_tensor(inputMesh.edge_map, device=dev),
+                               torch.as_tensor(inputMesh.v_e_map, device=dev), iter_num=60,
+                               max_edges=inputMesh.v_e_map.shape[2])
+        torch.cuda.synchronize()
+        return pts[0].cpu().numpy(), out.cpu().numpy()
     torch.cuda.synchronize()
     return out.cpu().numpy()

@@ -88,6 +88,21 @@ def getFacesLargeAdj(faces, K):
     return adj
 
 
+def getEdgeMap(faces, maxEdges=50):
+    """utils.py:91-183: (e_map [E,4] = [v1, v2, f1, f2 or -1], v_e_map [V, maxEdges] edge ids per vertex, -1 padded),
+    bit-exact (same visiting order), natively."""
+    from . import _lib
+    import ctypes as C
+    F = _faces_u32(faces)
+    nv = int(F.max()) + 1
+    e_map = np.empty((F.shape[0] * 3, 4), dtype=np.int32)
+    v_e_map = np.empty((nv, maxEdges), dtype=np.int32)
+    ne = C.c_int32(0)
+    _lib.check(_lib.lib().fgc_edge_map(F.ctypes.data, F.shape[0], nv, int(maxEdges), e_map.ctypes.data, C.byref(ne),
+                                       v_e_map.ctypes.data), "fgc_edge_map")
+    return e_map[:ne.value].copy(), v_e_map
+
+
 def coarsen_klists(adj, pos, normals, levels=4, K=23, seed=0, parents=None, keep=(0, 2, 4)):
     """listToSparseWNormals + coarsen + sparseToList (utils.py:1753-1827, lib/coarsening.py:5-31).
 

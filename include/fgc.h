@@ -104,6 +104,13 @@ int fgc_hierarchy_parents(const fgc_hierarchy* h, int32_t level, int32_t* out_h)
  * utils.py:1799-1827); *saturated = 1 if a row had more than K-1 neighbours. */
 int fgc_hierarchy_klist(const fgc_hierarchy* h, int32_t level, int32_t K, int32_t* adj_h, int32_t* saturated);
 
+/* Edge map = getEdgeMap (utils.py:91-183), host.  e_map_h [3*nf, 4] receives [v1, v2, f1, f2] per edge (f2 = -1
+ * on a boundary), *n_edges the number of edges written; v_e_map_h [nv, max_edges] the edge ids incident to every
+ * vertex in creation order, -1 padded.  Same visiting order as the reference, so both tables are bit-identical to
+ * its output.  -EINVAL if a vertex has more than max_edges edges (the reference raises IndexError there). */
+int fgc_edge_map(const uint32_t* faces_h, int32_t nf, int32_t nv, int32_t max_edges, int32_t* e_map_h,
+                 int32_t* n_edges, int32_t* v_e_map_h);
+
 /* ------------------------------------------------------------------------------------
  * Graph convolution  (replaces custom_conv2d, model.py:427-504, invariance-off branch,
  * with get_weight_assigments model.py:74-95 and get_patches model.py:380-405 fused in)
@@ -280,6 +287,15 @@ int fgc_infer_epilogue(const float* n_conv, const int32_t* perm, int32_t num_fac
 /* halo pack / unpack for facet sharding: dst[i] = src[idx[i]] rows of width c */
 int fgc_gather_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst, void* stream);
 int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst, void* stream);
+
+/* Vertex update from denoised normals = update_position2 (train.py:1467-1557; called with 60 iterations and
+ * lambda = 1/18 by inferNetOld, train.py:129-139).  Jacobi iterations
+ *   x_i <- x_i + lambda * sum_{edges e = (i,j,f1,f2) of i} sum_{f in {f1,f2}} n_f (n_f . (x_j - x_i))
+ * x [nv,3] input positions, normals [nf,3], e_map [ne,4], v_e_map [nv,max_edges] (device copies of fgc_edge_map's
+ * output).  x_out [nv,3] receives the result, tmp [nv,3] is scratch; x may alias neither.  iters >= 0. */
+int fgc_vertex_update(const float* x, float* x_out, float* tmp, int32_t nv, const float* normals, int32_t nf,
+                      const int32_t* e_map, int32_t ne, const int32_t* v_e_map, int32_t max_edges, int32_t iters,
+                      float lambda, void* stream);
 
 #ifdef __cplusplus
 }

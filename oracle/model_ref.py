@@ -251,3 +251,27 @@ def infer_epilogue(n_conv, permutations, num_faces):
         norms = torch.sqrt((outN * outN).sum(1, keepdim=True)) + 0.00000001
         outN = outN * (1 / norms)
     return outN
+
+
+def update_position2(x, face_normals, edge_map, v_edges, iter_num=20, lmbd=1.0 / 18):
+    """ref: train.py:1467-1557.  x [V,3], face_normals [F,3], edge_map [E,4] = [v1,v2,f1,f2 (-1: none)],
+    v_edges [V,max_edges] (-1: unused).  Per iteration, simultaneously for every vertex i,
+        x_i += lmbd * sum over its edges e = (v1, v2, f1, f2) and both faces f of  n_f (n_f . (x_v1 - x_i))
+                                                                                 + n_f (n_f . (x_v2 - x_i))
+    (the endpoint that is i itself contributes zero; missing faces and unused slots have zero normals)."""
+    x = torch.as_tensor(x)
+    dt = x.dtype
+    fn = torch.cat([torch.zeros(1, 3, dtype=dt), torch.as_tensor(face_normals).to(dt)], 0)      # :1490
+    em = torch.as_tensor(np.asarray(edge_map)).long() + torch.tensor([0, 0, 1, 1])                # :1482-1483
+    em = torch.cat([torch.zeros(1, 4, dtype=torch.long), em], 0)                                  # :1486-1487
+    ne = em[torch.as_tensor(np.asarray(v_edges)).long() + 1]                                      # [V, E, 4]  :1479,1494
+    nrm = fn[ne[:, :, 2:]]                                                                        # [V, E, 2, 3]
+    nrm4 = torch.cat([nrm, nrm], 2)                                                               # rows n1 n2 n1 n2  :1508
+    for _ in range(iter_num):
+        pairs = x[ne[:, :, :2]]                                                                   # [V, E, 2, 3]
+        d = pairs - x[:, None, None, :]                                                           # :1530
+        d4 = torch.stack([d[:, :, 0], d[:, :, 0], d[:, :, 1], d[:, :, 1]], 2)                     # rows d0 d0 d1 d1  :1533-1536
+        dp = (d4 * nrm4).sum(-1, keepdim=True)                                                    # :1539
+        upd = (nrm4 * dp).sum(2).sum(1)                                                           # :1545-1550
+        x = x + lmbd * upd
+    return x

@@ -172,3 +172,44 @@ def inv_perm(perm):
     for i, p in enumerate(perm):
         inverse[p] = i
     return np.array(inverse)
+
+
+def edge_map(faces, max_edges=20):
+    """ref: utils.py:91-183 (getEdgeMap).  Returns (e_map [E,4] = [v1, v2, f1, f2 or -1], v_e_map [V, max_edges]
+    edge ids per vertex, -1 padded).  Faces are visited in order; per face the edges (v1,v2), (v1,v3) are looked up
+    among v1's edges and (v2,v3) among v2's; a found edge gets the face as its second face (overwriting a previous
+    one on non-manifold input, as the reference does), a missing edge is created in the order 12, 13, 23."""
+    faces = np.asarray(faces).astype(np.int64)
+    fnum = faces.shape[0]
+    e_map = -np.ones((fnum * 3, 4), dtype=np.int32)
+    vnum = int(faces.max()) + 1
+    v_e_map = -np.ones((vnum, max_edges), dtype=np.int32)
+    cnt = np.zeros(vnum, dtype=np.int64)
+    eind = 0
+    for f in range(fnum):
+        v1, v2, v3 = (int(t) for t in faces[f])
+        found = {"12": False, "13": False, "23": False}
+        for ne in range(cnt[v1]):
+            ce = v_e_map[v1, ne]
+            if e_map[ce, 0] == v2 or e_map[ce, 1] == v2:
+                found["12"] = True
+                e_map[ce, 3] = f
+            if e_map[ce, 0] == v3 or e_map[ce, 1] == v3:
+                found["13"] = True
+                e_map[ce, 3] = f
+        for ne in range(cnt[v2]):
+            ce = v_e_map[v2, ne]
+            if e_map[ce, 0] == v3 or e_map[ce, 1] == v3:
+                found["23"] = True
+                e_map[ce, 3] = f
+        for key, (a, b) in (("12", (v1, v2)), ("13", (v1, v3)), ("23", (v2, v3))):
+            if found[key]:
+                continue
+            e_map[eind, 0], e_map[eind, 1], e_map[eind, 2] = a, b, f
+            for v in (a, b):
+                if cnt[v] >= max_edges:
+                    raise IndexError("vertex %d has more than %d edges (utils.py:103 sizes the table)" % (v, max_edges))
+                v_e_map[v, cnt[v]] = eind
+                cnt[v] += 1
+            eind += 1
+    return e_map[:eind], v_e_map

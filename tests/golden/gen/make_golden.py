@@ -260,6 +260,21 @@ def infer_case(tag, x_np, adjs_np, ds, seed):
     save("infer_%s%s.npz" % (tag, "_f64" if F64 else ""), n_conv=n_conv.detach().numpy(), predicted_normals=pred)
 
 
+def vertex_case(tag, V_noisy, F, normals):
+    """getEdgeMap (utils.py:91-183) + update_position2 (train.py:1467-1557), as called by inferNetOld
+    (train.py:129-139: 60 iterations, MAX_EDGES = 20 slots per vertex).  Also an open mesh variant (boundary edges)."""
+    e_map, v_e_map = ref_utils.getEdgeMap(F, maxEdges=20)
+    x = torch.tensor(V_noisy.astype(np.float32), dtype=FDT)[None]
+    fn = torch.tensor(normals.astype(np.float32), dtype=FDT)[None]
+    em = torch.tensor(e_map[None].astype(np.int32))
+    vem = torch.tensor(v_e_map[None].astype(np.int32))
+    out = {}
+    for it in (1, 60):
+        out["x_%d" % it] = ref_train.update_position2(x, fn, em, vem, iter_num=it, max_edges=20).detach().numpy()[0]
+    save("vertex_%s%s.npz" % (tag, "_f64" if F64 else ""), verts=V_noisy.astype(np.float32), faces=F.astype(np.int32),
+         normals=normals.astype(np.float32), edge_map=e_map, v_e_map=v_e_map, **out)
+
+
 def random_klist(n, K, seed, zero_rows=(3,), dup=True):
     """Random one-indexed K-list with self slot, ragged degrees, duplicates and an isolated (all-zero) row."""
     rs = np.random.RandomState(seed)
@@ -318,6 +333,17 @@ def main():
             net_case("torus640", xt, adjst, gtt, seed=1, multi_scale=False)
     if want("infer") and not F64:
         infer_case("ico3", x, adjs, ds, seed=0)
+    if want("vertex"):
+        # closed mesh: noisy icosphere, target normals = normals of the clean sphere
+        Vn = add_noise(V, F)
+        vertex_case("ico3", Vn, F, ref_utils.computeFacesNormals(V, F))
+        # open mesh (boundary edges have one face): the first 450 faces of the torus grid, vertices re-indexed
+        # (getEdgeMap sizes its table by max(faces) + 1, i.e. assumes every vertex is used)
+        Vt2, Ft2 = torus(20, 16)
+        used, Fo = np.unique(Ft2[:450], return_inverse=True)
+        Fo = Fo.reshape(-1, 3).astype(Ft2.dtype)
+        Vo = Vt2[used]
+        vertex_case("torus_open", add_noise(Vo, Fo), Fo, ref_utils.computeFacesNormals(Vo, Fo))
 
 
 if __name__ == "__main__":

@@ -65,6 +65,12 @@ def test_train_and_infer_drivers(tmp_path):
     im.addMesh(add_noise(V, F), F, seed=0)
     pred = inferNetOld(im, net)
     assert pred.shape == (1280, 3) and np.abs(np.linalg.norm(pred, axis=1) - 1).max() < 1e-5
+    # the reference's full return value: vertex positions after update_position2 on the predicted normals
+    pts, pred2 = inferNetOld(im, net, update_vertices=True)
+    assert pts.shape == V.shape and np.array_equal(pred2, pred) and np.isfinite(pts).all()
+    from oracle import model_ref as R
+    ref = R.update_position2(torch.tensor(im.vertices[0]), pred, im.edge_map[0], im.v_e_map[0], 60).numpy()
+    np.testing.assert_allclose(pts, ref, rtol=0, atol=2e-6)
     net2 = FacetDenoiser("cuda:0")
     assert load_checkpoint(os.path.join(str(tmp_path), "t.pt"), net2) == 110
     assert torch.equal(net2.params.theta, net.params.theta)

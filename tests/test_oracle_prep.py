@@ -45,3 +45,27 @@ def test_native_preprocessing_matches_oracle_on_other_meshes(mesh):
     for l in range(3):
         assert np.array_equal(klists[l], m.adj_list[0][l][0])
     assert np.array_equal(O.inv_perm(new_to_old), m.permutations[0])
+
+
+@pytest.mark.parametrize("tag", ["ico3", "torus_open"])
+def test_edge_map_matches_reference(golden_dir, tag):
+    """getEdgeMap (utils.py:91-183): the restatement reproduces the reference's tables (closed and open mesh)."""
+    z = np.load(os.path.join(golden_dir, "vertex_%s.npz" % tag))
+    em, vem = O.edge_map(z["faces"], 20)
+    assert np.array_equal(em, z["edge_map"]) and np.array_equal(vem, z["v_e_map"])
+    if tag == "torus_open":
+        assert (em[:, 3] < 0).sum() > 0     # boundary edges exist in this fixture
+
+
+@pytest.mark.parametrize("tag", ["ico3", "torus_open"])
+def test_vertex_update_restatement_matches_reference(golden_dir, tag):
+    """update_position2 (train.py:1467-1557) after 1 and 60 iterations, fp32 and against the float64 run."""
+    import torch
+    from oracle import model_ref as R
+    z = np.load(os.path.join(golden_dir, "vertex_%s.npz" % tag))
+    z64 = np.load(os.path.join(golden_dir, "vertex_%s_f64.npz" % tag))
+    for it in (1, 60):
+        x = R.update_position2(torch.tensor(z["verts"]), z["normals"], z["edge_map"], z["v_e_map"], it).numpy()
+        np.testing.assert_allclose(x, z["x_%d" % it], rtol=0, atol=1e-6)
+    x64 = R.update_position2(torch.tensor(z["verts"]).double(), z["normals"], z["edge_map"], z["v_e_map"], 60).numpy()
+    np.testing.assert_allclose(x64, z64["x_60"], rtol=0, atol=1e-12)
