@@ -895,6 +895,108 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
 }
 
+// Streaming form of gemm_tn_kernel for 16-byte aligned operands whose widths are multiples of 4 (every layer but
+// conv1).  Same tiling, same summation order, bit-identical results; what differs is how memory is asked for:
+//   * loads are UNCONDITIONAL (row and column indices clamped into the operands, out-of-range rows zeroed by a
+//     select on the A fragment): no exec-masked branch around a load, so hipcc counts its s_waitcnt instead of
+//     draining everything with vmcnt(0) in front of every MFMA group;
+//   * four operand register sets with fixed roles (loop unrolled by 4): each load has three MFMA groups = 48
+//     matrix instructions to land;
+//   * the 4-wave sum goes through 2 x 16 KB of LDS instead of 4, so four workgroups are resident per CU.
+__global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __restrict__ A, int lda, int P,
+                                                                const float* __restrict__ x0,
+                                                                const float* __restrict__ x1, int c0, int c1, int shift,
+                                                                int rows, int rows_per_split, float* __restrict__ slab) {
+    __shared__ float red[2][64][65];
+    const int Q = c0 + c1;
+    const int npt = (P + 63) >> 6;
+    const int pt = blockIdx.x % npt, qt = blockIdx.x / npt;
+    const int p0 = pt * 64, q0 = qt * 64;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_end = min(rows, r_begin + rows_per_split);
+    const int nsteps = (r_end - r_begin + 3) >> 2;
+    // column quads of this lane, clamped into the operands (results of clamped columns are never stored)
+    const int pc = min(p0 + 4 * lr, P - 4);
+    const int qc = min(q0 + 4 * lr, Q - 4);
+    const float* bsrc = qc < c0 ? x0 + qc : x1 + (qc - c0);
+    const int bld = qc < c0 ? c0 : c1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A load only requests memory; the zeroing of out-of-range rows happens where the fragment is consumed (a select
+    // right behind the load would make the compiler wait for it on the spot)
+    auto ld = [&](int step, f32x4& a, f32x4& b, int& row) {
+        row = r_begin + 4 * step + lq;
+        const int rc = min(row, r_end - 1);
+        a = *reinterpret_cast<const f32x4*>(A + (size_t)rc * lda + pc);
+        b = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(rc >> shift) * bld);
+    };
+    auto mm = [&](f32x4 a, const f32x4& b, int row) {
+        if (row >= r_end) a = f32x4{0.f, 0.f, 0.f, 0.f};   // a select, not a branch
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    f32x4 a0, b0, a1, b1, a2, b2, a3, b3;
+    int r0, r1, r2, r3;
+    ld(wave, a0, b0, r0);
+    ld(wave + 4, a1, b1, r1);
+    ld(wave + 8, a2, b2, r2);
+    ld(wave + 12, a3, b3, r3);
+    // sched_barrier: keep the program order "16 MFMAs, then the refill of the set they consumed" (left alone the
+    // scheduler sinks every refill to just in front of its use and the prefetch distance collapses to zero)
+#define FGC_TN_STEP(A_, B_, R_, NEXT_)          \
+    mm(A_, B_, R_);                             \
+    __builtin_amdgcn_sched_barrier(0);          \
+    ld(NEXT_, A_, B_, R_);                      \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = wave; s < nsteps; s += 16) {   // steps past the end load a clamped row and multiply by zero
+        FGC_TN_STEP(a0, b0, r0, s + 16)
+        FGC_TN_STEP(a1, b1, r1, s + 20)
+        FGC_TN_STEP(a2, b2, r2, s + 24)
+        FGC_TN_STEP(a3, b3, r3, s + 28)
+    }
+#undef FGC_TN_STEP
+    // (w0 + w1) + (w2 + w3), as gemm_tn_kernel sums them.  C layout of acc[i][j]: column lr -> q = 4*lr + j,
+    // row lq*4+reg -> p = 4*(lq*4+reg) + i
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) red[slot][4 * (lq * 4 + t) + i][4 * lr + j] = acc[i][j][t];
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[i][j][t] += red[slot][4 * (lq * 4 + t) + i][4 * lr + j];
+    };
+    if (wave == 1) put(0);
+    if (wave == 3) put(1);
+    __syncthreads();
+    if (wave == 0) add(0);
+    if (wave == 2) add(1);
+    __syncthreads();
+    if (wave == 0) put(0);
+    if (wave == 2) put(1);
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.y * P * Q;
+    for (int t = tid; t < 64 * 64; t += 256) {
+        const int pp = t >> 6, qq = t & 63;
+        if (p0 + pp < P && q0 + qq < Q) out[(size_t)(p0 + pp) * Q + q0 + qq] = red[0][pp][qq] + red[1][pp][qq];
+    }
+}
+
 static int tn_splits(int P, int Q, int rows) {
     const int tiles = cdiv(P, 64) * cdiv(Q, 64);
     int s = 768 / tiles;
@@ -1106,7 +1208,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;
         int ns = cdiv(d->n, rps);
         const dim3 g1(cdiv(P, 64) * cdiv(cin, 64), ns);
-        if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+        const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
+        if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel, g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+                                  d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        else if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
                            d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<false>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
                         d->c0, d->c1, d->shift, d->n, rps, w.slab);
@@ -1115,7 +1220,9 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         rps = cdiv(cdiv(d->n, w.splitUV), 4) * 4;
         ns = cdiv(d->n, rps);
         const dim3 g2(cdiv(cin, 64), ns);
-        if (v4) FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<true>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
+        if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:duv", st, gemm_tn_stream_kernel, g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
+                                  d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
+        else if (v4) FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<true>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
                            d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
         else FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<false>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
                         d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
