@@ -24,10 +24,11 @@ __global__ void mlp_pack_kernel(const float* __restrict__ W1, float* __restrict_
     }
 }
 
+template <int T = MLP_T>
 __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int n, int cin, int kpad, int xs, int row0,
                                             float* xt) {
-    // xt [MLP_T][xs]; zero padded rows / channels
-    for (int t = threadIdx.x; t < MLP_T * kpad; t += MLP_THREADS) {
+    // xt [T][xs]; zero padded rows / channels
+    for (int t = threadIdx.x; t < T * kpad; t += MLP_THREADS) {
         const int r = t / kpad, c = t % kpad;
         const int row = row0 + r;
         xt[r * xs + c] = (row < n && c < cin) ? x[(size_t)row * cin + c] : 0.f;
@@ -35,15 +36,16 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int n, 
 }
 
 // hidden pre-activation slab for column tile ct: h[rt] (C layout: col = lane&15, row = rt*16 + (lane>>4)*4 + reg)
+template <int RT>
 __device__ __forceinline__ void hidden_slab(const float* xt, int xs, int kg, const f32x4* __restrict__ Wp4, int hidden,
-                                            int ct, f32x4 (&h)[MLP_RT]) {
+                                            int ct, f32x4 (&h)[RT]) {
     const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < MLP_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < kg; ++g) {
         const f32x4 b = Wp4[(size_t)(g * 4 + lq) * hidden + ct * 16 + lr];
 #pragma unroll
-        for (int r = 0; r < MLP_RT; ++r) {
+        for (int r = 0; r < RT; ++r) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(xt + (r * 16 + lr) * xs + g * 16 + lq * 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) h[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], h[r], 0, 0, 0);
@@ -153,8 +155,11 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 // MLP_BWD_MT = cin tiles of 16, MLP_BWD_CTW = column tiles per wave per workgroup (hcw = 4 waves * CTW * 16 columns).
 // <2,4> serves the 32-wide head of the network; <4,2> and <8,1> the 64/128-wide multi-scale heads (model.py:894-899,
 // 915-920), trading column width for the wider dx / dW1 accumulators.
+constexpr int BWD_T = 32;         // rows per tile of the backward kernel
+constexpr int BWD_RT = BWD_T / 16;
+
 template <int MLP_BWD_MT, int MLP_BWD_CTW>
-__global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int n, int cin, int kpad, int hidden, int cout,
     const float* __restrict__ Wp, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, float alpha, float* __restrict__ dx_slab /* [gridDim.y][n][cin] */,
@@ -162,15 +167,15 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
     float* __restrict__ dW2_slab /* [gridDim.x][hidden][4] */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int xs = kpad + 8;
-    float* xt = reinterpret_cast<float*>(smem_raw);                // [MLP_T][xs]
-    float* dyt = xt + MLP_T * xs;                                   // [MLP_T][4]
-    float* dht = dyt + MLP_T * 4;                                   // [4 waves][MLP_T][24]  (stride 24 == 8 mod 16)
-    float* dxp = dht + 4 * MLP_T * 24;                              // [4 waves][MLP_T][kpad+1]  ([1][..] when MT > 2)
+    float* xt = reinterpret_cast<float*>(smem_raw);                // [BWD_T][xs]
+    float* dyt = xt + BWD_T * xs;                                   // [BWD_T][4]
+    float* dht = dyt + BWD_T * 4;                                   // [4 waves][BWD_T][24]  (stride 24 == 8 mod 16)
+    float* dxp = dht + 4 * BWD_T * 24;                              // [4 waves][BWD_T][kpad+1]  ([1][..] when MT > 2)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int kg = kpad >> 4;
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(Wp);
     const int hc0 = blockIdx.y * (4 * MLP_BWD_CTW * 16);
-    const int ntiles = (n + MLP_T - 1) / MLP_T;
+    const int ntiles = (n + BWD_T - 1) / BWD_T;
 
     f32x4 dW1acc[MLP_BWD_CTW][MLP_BWD_MT];
     float dW2acc[MLP_BWD_CTW][MLP_COUT_MAX];
@@ -185,33 +190,37 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row0 = tile * MLP_T;
+        const int row0 = tile * BWD_T;
         __syncthreads();
-        load_x_tile(x, n, cin, kpad, xs, row0, xt);
-        for (int t = threadIdx.x; t < MLP_T * 4; t += MLP_THREADS) {
+        load_x_tile<BWD_T>(x, n, cin, kpad, xs, row0, xt);
+        for (int t = threadIdx.x; t < BWD_T * 4; t += MLP_THREADS) {
             const int r = t >> 2, o = t & 3;
             dyt[t] = (row0 + r < n && o < cout) ? dy[(size_t)(row0 + r) * cout + o] : 0.f;
         }
         __syncthreads();
-        f32x4 dxacc[MLP_RT][MLP_BWD_MT];
+        f32x4 dxacc[BWD_RT][MLP_BWD_MT];
 #pragma unroll
-        for (int r = 0; r < MLP_RT; ++r)
+        for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
             for (int m = 0; m < MLP_BWD_MT; ++m) dxacc[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
         for (int c = 0; c < MLP_BWD_CTW; ++c) {
+            // one column tile at a time: without this fence the scheduler interleaves the unrolled iterations to
+            // overlap their loads and the live fragments of all of them push the kernel past 256 registers
+            // (384 = one wave per SIMD, every memory wait exposed)
+            __builtin_amdgcn_sched_barrier(0);
             const int ct = (hc0 >> 4) + wave * MLP_BWD_CTW + c;
             const int col = ct * 16 + lr;
-            f32x4 h[MLP_RT];
+            f32x4 h[BWD_RT];
             hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
             const float bb = b1[col];
             float w2[MLP_COUT_MAX];
 #pragma unroll
             for (int o = 0; o < MLP_COUT_MAX; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
-            f32x4 dh[MLP_RT];
+            f32x4 dh[BWD_RT];
 #pragma unroll
-            for (int r = 0; r < MLP_RT; ++r)
+            for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int rr = r * 16 + lq * 4 + t;
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
                 }
             // dW1[cin tile m][col] += sum_rows x[row][cm] * dh[row][col]  (K = rows; dh regs are the B fragment)
 #pragma unroll
-            for (int r = 0; r < MLP_RT; ++r)
+            for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int rr = r * 16 + lq * 4 + t;
@@ -243,9 +252,9 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
                     }
                 }
             // dx += dh[T x 16] * W1^T[16 x cin]: transpose dh through LDS into the A-fragment layout
-            float* dhw = dht + wave * MLP_T * 24;
+            float* dhw = dht + wave * BWD_T * 24;
 #pragma unroll
-            for (int r = 0; r < MLP_RT; ++r)
+            for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dhw[(r * 16 + lq * 4 + t) * 24 + lr] = dh[r][t];
             // same wave wrote and reads: LDS ops of one wave are ordered; the compiler inserts the lgkmcnt wait
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
                 f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (cc < cin) b = *reinterpret_cast<const f32x4*>(W1 + (size_t)cc * hidden + ct * 16 + lq * 4);
 #pragma unroll
-                for (int r = 0; r < MLP_RT; ++r) {
+                for (int r = 0; r < BWD_RT; ++r) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(dhw + (r * 16 + lr) * 24 + lq * 4);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -267,19 +276,19 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
         // reduce dx over the 4 waves (fixed order) and write this hidden-range's slab
         const int dxs = kpad + 1;
         if constexpr (MLP_BWD_MT <= 2) {
-            float* dxw = dxp + wave * MLP_T * dxs;
+            float* dxw = dxp + wave * BWD_T * dxs;
 #pragma unroll
-            for (int r = 0; r < MLP_RT; ++r)
+            for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
                 for (int m = 0; m < MLP_BWD_MT; ++m)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dxw[(r * 16 + lq * 4 + t) * dxs + m * 16 + lr] = dxacc[r][m][t];
             __syncthreads();
-            for (int t = threadIdx.x; t < MLP_T * cin; t += MLP_THREADS) {
+            for (int t = threadIdx.x; t < BWD_T * cin; t += MLP_THREADS) {
                 const int r = t / cin, c = t % cin;
                 if (row0 + r < n) {
-                    const float v = (dxp[(0 * MLP_T + r) * dxs + c] + dxp[(1 * MLP_T + r) * dxs + c]) +
-                                    (dxp[(2 * MLP_T + r) * dxs + c] + dxp[(3 * MLP_T + r) * dxs + c]);
+                    const float v = (dxp[(0 * BWD_T + r) * dxs + c] + dxp[(1 * BWD_T + r) * dxs + c]) +
+                                    (dxp[(2 * BWD_T + r) * dxs + c] + dxp[(3 * BWD_T + r) * dxs + c]);
                     dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = v;
                 }
             }
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
             for (int w = 0; w < 4; ++w) {
                 if (wave == w) {
 #pragma unroll
-                    for (int r = 0; r < MLP_RT; ++r)
+                    for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
                         for (int m = 0; m < MLP_BWD_MT; ++m)
 #pragma unroll
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_bwd_kernel(
                 }
                 __syncthreads();
             }
-            for (int t = threadIdx.x; t < MLP_T * cin; t += MLP_THREADS) {
+            for (int t = threadIdx.x; t < BWD_T * cin; t += MLP_THREADS) {
                 const int r = t / cin, c = t % cin;
                 if (row0 + r < n) dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = dxp[r * dxs + c];
             }
@@ -354,7 +363,7 @@ static int mlp_bwd_ctw(int cin) { return cin <= 32 ? 4 : (cin <= 64 ? 2 : 1); } 
 // the backward kernel's k extent is its template width (16 * MT = 128 / CTW): narrower inputs are zero padded up to it
 static int mlp_bwd_kpad(int cin) { return 128 / mlp_bwd_ctw(cin); }
 static int mlp_bwd_gx(int n) {
-    const int ntiles = cdiv(n, MLP_T);
+    const int ntiles = cdiv(n, BWD_T);
     return ntiles < 128 ? ntiles : 128;
 }
 
@@ -434,7 +443,7 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
 
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
-    const size_t smem = (size_t)(MLP_T * (kpad + 8) + MLP_T * 4 + 4 * MLP_T * 24 + (ctw == 4 ? 4 : 1) * MLP_T * (kpad + 1)) * 4;
+    const size_t smem = (size_t)(BWD_T * (kpad + 8) + BWD_T * 4 + 4 * BWD_T * 24 + (ctw == 4 ? 4 : 1) * BWD_T * (kpad + 1)) * 4;
 #define FGC_MLP_BWD_LAUNCH(MT, CTW)                                                                                       \
     do {                                                                                                                  \
         hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
