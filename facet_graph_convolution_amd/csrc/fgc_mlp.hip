@@ -6,7 +6,10 @@
 
 namespace fgc {
 
-constexpr int MLP_T = 64;          // rows per tile
+#ifndef FGC_MLP_T
+#define FGC_MLP_T 64
+#endif
+constexpr int MLP_T = FGC_MLP_T;   // rows per tile (forward kernel)
 constexpr int MLP_RT = MLP_T / 16;
 constexpr int MLP_COUT_MAX = 4;
 constexpr int MLP_THREADS = 256;
@@ -44,12 +47,15 @@ __device__ __forceinline__ void hidden_slab(const float* xt, int xs, int kg, con
     for (int r = 0; r < RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < kg; ++g) {
         const f32x4 b = Wp4[(size_t)(g * 4 + lq) * hidden + ct * 16 + lr];
+        f32x4 a[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xt + (r * 16 + lr) * xs + g * 16 + lq * 4);
+        for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const f32x4*>(xt + (r * 16 + lr) * xs + g * 16 + lq * 4);
+        // k outer, row tile inner: consecutive MFMAs write different accumulators (a dependent 16x16x4 f32 MFMA
+        // needs 40 cycles, an independent one issues every 32)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) h[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], h[r], 0, 0, 0);
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) h[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], h[r], 0, 0, 0);
     }
 }
 
@@ -155,11 +161,17 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 // MLP_BWD_MT = cin tiles of 16, MLP_BWD_CTW = column tiles per wave per workgroup (hcw = 4 waves * CTW * 16 columns).
 // <2,4> serves the 32-wide head of the network; <4,2> and <8,1> the 64/128-wide multi-scale heads (model.py:894-899,
 // 915-920), trading column width for the wider dx / dW1 accumulators.
-constexpr int BWD_T = 32;         // rows per tile of the backward kernel
+#ifndef FGC_MLP_BWD_T
+#define FGC_MLP_BWD_T 32
+#endif
+#ifndef FGC_MLP_BWD_WAVES
+#define FGC_MLP_BWD_WAVES 2
+#endif
+constexpr int BWD_T = FGC_MLP_BWD_T;   // rows per tile of the backward kernel
 constexpr int BWD_RT = BWD_T / 16;
 
 template <int MLP_BWD_MT, int MLP_BWD_CTW>
-__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_bwd_kernel(
+__global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int n, int cin, int kpad, int hidden, int cout,
     const float* __restrict__ Wp, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, float alpha, float* __restrict__ dx_slab /* [gridDim.y][n][cin] */,
@@ -264,13 +276,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_bwd_kernel(
                 const int cc = m * 16 + lr;
                 f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (cc < cin) b = *reinterpret_cast<const f32x4*>(W1 + (size_t)cc * hidden + ct * 16 + lq * 4);
+                f32x4 a[BWD_RT];
 #pragma unroll
-                for (int r = 0; r < BWD_RT; ++r) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(dhw + (r * 16 + lr) * 24 + lq * 4);
+                for (int r = 0; r < BWD_RT; ++r) a[r] = *reinterpret_cast<const f32x4*>(dhw + (r * 16 + lr) * 24 + lq * 4);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        dxacc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], dxacc[r][m], 0, 0, 0);
-                }
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < BWD_RT; ++r)
+                        dxacc[r][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], dxacc[r][m], 0, 0, 0);
             }
         }
         // reduce dx over the 4 waves (fixed order) and write this hidden-range's slab
