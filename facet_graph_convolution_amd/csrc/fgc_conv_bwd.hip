@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "fgc_conv_pc.h"
+#include "fgc_conv_narrow.h"
 #include "fgc_reduce.h"
 
 namespace fgc {
@@ -997,6 +998,15 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     }
 }
 
+int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,
+                          int rows_per_split, int nsplits, float* slab, hipStream_t st) {
+    const dim3 grid(cdiv(P, 64) * cdiv(c0, 64), nsplits);
+    FGC_LAUNCH(tag, st, gemm_tn_stream_kernel, grid, dim3(256), 0, A, lda, P, x0, (const float*)nullptr, c0, 0, 0, rows,
+               rows_per_split, slab);
+    FGC_CHECK_LAUNCH("gemm_tn_stream_kernel");
+    return FGC_OK;
+}
+
 static int tn_splits(int P, int Q, int rows) {
     const int tiles = cdiv(P, 64) * cdiv(Q, 64);
     int s = 768 / tiles;
@@ -1014,6 +1024,7 @@ struct BwdWorkspace {
     float* slab;      // gemm_tn partials of dW0
     float* slab_uv;   // gemm_tn partials of [du; dv]
     float* rtmp;      // scratch of the fixed-order reductions
+    float* narrow;    // first-layer path (cin <= 8): z buffer, partial slabs (fgc_conv_narrow.hip)
     size_t bytes;
     int nb_db, rows_per_db;
     int splitW, splitUV;
@@ -1044,6 +1055,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.slab_uv = take((size_t)w.splitUV * 24 * cin);
     w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitUV, (size_t)FGC_M * cin) +
                   reduce_tmp_floats(cdiv(d->n, TILE), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
+    w.narrow = narrow_supported(d) ? take(narrow_bwd_floats(d)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -1121,6 +1133,18 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
                    d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");   // db partials are summed with the other parameter gradients (stage 8)
+    }
+    // first layer over a narrow input (no input gradient wanted): vector-ALU path, no transposed graph, no r buffer
+    if (io->dx0 == nullptr && w.narrow) {
+        if (stages & 2) {
+            rc = narrow_bwd_logits(d, io, w.narrow, st);
+            if (rc) return rc;
+        }
+        if (stages & 8) {
+            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, st);
+            if (rc) return rc;
+        }
+        return FGC_OK;
     }
     // operand packing
     if ((stages & 6) && !(io->flags & FGC_CONV_PACKED)) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "fgc_conv_pc.h"
+#include "fgc_conv_narrow.h"
 
 namespace fgc {
 
@@ -281,7 +282,8 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FGC_CHECK_ARG(d->tile_list == nullptr || (d->n_tiles >= 0 && d->n_tiles <= cdiv(d->n, TILE)),
                   "fgc_conv_fwd: n_tiles=%d outside [0, %d]", d->n_tiles, cdiv(d->n, TILE));
 
-    if (!(d->flags & FGC_CONV_PACKED)) {
+    const bool narrow = narrow_supported(d);   // cin <= 8: vector-ALU kernel, no packed operand (fgc_conv_narrow.hip)
+    if (!narrow && !(d->flags & FGC_CONV_PACKED)) {
         const size_t tot = packed_floats(g);
         FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, d->W0, Wp, cin,
                    d->cout, cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
@@ -301,6 +303,7 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
         FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
     }
     if (d->tile_list && d->n_tiles == 0) return FGC_OK;
+    if (narrow) return launch_narrow_fwd(d, ag, y, y_pool, st);
 
     CoreParams p;
     fill_core_params(p, g, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, d->cout, ag,

@@ -1,0 +1,24 @@
+// Narrow-input graph convolution (cin <= 8): the network's first layer.  See fgc_conv_narrow.hip.
+#pragma once
+#include "fgc_conv_core.h"
+
+namespace fgc {
+
+bool narrow_supported(const fgc_conv_desc* d);
+// forward (after the logit table `ag` has been computed); honours d->tile_list
+int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, hipStream_t st);
+
+// backward of a narrow FIRST layer (io->dx0 == NULL).  `scratch` holds narrow_bwd_floats(d) floats and must survive
+// from the stage-2 call to the stage-8 call.
+int narrow_zld(int cin);
+int narrow_splits(const fgc_conv_desc* d);
+size_t narrow_bwd_floats(const fgc_conv_desc* d);
+int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, hipStream_t st);
+int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
+                      int nb_db, hipStream_t st);
+
+// streaming TN GEMM (fgc_conv_bwd.hip): slab[split][P][c0] = A[rows of the split, P]^T x0[rows of the split, c0]
+int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,
+                          int rows_per_split, int nsplits, float* slab, hipStream_t st);
+
+}  // namespace fgc

@@ -1,0 +1,453 @@
+// Graph convolution over NARROW inputs (cin <= 8, one source, no upsampling): the network's first layer (6 -> 32).
+//
+// The tiled kernels pad every gathered row to 32 channels so that the weight transform fills the matrix cores; with
+// 6 input channels that is 5x wasted MFMA and gather work (conv1 used 13 % of the training step for 1 % of its FLOPs).
+// Here the arithmetic is small enough for the vector ALU and the problem is purely a gather:
+//   forward   one NODE PER LANE: the lane walks its edges (4 at a time: neighbour ids, then their logit and feature
+//             rows, all requested together), keeps z_i[m][c] = sum_k q_ikm x_j[c] (9*cin registers) and applies the
+//             weights from scalar registers (the weight index is wave-uniform, hipcc turns it into s_load + v_fma);
+//             outputs leave through an LDS tile so that rows are written coalesced (+ activation, 4:1 max-pool).
+//   backward  (first layer only: no input gradient wanted)  same walk, per lane: dz_i = W^T s_i, per edge the softmax
+//             backward, da_i, and the outer products that the tiled path gets from two extra kernels and a GEMM:
+//               du = sum_i da_i (x) x_i     dv = sum_i sum_k dl_ik (x) x_j(i,k)     dc = sum_i da_i
+//             block-reduced in a fixed order and written as slabs.  dW0 = sum_i s_i (x) z_i is the only dense
+//             contraction left: z is written out by the forward kernel in "z only" mode and contracted with s by the
+//             streaming TN GEMM.  No transposed graph, no per-edge buffer, no r buffer.
+// Reference: custom_conv2d, model.py:427-504 (forward); its gradient as derived in SURVEY.md Appendix A.
+#include <stdlib.h>
+
+#include "fgc_conv_narrow.h"
+#include "fgc_reduce.h"
+
+namespace fgc {
+
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+constexpr int NB = 256;          // nodes per workgroup (= 8 tiles of 32)
+constexpr int EB_FWD = 4;        // edges requested together (forward)
+constexpr int EB_BWD = 2;        // (backward: twice the per-lane state, half the batch)
+
+struct NarrowFwd {
+    int n;
+    const int* rowptr;
+    const int* col;
+    const float* x;        // [rows, cin]
+    const float* ag;       // [rows, 24]
+    const float* W0;       // [9, cout, cin]
+    const float* bias;
+    int cin, cout, bias_mask, act;
+    float alpha;
+    float* y;
+    float* y_pool;
+    float* z;              // ZONLY: [n, zld], z[i][m * CIN + c]
+    int zld;
+    const int* tile_list;  // 32-row tiles (NULL = all); a workgroup takes 8 consecutive entries
+    int n_tiles;
+};
+
+__device__ __forceinline__ int narrow_node(const int* tile_list, int n_tiles, int n, int& active) {
+    const int t = blockIdx.x * (NB / TILE) + (threadIdx.x >> 5);
+    if (tile_list) {
+        active = t < n_tiles;
+        const int i = (active ? tile_list[t] : 0) * TILE + (threadIdx.x & 31);
+        active = active && i < n;
+        return i;
+    }
+    const int i = t * TILE + (threadIdx.x & 31);
+    active = i < n;
+    return i;
+}
+
+// softmax over the 9 logits a + g
+__device__ __forceinline__ void softmax9(const float (&a)[FGC_M], const float (&g)[FGC_M], float (&q)[FGC_M]) {
+    float mx = a[0] + g[0];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) {
+        q[m] = a[m] + g[m];
+        mx = fmaxf(mx, q[m]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) {
+        q[m] = expf(q[m] - mx);
+        sum += q[m];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) q[m] *= inv;
+}
+
+// rows of EB edges of this lane's node: ids first, then every logit / feature row, so that the two memory round
+// trips of an edge are shared by EB edges.  Slots past the node's last edge repeat it (their weight is dropped by the
+// caller), so every load is unconditional.
+template <int CIN, int EB>
+__device__ __forceinline__ void fetch_edges(const int* __restrict__ col, const float* __restrict__ ag,
+                                            const float* __restrict__ x, int cin, int e, int e1,
+                                            float (&g)[EB][FGC_M], float (&xj)[EB][CIN]) {
+    int j[EB];
+#pragma unroll
+    for (int t = 0; t < EB; ++t) j[t] = col[min(e + t, e1 - 1)];
+#pragma unroll
+    for (int t = 0; t < EB; ++t) {
+        const float* gr = ag + (size_t)j[t] * FGC_AG_LD + 12;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gr + 4);
+        g[t][0] = g0[0]; g[t][1] = g0[1]; g[t][2] = g0[2]; g[t][3] = g0[3];
+        g[t][4] = g1[0]; g[t][5] = g1[1]; g[t][6] = g1[2]; g[t][7] = g1[3];
+        g[t][8] = gr[8];
+        const float* xr = x + (size_t)j[t] * CIN;
+        if (CIN % 2 == 0) {   // rows are 8-byte aligned when the width is even
+#pragma unroll
+            for (int c = 0; c < CIN; c += 2) {
+                const f32x2n v = *reinterpret_cast<const f32x2n*>(xr + c);
+                xj[t][c] = v[0];
+                xj[t][c + 1] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xj[t][c] = xr[c];
+        }
+    }
+}
+
+template <int CIN, bool ZONLY>
+__global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* yt = reinterpret_cast<float*>(smem_raw);   // [NB][cout + 1]
+    int active;
+    const int i = narrow_node(p.tile_list, p.n_tiles, p.n, active);
+    int e0 = 0, e1 = 0;
+    float a[FGC_M];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) a[m] = 0.f;
+    if (active) {
+        e0 = p.rowptr[i];
+        e1 = p.rowptr[i + 1];
+        const float* ar = p.ag + (size_t)i * FGC_AG_LD;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+        a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+        a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+        a[8] = ar[8];
+    }
+    float z[FGC_M][CIN];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) z[m][c] = 0.f;
+    for (int e = e0; e < e1; e += EB_FWD) {
+        float g[EB_FWD][FGC_M], xj[EB_FWD][CIN];
+        fetch_edges<CIN, EB_FWD>(p.col, p.ag, p.x, p.cin, e, e1, g, xj);
+#pragma unroll
+        for (int t = 0; t < EB_FWD; ++t) {
+            float q[FGC_M];
+            softmax9(a, g[t], q);
+            const float w = e + t < e1 ? 1.f : 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                const float qm = q[m] * w;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) z[m][c] = fmaf(qm, xj[t][c], z[m][c]);
+            }
+        }
+    }
+    if (ZONLY) {
+        if (active) {
+            float* zr = p.z + (size_t)i * p.zld;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m)
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) zr[m * CIN + c] = z[m][c];
+            for (int k = FGC_M * CIN; k < p.zld; ++k) zr[k] = 0.f;
+        }
+        return;
+    }
+    // y_i = (1/d) W~ z_i + b [d > 0]; the weight address depends on loop counters only (scalar loads)
+    const int d = e1 - e0;
+    const float inv = d > 0 ? 1.0f / (float)d : 0.f;
+    const int ys = p.cout + 1;
+    for (int o = 0; o < p.cout; ++o) {
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) {
+            const float* w = p.W0 + ((size_t)m * p.cout + o) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) acc = fmaf(w[c], z[m][c], acc);
+        }
+        float val = acc * inv;
+        if (!p.bias_mask || d > 0) val += p.bias[o];
+        if (p.act) val = fmaxf(val, 0.f) - p.alpha * fmaxf(-val, 0.f);
+        yt[threadIdx.x * ys + o] = val;
+    }
+    __syncthreads();
+    // coalesced row writes, one 32-row tile (= 32 * cout contiguous floats) at a time; 4:1 max-pool from the tile
+    for (int tl = 0; tl < NB / TILE; ++tl) {
+        const int t = blockIdx.x * (NB / TILE) + tl;
+        if (p.tile_list ? t >= p.n_tiles : t * TILE >= p.n) break;
+        const int row0 = (p.tile_list ? p.tile_list[t] : t) * TILE;
+        for (int k = threadIdx.x; k < TILE * p.cout; k += NB) {
+            const int r = k / p.cout, o = k % p.cout;
+            if (row0 + r < p.n) p.y[(size_t)(row0 + r) * p.cout + o] = yt[(tl * TILE + r) * ys + o];
+        }
+        if (p.y_pool) {
+            for (int k = threadIdx.x; k < (TILE / 4) * p.cout; k += NB) {
+                const int pr = k / p.cout, o = k % p.cout;
+                float mx = -INFINITY;
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = pr * 4 + q;
+                    if (row0 + r < p.n) {
+                        mx = fmaxf(mx, yt[(tl * TILE + r) * ys + o]);
+                        any = true;
+                    }
+                }
+                if (any) p.y_pool[(size_t)((row0 >> 2) + pr) * p.cout + o] = mx;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the first layer (no input gradient): du, dv, dc partial sums per workgroup
+// ---------------------------------------------------------------------------------------------
+struct NarrowBwd {
+    int n;
+    const int* rowptr;
+    const int* col;
+    const float* x;
+    const float* ag;
+    const float* W0;
+    const float* ds;       // [n, cout]  s = dy * lrelu'(y) / deg
+    int cin, cout;
+    float* part;           // [grid][NARROW_PART]: du [9*CIN] | dv [9*CIN] | dc [9], zero padded
+};
+constexpr int NARROW_PART = 160;   // >= 2 * 9 * 8 + 9
+
+template <int CIN>
+__global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
+    __shared__ float red[NB / 64][NARROW_PART];
+    const int i = blockIdx.x * NB + threadIdx.x;
+    const bool active = i < p.n;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int e0 = 0, e1 = 0;
+    float a[FGC_M], xi[CIN];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) a[m] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xi[c] = 0.f;
+    // dz_i[m][c] = sum_o W0[m][o][c] s_i[o]   (scalar weight loads)
+    float dz[FGC_M][CIN];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dz[m][c] = 0.f;
+    if (active) {
+        e0 = p.rowptr[i];
+        e1 = p.rowptr[i + 1];
+        const float* ar = p.ag + (size_t)i * FGC_AG_LD;
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) a[m] = ar[m];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) xi[c] = p.x[(size_t)i * CIN + c];
+    }
+    for (int o = 0; o < p.cout; ++o) {
+        const float so = active ? p.ds[(size_t)i * p.cout + o] : 0.f;
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) {
+            const float* w = p.W0 + ((size_t)m * p.cout + o) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) dz[m][c] = fmaf(w[c], so, dz[m][c]);
+        }
+    }
+    float da[FGC_M], wv[FGC_M][CIN];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) {
+        da[m] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) wv[m][c] = 0.f;
+    }
+    for (int e = e0; e < e1; e += EB_BWD) {
+        float g[EB_BWD][FGC_M], xj[EB_BWD][CIN];
+        fetch_edges<CIN, EB_BWD>(p.col, p.ag, p.x, p.cin, e, e1, g, xj);
+#pragma unroll
+        for (int t = 0; t < EB_BWD; ++t) {
+            float q[FGC_M];
+            softmax9(a, g[t], q);
+            float dq[FGC_M], dot = 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) v = fmaf(dz[m][c], xj[t][c], v);
+                dq[m] = v;
+                dot = fmaf(q[m], v, dot);
+            }
+            const float w = e + t < e1 ? 1.f : 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                const float dl = q[m] * (dq[m] - dot) * w;
+                da[m] += dl;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) wv[m][c] = fmaf(dl, xj[t][c], wv[m][c]);
+            }
+        }
+    }
+    // block sums in a fixed order: wave butterfly, then the 4 waves
+    auto wave_sum = [](float v) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    };
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            const float u = wave_sum(da[m] * xi[c]);
+            const float v = wave_sum(wv[m][c]);
+            if (lane == 0) {
+                red[wave][m * CIN + c] = u;
+                red[wave][FGC_M * CIN + m * CIN + c] = v;
+            }
+        }
+        const float cc = wave_sum(da[m]);
+        if (lane == 0) red[wave][2 * FGC_M * CIN + m] = cc;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NARROW_PART; k += NB) {
+        const float v = k < 2 * FGC_M * CIN + FGC_M ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
+        p.part[(size_t)blockIdx.x * NARROW_PART + k] = v;
+    }
+}
+
+// du/dv from their [9][CIN] slots to [9][cin]; dW0[m][o][c] = T[(m * CIN + c) * cout + o]
+__global__ void narrow_finish_kernel(const float* __restrict__ uvc /* [NARROW_PART] */, const float* __restrict__ T,
+                                     int CIN, int cin, int cout, float* __restrict__ du, float* __restrict__ dv,
+                                     float* __restrict__ dc, float* __restrict__ dW0) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < FGC_M * cin) {
+        const int m = k / cin, c = k % cin;
+        du[k] = uvc[m * CIN + c];
+        dv[k] = uvc[FGC_M * CIN + m * CIN + c];
+    }
+    if (k < FGC_M) dc[k] = uvc[2 * FGC_M * CIN + k];
+    if (k < FGC_M * cout * cin) {
+        const int c = k % cin, o = (k / cin) % cout, m = k / (cin * cout);
+        dW0[k] = T[(size_t)(m * CIN + c) * cout + o];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int narrow_cin_pad(int cin) { return cin; }   // kernels are instantiated for the exact width 1..8
+
+bool narrow_supported(const fgc_conv_desc* d) {
+    if (getenv("FGC_NO_NARROW") && getenv("FGC_NO_NARROW")[0] == '1') return false;
+    const int cin = d->c0 + d->c1;
+    return d->c1 == 0 && d->x1 == nullptr && d->shift == 0 && cin <= 8 && d->cout <= 64 && d->cout % 4 == 0 &&
+           (size_t)d->n * 4 * 128 < 0xFFFFFFFFull;
+}
+
+template <int CIN, bool ZONLY>
+static int launch_narrow_fwd_t(const NarrowFwd& p, hipStream_t st) {
+    const int tiles = p.tile_list ? p.n_tiles : cdiv(p.n, TILE);
+    if (tiles == 0) return FGC_OK;
+    const size_t smem = ZONLY ? 0 : (size_t)NB * (p.cout + 1) * 4;
+    hipFuncSetAttribute((const void*)conv_narrow_fwd_kernel<CIN, ZONLY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)smem);
+    FGC_LAUNCH(ZONLY ? "conv_narrow_kernel<z>" : "conv_narrow_kernel<fwd>", st, (conv_narrow_fwd_kernel<CIN, ZONLY>),
+               dim3(cdiv(tiles, NB / TILE)), dim3(NB), smem, p);
+    FGC_CHECK_LAUNCH("conv_narrow_fwd_kernel");
+    return FGC_OK;
+}
+
+template <bool ZONLY>
+static int launch_narrow_fwd_z(const NarrowFwd& p, hipStream_t st) {
+    switch (p.cin) {
+        case 1: return launch_narrow_fwd_t<1, ZONLY>(p, st);
+        case 2: return launch_narrow_fwd_t<2, ZONLY>(p, st);
+        case 3: return launch_narrow_fwd_t<3, ZONLY>(p, st);
+        case 4: return launch_narrow_fwd_t<4, ZONLY>(p, st);
+        case 5: return launch_narrow_fwd_t<5, ZONLY>(p, st);
+        case 6: return launch_narrow_fwd_t<6, ZONLY>(p, st);
+        case 7: return launch_narrow_fwd_t<7, ZONLY>(p, st);
+        default: return launch_narrow_fwd_t<8, ZONLY>(p, st);
+    }
+}
+
+int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, hipStream_t st) {
+    NarrowFwd p{d->n,    d->rowptr,    d->col, d->x0,   ag, d->W0, d->b, d->c0, d->cout, d->bias_mask, d->act,
+                d->alpha, y, y_pool, nullptr, 0, d->tile_list, d->n_tiles};
+    return launch_narrow_fwd_z<false>(p, st);
+}
+
+int narrow_zld(int cin) { return (FGC_M * narrow_cin_pad(cin) + 3) / 4 * 4; }
+size_t narrow_bwd_floats(const fgc_conv_desc* d) {
+    const int zld = narrow_zld(d->c0);
+    const size_t nblk = cdiv(d->n, NB);
+    const int splits = narrow_splits(d);
+    return (size_t)d->n * zld + 64 + nblk * NARROW_PART + 64 + (size_t)splits * zld * d->cout + 64 +
+           (size_t)zld * d->cout + NARROW_PART + 64 + reduce_tmp_floats((int)nblk, NARROW_PART) +
+           reduce_tmp_floats(splits, (size_t)zld * d->cout) + 64;
+}
+
+int narrow_splits(const fgc_conv_desc* d) {
+    int s = 768 / cdiv(d->cout, 64);
+    const int maxs = cdiv(d->n, 256);
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : s;
+}
+
+// stage 2 of the first layer's backward: everything except db (stage 1 left its partials) and the final sums
+int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, hipStream_t st) {
+    const int cin = d->c0, zld = narrow_zld(cin);
+    float* zbuf = scratch;
+    float* part = zbuf + (size_t)d->n * zld + 64;
+    NarrowFwd pz{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, d->b, cin, d->cout, d->bias_mask, d->act, d->alpha,
+                 nullptr, nullptr, zbuf, zld, nullptr, 0};
+    int rc = launch_narrow_fwd_z<true>(pz, st);
+    if (rc) return rc;
+    NarrowBwd pb{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, io->ds, cin, d->cout, part};
+    const dim3 grid(cdiv(d->n, NB));
+#define FGC_NARROW_BWD(C_) \
+    case C_: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, conv_narrow_bwd_kernel<C_>, grid, dim3(NB), 0, pb); break;
+    switch (cin) {
+        FGC_NARROW_BWD(1) FGC_NARROW_BWD(2) FGC_NARROW_BWD(3) FGC_NARROW_BWD(4)
+        FGC_NARROW_BWD(5) FGC_NARROW_BWD(6) FGC_NARROW_BWD(7)
+        default: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, conv_narrow_bwd_kernel<8>, grid, dim3(NB), 0, pb); break;
+    }
+#undef FGC_NARROW_BWD
+    FGC_CHECK_LAUNCH("conv_narrow_bwd_kernel");
+    return FGC_OK;
+}
+
+// stage 8: dW0 = sum_i s_i (x) z_i through the streaming GEMM, then every partial in two reduction launches
+int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
+                      int nb_db, hipStream_t st) {
+    const int cin = d->c0, cout = d->cout, zld = narrow_zld(cin), CIN = narrow_cin_pad(cin);
+    const int nblk = cdiv(d->n, NB);
+    const int splits = narrow_splits(d);
+    float* zbuf = scratch;
+    float* part = zbuf + (size_t)d->n * zld + 64;
+    float* slab = part + (size_t)nblk * NARROW_PART + 64;
+    float* T = slab + (size_t)splits * zld * cout + 64;
+    float* uvc = T + (size_t)zld * cout;
+    float* rtmp = uvc + NARROW_PART + 64;
+    const int rps = cdiv(cdiv(d->n, splits), 4) * 4;
+    const int ns = cdiv(d->n, rps);
+    int rc = launch_gemm_tn_stream("gemm_tn_kernel:dW", zbuf, zld, zld, io->ds, cout, d->n, rps, ns, slab, st);
+    if (rc) return rc;
+    const RedJob jobs[3] = {
+        {slab, (size_t)zld * cout, ns, zld * cout, cout, cout, T},
+        {part, (size_t)NARROW_PART, nblk, NARROW_PART, NARROW_PART, NARROW_PART, uvc},
+        {db_part, (size_t)cout, nb_db, cout, cout, cout, io->db},
+    };
+    rc = reduce_jobs("reduce:params", jobs, 3, rtmp, st);
+    if (rc) return rc;
+    const int total = FGC_M * cout * cin;
+    FGC_LAUNCH("narrow_finish_kernel", st, narrow_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, uvc, T, CIN, cin,
+               cout, io->du, io->dv, io->dc, io->dW0);
+    FGC_CHECK_LAUNCH("narrow_finish_kernel");
+    return FGC_OK;
+}
+
+}  // namespace fgc

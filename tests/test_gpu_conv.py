@@ -211,3 +211,33 @@ def test_partial_calls_compose_to_the_whole_layer(golden_dir):
     assert torch.equal(bufs["dx"], dx_ref)
     for a, b in zip(grads, grads_ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["c1_raw", "c1_coarsened"])
+def test_first_layer_backward_without_input_gradient(golden_dir, case):
+    """need_dx=False on a narrow input (cin = 6: the network's conv1) takes the vector-ALU first-layer path
+    (fgc_conv_narrow.hip: no transposed graph, no per-edge buffer).  Same five parameter gradients as the reference."""
+    from facet_graph_convolution_amd import ops
+    from facet_graph_convolution_amd.graph import FacetGraph
+    z = np.load(os.path.join(golden_dir, "conv_%s.npz" % case))
+    z64 = np.load(os.path.join(golden_dir, "conv_%s_f64.npz" % case))
+    dev = torch.device("cuda:0")
+    x = torch.tensor(z["x"][0], device=dev)
+    g = FacetGraph(z["adj"], dev)
+    params = _params(x.shape[1], int(z["cout"]), int(z["seed"]), dev)
+    y, _, ag = ops.conv_fwd(g, x, None, 0, params)
+    dy = torch.tensor(z["dy"][0], device=dev)
+    dx, _, grads = ops.conv_bwd(g, x, None, 0, params, ag, y, dy, need_dx=False)
+    assert dx is None
+    for key, got in zip(["dW0", "db", "du", "dc", "dv"], grads):
+        got = got.cpu().numpy()
+        ref64 = z64[key].reshape(got.shape)
+        scale = max(1.0, np.abs(ref64).max())
+        assert np.abs(got - ref64).max() / scale < 5e-6, key
+    # activation + pooled output through the narrow forward kernel
+    yp_ref = None
+    y2, yp, _ = ops.conv_fwd(g, x, None, 0, params, act=1, alpha=0.1, want_pool=(g.n % 4 == 0))
+    ref = torch.where(y > 0, y, 0.1 * y)
+    assert torch.allclose(y2, ref, atol=1e-7)
+    if yp is not None:
+        assert torch.equal(yp, y2.view(-1, 4, y2.shape[1]).amax(1))
