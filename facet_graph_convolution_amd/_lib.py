@@ -77,6 +77,7 @@ _SIGS = {
     "fgc_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_void_p]),
     "fgc_conv_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "fgc_conv_bwd_needs_exchange": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO)]),
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_mlp_num_partials": (C.c_int32, [C.c_int32]),
     "fgc_mlp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

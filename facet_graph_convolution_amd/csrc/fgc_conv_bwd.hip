@@ -1069,6 +1069,11 @@ extern "C" size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d) {
     return plan_bwd(d, nullptr).bytes;
 }
 
+extern "C" int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
+    if (!d || !io) return 1;
+    return (io->dx0 == nullptr && narrow_supported(d)) ? 0 : 1;
+}
+
 template <int LPN>
 static int launch_logits(const CoreParams& p, const LogitParams& lp, bool vec4, size_t smem, hipStream_t st) {
     const int grid = cdiv(p.n, TILE);

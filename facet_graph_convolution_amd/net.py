@@ -449,6 +449,12 @@ class FacetDenoiser:
                                            name + " bwd/" + what)
             io.stages, io.flags = 1, 0   # s = dy * lrelu'(y) / deg on owned rows
             call("ds")
+            if not L.fgc_conv_bwd_needs_exchange(C.byref(d), C.byref(io)):
+                # first layer over a narrow input: its parameter gradients are sums over owned nodes, nothing to
+                # exchange (the flat-gradient all-reduce adds the ranks)
+                io.stages = 2 | 8
+                call("params")
+                continue
             # the halo rows of s (from their owners) are first read by the data kernel: they travel under the
             # d-logits kernel, which only reads the owned rows
             yield ("rows_begin", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False, "ds")

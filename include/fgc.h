@@ -209,6 +209,10 @@ typedef struct fgc_conv_bwd_io {
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
+/* 1 if a staged (facet-sharded) backward of this layer needs the halo rows of ds and the d-logits of incoming
+ * cross-shard edges between its stages; 0 for a first layer over a narrow input (dx0 == NULL, cin <= 8), whose
+ * parameter gradients are sums over the owned nodes only (stages 1, 2, 8; stage 4 is empty). */
+int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* io);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);
 
