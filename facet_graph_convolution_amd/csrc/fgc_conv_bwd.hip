@@ -1044,7 +1044,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     };
     w.Wq = take((size_t)g1.passes * opad * g1.kpass);
     w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
-    w.nb_db = d->n < 512 * 64 ? cdiv(d->n, 64) : 512;
+    w.nb_db = d->n < 4096 * 32 ? cdiv(d->n, 32) : 4096;   // >= 16 workgroups per CU: the kernel is a latency-bound stream
     w.rows_per_db = cdiv(d->n, w.nb_db);
     w.nb_db = cdiv(d->n, w.rows_per_db);
     w.db_part = take((size_t)w.nb_db * d->cout);
