@@ -15,7 +15,7 @@
 // No float atomics anywhere: every sum has a fixed order, results are bitwise reproducible.
 #include <stdlib.h>
 
-#include "fgc_conv_pc.h"
+#include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
 #include "fgc_reduce.h"
 
@@ -1217,10 +1217,6 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
         if (g2.lpn == 8 && w8_supported(p, io->max_in_deg)) {
             rc = launch_data_w8(p, ep, smem, st);
-            if (rc) return rc;
-        } else
-        if (g2.lpn == 8 && vec4 && !p.tile_list && io->max_in_deg > 0 && io->max_in_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1')) {
-            rc = launch_data_pc(p, ep, g2, st);
             if (rc) return rc;
         } else
         switch (g2.lpn) {

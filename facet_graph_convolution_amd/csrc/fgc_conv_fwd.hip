@@ -3,7 +3,7 @@
 
 #include <algorithm>
 
-#include "fgc_conv_pc.h"
+#include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
 
 namespace fgc {
@@ -314,8 +314,6 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
     if (g.lpn == 8 && w8_supported(p, d->max_deg)) return launch_fwd_w8(p, ep, smem, st);
-    if (g.lpn == 8 && vec4 && !p.tile_list && d->max_deg > 0 && d->max_deg <= KMAX && (getenv("FGC_PC") && getenv("FGC_PC")[0] == '1'))
-        return launch_fwd_pc(p, ep, g, st);
     switch (g.lpn) {
         case 2: return launch_fwd<2>(p, ep, vec4, smem, st);
         case 4: return launch_fwd<4>(p, ep, vec4, smem, st);

@@ -1,4 +1,4 @@
-// Producer/consumer variant of the fused conv core for the wide layers (LPN = 8, float4 rows).
+// Epilogue descriptors shared by the tiled conv kernels, and the eight-wave kernels' entry points (fgc_conv_w8.hip).
 #pragma once
 #include "fgc_conv_core.h"
 
@@ -27,12 +27,8 @@ struct DataEpilogue {
     int acc0, acc1;
 };
 
-size_t pc_smem_bytes(const ConvGeom& g);
-// eight-wave kernels (fgc_conv_w8.hip)
 bool w8_supported(const CoreParams& p, int max_deg);
 int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, hipStream_t st);
 int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, hipStream_t st);
-int launch_fwd_pc(const CoreParams& p, const FwdEpilogue& ep, const ConvGeom& g, hipStream_t st);
-int launch_data_pc(const CoreParams& p, const DataEpilogue& ep, const ConvGeom& g, hipStream_t st);
 
 }  // namespace fgc

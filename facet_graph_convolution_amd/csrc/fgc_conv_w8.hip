@@ -9,7 +9,7 @@
 // no node has more than 24 edges; everything else takes the 4-wave kernels.
 #include <stdlib.h>
 
-#include "fgc_conv_pc.h"
+#include "fgc_conv_w8.h"
 
 namespace fgc {
 
