@@ -55,6 +55,23 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef __HIPCC__
+// Sum over each row of 16 lanes, result in every lane, on the VALU's DPP crossbar (4 adds) instead of 4 LDS-pipe
+// ds_bpermute round trips: quad xor 1, quad xor 2, then mirror within 8 and within 16 (the partial sums are already
+// uniform inside each quad, so the mirrors act as xor 4 / xor 8).  Lane 0 adds in the same order as an xor butterfly.
+#define FGC_ROW16_SUM(v)                      \
+    do {                                      \
+        (v) += fgc_dpp_c<0xB1>(v);            \
+        (v) += fgc_dpp_c<0x4E>(v);            \
+        (v) += fgc_dpp_c<0x141>(v);           \
+        (v) += fgc_dpp_c<0x140>(v);           \
+    } while (0)
+template <int CTRL>
+__device__ __forceinline__ float fgc_dpp_c(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+#endif
+
 // ---- geometry of the fused "edge-aggregate + MFMA" kernels ------------------------------
 // A node's input row is processed KC = 4*LPN channels per pass by LPN lanes (float4 each).
 struct ConvGeom {

@@ -635,10 +635,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = da[t];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
+                FGC_ROW16_SUM(v);
                 da[t] = v;
             }
             dcacc += da;                               // dc = sum over nodes and edges of dl

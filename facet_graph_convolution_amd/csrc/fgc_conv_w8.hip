@@ -151,10 +151,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 #pragma unroll
             for (int m = 0; m < FGC_M; ++m) {
                 float v = dgsum[m];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
+                FGC_ROW16_SUM(v);
                 dgsum[m] = v;
             }
             if (kl == 0) {
