@@ -101,6 +101,10 @@ class InferenceMesh(PreprocessedData):
     """dataClasses.py:510-531."""
 
     def addMesh(self, V, faces, seed=None, parents=None):
+        """dataClasses.py:513-519.  Either the reference's call addMesh(inputFilePath, filename) (an OBJ is read with
+        utils.load_mesh) or arrays addMesh(V, faces)."""
+        if isinstance(V, str):
+            V, _, _, faces, _ = utils.load_mesh(V, faces, 0, False)
         self.vertices = np.asarray(V, dtype=np.float32)[np.newaxis]
         self.faces = np.asarray(faces)
         self.addMesh_TimeEfficient(V, faces, seed=seed, parents=parents)

@@ -1,0 +1,57 @@
+"""Denoise every OBJ of a folder (the reference's infer.py:40-100 for the face-normal network, withVerts = False):
+
+    python -m facet_graph_convolution_amd.infer NOISY_DIR RESULTS_DIR NETWORK.pt
+
+For each `name.obj`: preprocess (native adjacency + coarsening), predict the facet normals, move the vertices with 60
+iterations of update_position2, write `name_denoised.obj` (same faces) and, like the reference,
+`name_inferred_normals.obj` is replaced by a plain `name_normals.txt` (one predicted unit normal per face).
+Existing results are skipped unless --overwrite (B_OVERWRITE_RESULT, settings.py).
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+
+def denoise_file(net, noisy_dir, filename, results_dir, overwrite=False, log=print):
+    from .dataClasses import InferenceMesh
+    from .train import inferNetOld
+    from .utils import write_mesh
+    out_name = filename[:-4] + "_denoised.obj"
+    out_path = os.path.join(results_dir, out_name)
+    if os.path.isfile(out_path) and not overwrite:
+        log("Skipping %s. File already exists." % out_name)
+        return None
+    t0 = time.time()
+    mesh = InferenceMesh()
+    mesh.addMesh(noisy_dir, filename)
+    log("mesh added (%.0f ms): %d faces" % (1000 * (time.time() - t0), mesh.faces.shape[0]))
+    t0 = time.time()
+    points, normals = inferNetOld(mesh, net, update_vertices=True)
+    log("Inference complete (%.0f ms)" % (1000 * (time.time() - t0)))
+    write_mesh(points, mesh.faces, out_path)
+    np.savetxt(os.path.join(results_dir, filename[:-4] + "_normals.txt"), normals, fmt="%.6f")
+    return out_path
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("noisy_dir")
+    ap.add_argument("results_dir")
+    ap.add_argument("network", help="checkpoint written by train.save_checkpoint / trainNet")
+    ap.add_argument("--overwrite", action="store_true")
+    args = ap.parse_args(argv)
+    from .net import FacetDenoiser
+    from .train import load_checkpoint
+    net = FacetDenoiser("cuda:0")
+    load_checkpoint(args.network, net)
+    os.makedirs(args.results_dir, exist_ok=True)
+    for f in sorted(os.listdir(args.noisy_dir)):
+        if f.endswith(".obj"):
+            print("processing noisy file: " + f)
+            denoise_file(net, args.noisy_dir, f, args.results_dir, args.overwrite)
+
+
+if __name__ == "__main__":
+    main()

@@ -165,3 +165,63 @@ def metis_one_level(rr, cc, vv, rid, weights):
                                               rid.ctypes.data, weights.ctypes.data, N, cid.ctypes.data,
                                               C.byref(assoc)), "fgc_metis_one_level")
     return cid, assoc.value
+
+
+# ---------------------------------------------------------------------------------------------------
+# OBJ input / output (utils.py:476-640, 659-697): what infer.py reads and writes
+# ---------------------------------------------------------------------------------------------------
+def load_mesh(path, filename, K=0, bGetAdj=False):
+    """utils.py:476-640 for bGetAdj=False (the only mode the denoising path uses, dataClasses.py:513): reads 'v' and
+    'f' records of a Wavefront OBJ (vertex/texture/normal triplets accepted, polygons fan-triangulated around their
+    first vertex, everything else ignored).  Returns (vertices float32 [V,3], adj, free_ind, faces [F,3] zero-indexed
+    uint16 when V < 65536 else uint32, per-vertex normals) with adj / free_ind empty as in the reference."""
+    import os
+    if bGetAdj:
+        raise NotImplementedError("vertex adjacency (bGetAdj=True) is not on the facet denoising path")
+    verts, faces = [], []
+    with open(os.path.join(path, filename), "r") as fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "v":
+                verts.append((float(tok[1]), float(tok[2]), float(tok[3])))
+            elif tok[0] == "f":
+                idx = [int(t.split("/")[0]) - 1 for t in tok[1:]]
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+    V = np.asarray(verts, dtype=np.float32).reshape(-1, 3)
+    F = np.asarray(faces, dtype=np.int64).reshape(-1, 3).astype(np.uint16 if V.shape[0] < 65536 else np.uint32)
+    return V, [], [], F, computeNormals(V, F)
+
+
+def computeNormals(verts, faces):
+    """utils.py:44-60: per-vertex normals from the unit face normals.  `normals[faces[:, i]] += Nn` is a buffered
+    fancy-index add: for each corner i a vertex keeps the contribution of the LAST face listing it there, not the sum
+    over faces.  Kept as the reference has it (the denoising path never reads this output, dataClasses.py:513)."""
+    verts = np.asarray(verts, dtype=np.float32)
+    F = np.asarray(faces).astype(np.int64)
+    T = verts[F]
+    Nn = normalize(np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]))
+    out = np.zeros(verts.shape, dtype=np.float32)
+    for k in range(3):
+        out[F[:, k]] += Nn
+    return normalize(out)
+
+
+def write_mesh(vl, fl, strFileName):
+    """utils.py:659-697: 'v x y z' (6 decimals, extra per-vertex columns such as colours written as they are), then
+    'f a b c' one-indexed; a face (0,0,..) ends the list and a face (-1,-1,..) is skipped, as in the reference."""
+    vl = np.asarray(vl)
+    fl = np.asarray(fl).astype(np.int64) + 1
+    with open(strFileName, "w") as fh:
+        for row in vl:
+            fh.write("v " + " ".join("%.6f" % x for x in row) + " \n")
+        for row in fl:
+            if row[0] == 1 and row[1] == 1:
+                break
+            if row[0] == 0 and row[1] == 0:
+                continue
+            fh.write("f " + " ".join(str(int(t)) for t in row) + " \n")

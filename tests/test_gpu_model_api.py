@@ -104,3 +104,27 @@ def test_multiscale_heads_train_through_the_operator_api(golden_dir):
         scale = max(r.grad.abs().max().item(), 1e-3)
         err = (v.grad.cpu().double() - r.grad).abs().max().item() / scale
         assert err < 2e-4, "grad %d: %g" % (i, err)
+
+
+def test_obj_in_obj_out_inference(tmp_path):
+    """infer.py:40-100 for the face-normal network: OBJ in, checkpoint, denoised OBJ out."""
+    from facet_graph_convolution_amd import infer, utils
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.train import save_checkpoint
+    V, F = icosphere(3)
+    noisy = tmp_path / "noisy"
+    noisy.mkdir()
+    utils.write_mesh(add_noise(V, F), F, str(noisy / "ball.obj"))
+    net = FacetDenoiser("cuda:0", seed=3)
+    ckpt = str(tmp_path / "net.pt")
+    save_checkpoint(ckpt, net, 0)
+    infer.main([str(noisy), str(tmp_path / "out"), ckpt])
+    V2, _, _, F2, _ = utils.load_mesh(str(tmp_path / "out"), "ball_denoised.obj")
+    assert np.array_equal(F2, F) and V2.shape == V.shape and np.isfinite(V2).all()
+    nrm = np.loadtxt(str(tmp_path / "out" / "ball_normals.txt"))
+    assert nrm.shape == (F.shape[0], 3) and np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-4
+    # a second run skips existing results (B_OVERWRITE_RESULT = False in the reference's settings)
+    t = os.path.getmtime(str(tmp_path / "out" / "ball_denoised.obj"))
+    infer.main([str(noisy), str(tmp_path / "out"), ckpt])
+    assert os.path.getmtime(str(tmp_path / "out" / "ball_denoised.obj")) == t

@@ -169,3 +169,21 @@ def test_native_edge_map_rejects_overfull_vertices():
         utils.getEdgeMap(fan, maxEdges=20)
     em, vem = utils.getEdgeMap(fan, maxEdges=50)
     assert (vem[0] >= 0).sum() == 30 and len(em) == 59
+
+
+def test_obj_round_trip_and_polygon_fan(tmp_path):
+    """load_mesh / write_mesh (utils.py:476-640, 659-697): 6-decimal vertices, one-indexed faces, v/vt/vn triplets,
+    polygons fan-triangulated around their first vertex, index width by vertex count."""
+    V, F = icosphere(2)
+    utils.write_mesh(V, F, str(tmp_path / "a.obj"))
+    V2, adj, free_ind, F2, N = utils.load_mesh(str(tmp_path), "a.obj", 0, False)
+    assert adj == [] and free_ind == [] and F2.dtype == np.uint16 and np.array_equal(F2, F)
+    assert np.abs(V2 - V).max() < 1e-6 and N.shape == V.shape
+    (tmp_path / "q.obj").write_text("# quad\nmtllib x\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n"
+                                    "usemtl m\nf 1/1/1 2/2/1 3/3/1 4/4/1\n")
+    assert utils.load_mesh(str(tmp_path), "q.obj")[3].tolist() == [[0, 1, 2], [0, 2, 3]]
+    # the reference's addMesh(inputFilePath, filename) call form
+    im = InferenceMesh()
+    im.addMesh(str(tmp_path), "a.obj", seed=0)
+    assert im.vertices.shape == (1, V.shape[0], 3) and im.num_faces[0] == F.shape[0]
+    assert im.edge_map.shape[2] == 4 and im.v_e_map.shape[1:] == (V.shape[0], 20)
