@@ -94,6 +94,14 @@ class TrainingSet(PreprocessedData):
     """dataClasses.py:480-506 (array interface; OBJ parsing is outside the hot path)."""
 
     def addMeshWithGT(self, V_noisy, faces, V_gt, seed=None, parents=None):
+        """dataClasses.py:490-494.  Either the reference's call addMeshWithGT(inputFilePath, filename, gtFilePath,
+        gtfilename) (both OBJs are read with utils.load_mesh; the faces of the noisy file are used for both) or arrays
+        addMeshWithGT(V_noisy, faces, V_gt)."""
+        if isinstance(V_noisy, str):
+            in_path, in_name, gt_path, gt_name = V_noisy, faces, V_gt, seed
+            V_noisy, _, _, faces, _ = utils.load_mesh(in_path, in_name, 0, False)
+            V_gt = utils.load_mesh(gt_path, gt_name, 0, False)[0]
+            seed = None
         self.addMesh_TimeEfficient(V_noisy, faces, GTV=V_gt, seed=seed, parents=parents)
 
 

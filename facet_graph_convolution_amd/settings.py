@@ -7,3 +7,8 @@ MIN_PATCH_SIZE = 2000       # settings.py:22
 SAVEITER = 5000             # settings.py:30
 NUM_ITERATIONS = 300000     # settings.py:33
 MAX_EDGES = 20              # dataClasses.py:40 (getEdgeMap(faces0, maxEdges = 20)); train.py:44 reads it off v_e_map
+
+
+def getGTFilename(filename):
+    """settings.py:44-47: the ground truth of `<model>_n<k>.obj` is `<model>.obj` (the last 7 characters go)."""
+    return filename[:-7] + ".obj"

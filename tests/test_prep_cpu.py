@@ -187,3 +187,22 @@ def test_obj_round_trip_and_polygon_fan(tmp_path):
     im.addMesh(str(tmp_path), "a.obj", seed=0)
     assert im.vertices.shape == (1, V.shape[0], 3) and im.num_faces[0] == F.shape[0]
     assert im.edge_map.shape[2] == 4 and im.v_e_map.shape[1:] == (V.shape[0], 20)
+
+
+def test_preprocess_folder_to_pickled_training_set(tmp_path):
+    """preprocess.py:8-52: OBJ folders -> pickled TrainingSet (noisy / ground-truth pairing by file name)."""
+    import pickle
+    from facet_graph_convolution_amd import preprocess
+    from facet_graph_convolution_amd.settings import getGTFilename
+    V, F = icosphere(2)
+    (tmp_path / "noisy").mkdir()
+    (tmp_path / "gt").mkdir()
+    utils.write_mesh(V, F, str(tmp_path / "gt" / "ball.obj"))
+    utils.write_mesh(add_noise(V, F), F, str(tmp_path / "noisy" / "ball_n1.obj"))
+    assert getGTFilename("ball_n1.obj") == "ball.obj" and preprocess.gt_filename("ball_noisy.obj") == "ball.obj"
+    out = preprocess.pickleData(str(tmp_path / "noisy"), str(tmp_path / "gt"), str(tmp_path / "dump"), redundancy=2,
+                                log=lambda *_: None)
+    ts = pickle.load(open(str(tmp_path / "dump" / "trainingSet.pkl"), "rb"))
+    assert ts.mesh_count == 2 and len(ts.in_list) == 2 and ts.gt_list[0].shape[2] == 3
+    assert ts.in_list[0].shape[1] == ts.adj_list[0][0].shape[1] and ts.num_faces == [F.shape[0]] * 2
+    assert not (tmp_path / "dump" / "validSet.pkl").exists() and "trainingSet.pkl" in out
