@@ -285,6 +285,22 @@ class FacetDenoiser:
         self._graph_fb = None
         return self
 
+    def bind_cached(self, key, x, adjs, gt=None, max_bytes=64 << 30):
+        """bind_mesh with the bound state (graphs, activations, descriptors: ~7 KB per facet) kept in HBM under `key`,
+        so that a training loop that alternates between meshes (train.py:556 draws one per iteration) switches
+        between them without re-uploading or re-allocating anything.  States are kept while they fit in max_bytes."""
+        cache = self.__dict__.setdefault("_mesh_cache", {})
+        if key in cache:
+            self._mesh = cache[key]
+            self._graph_fb = None
+            return self
+        self.bind_mesh(x, adjs, gt=gt)
+        used = sum(sum(t.numel() * t.element_size() for t in m["B"].values()) for m in cache.values())
+        mine = sum(t.numel() * t.element_size() for t in self._mesh["B"].values())
+        if used + mine <= max_bytes:
+            cache[key] = self._mesh
+        return self
+
     def _cout(self, lay):
         return self.params.spec[lay.pidx][1][1]
 

@@ -79,9 +79,9 @@ def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device
         if ckpt and it % SAVEITER == 0 and it > 0:
             save_checkpoint(ckpt, net, start + it)
         b = rs.randint(len(meshes))
-        if b != bound:       # the reference feeds a new patch through feed_dict; here the mesh is (re)bound to HBM
+        if b != bound:       # the reference feeds a new patch through feed_dict; here every mesh stays bound in HBM
             x, adjs, gt = meshes[b]
-            net.bind_mesh(x, adjs, gt=gt)
+            net.bind_cached(b, x, adjs, gt=gt)
             bound = b
         n0 = meshes[b][0].shape[1]
         loss = net.train_step(sample_ind=rs.randint(n0, size=COST_SAMPLES),

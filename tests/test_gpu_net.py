@@ -165,3 +165,30 @@ def test_two_process_sharded_step_over_gloo():
 def test_rccl_code_path_world_of_one():
     """backend 'nccl' (= RCCL): the async all_to_all_single / all_reduce calls of the sharded schedule, world size 1."""
     _run_ranks(1, "nccl", 29632)
+
+
+def test_training_alternates_between_cached_meshes(golden_dir):
+    """bind_cached: two meshes stay bound in HBM; switching back and forth gives the same losses as re-binding."""
+    prep_a = np.load(os.path.join(golden_dir, "prep_ico3.npz"))
+    prep_b = np.load(os.path.join(golden_dir, "prep_torus640.npz"))
+    meshes = [(p["x"], [p["adj%d" % l] for l in range(3)], p["gt"]) for p in (prep_a, prep_b)]
+
+    from facet_graph_convolution_amd.net import FacetDenoiser
+
+    def run(cached):
+        net = FacetDenoiser("cuda:0", seed=4)
+        rs = np.random.RandomState(1)
+        out = []
+        for it in range(8):
+            b = it % 2
+            x, adjs, gt = meshes[b]
+            if cached:
+                net.bind_cached(b, x, adjs, gt=gt)
+            else:
+                net.bind_mesh(x, adjs, gt=gt)
+            loss = net.train_step(sample_ind=rs.randint(x.shape[1], size=4000), R=np.eye(3))
+            out.append(loss[0].item())
+        return out, net
+    a, net = run(True)
+    b, _ = run(False)
+    assert a == b and len(net._mesh_cache) == 2
