@@ -756,6 +756,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
                 *reinterpret_cast<f32x4*>(o) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
                 *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                 *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
+                // da | dg behind the node's r row (scalar stores: rld need not be a multiple of 4 on this path)
+                float* rt = ep.r + (size_t)j * ep.rld + (ep.rld - 24);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    rt[m] = m < FGC_M ? da[m] : 0.f;
+                    rt[12 + m] = m < FGC_M ? dgsum[m] : 0.f;
+                }
             } else {
 #pragma unroll
                 for (int m = 0; m < 24; ++m) t[m] = 0.f;
@@ -1018,13 +1025,12 @@ struct BwdWorkspace {
     float* Wpt;       // data-gradient operand
     float* db_part;   // [nb][cout]
     float* dc_part;   // [tiles][12]
-    float* slab;      // gemm_tn partials of dW0
-    float* slab_uv;   // gemm_tn partials of [du; dv]
+    float* slab;      // gemm_tn partials of [dW0; du; dv]
     float* rtmp;      // scratch of the fixed-order reductions
     float* narrow;    // first-layer path (cin <= 8): z buffer, partial slabs (fgc_conv_narrow.hip)
     size_t bytes;
     int nb_db, rows_per_db;
-    int splitW, splitUV;
+    int splitW;
 };
 
 static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
@@ -1046,11 +1052,9 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.nb_db = cdiv(d->n, w.rows_per_db);
     w.db_part = take((size_t)w.nb_db * d->cout);
     w.dc_part = take((size_t)cdiv(d->n, TILE) * 12);
-    w.splitW = tn_splits(FGC_M * d->cout, cin, d->n);
-    w.splitUV = tn_splits(24, cin, d->n);
-    w.slab = take((size_t)w.splitW * FGC_M * d->cout * cin);
-    w.slab_uv = take((size_t)w.splitUV * 24 * cin);
-    w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitUV, (size_t)FGC_M * cin) +
+    w.splitW = tn_splits(FGC_M * d->cout + 24, cin, d->n);
+    w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
+    w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
                   reduce_tmp_floats(cdiv(d->n, TILE), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
     w.narrow = narrow_supported(d) ? take(narrow_bwd_floats(d)) : nullptr;
     w.bytes = off;
@@ -1208,7 +1212,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                          d->shift, 12, 0, w.Wpt);
         p.tile_list = io->data_tile_list;
         p.n_tiles = io->n_data_tiles;
-        DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout, d->u, d->v, cin, d->c0, d->c1, d->shift,
+        DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout + 24, d->u, d->v, cin, d->c0, d->c1, d->shift,
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
@@ -1225,36 +1229,28 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     }
     // K3: dW0 = r^T x ; [du; dv] = dag^T x
     if (stages & 8) {
-        const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0) && ((uintptr_t)io->dag % 16 == 0);
-        const int P = FGC_M * cout;
-        int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;
-        int ns = cdiv(d->n, rps);
-        const dim3 g1(cdiv(P, 64) * cdiv(cin, 64), ns);
+        const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0);
+        // one GEMM over the rows of r = [9*cout aggregate columns | da | dg]: rows 0..P-1 of the product are dW0^T
+        // blocks, rows P..P+8 du, rows P+12..P+20 dv
+        const int P = FGC_M * cout, PL = P + 24;
+        const int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;
+        const int ns = cdiv(d->n, rps);
+        const dim3 g1(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
-        if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel, g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+        if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel, g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                                   d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+        else if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                            d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<false>), g1, dim3(256), 0, io->r, P, P, d->x0, d->x1,
+        else FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<false>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                         d->c0, d->c1, d->shift, d->n, rps, w.slab);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
-        const int nsW = ns;
-        rps = cdiv(cdiv(d->n, w.splitUV), 4) * 4;
-        ns = cdiv(d->n, rps);
-        const dim3 g2(cdiv(cin, 64), ns);
-        if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:duv", st, gemm_tn_stream_kernel, g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
-                                  d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
-        else if (v4) FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<true>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
-                           d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
-        else FGC_LAUNCH("gemm_tn_kernel:duv", st, (gemm_tn_kernel<false>), g2, dim3(256), 0, io->dag, FGC_AG_LD, 24,
-                        d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab_uv);
-        FGC_CHECK_LAUNCH("fgc_conv_bwd/duv");
         // every parameter gradient of the layer in two launches (fixed summation order).  The db / dc partials were
         // left in the workspace by stages 1 and 2: a staged caller keeps the workspace untouched between its calls.
+        const size_t sst = (size_t)PL * cin;
         const RedJob jobs[5] = {
-            {w.slab, (size_t)P * cin, nsW, P * cin, cin, cin, io->dW0},
-            {w.slab_uv, (size_t)24 * cin, ns, FGC_M * cin, cin, cin, io->du},
-            {w.slab_uv + (size_t)12 * cin, (size_t)24 * cin, ns, FGC_M * cin, cin, cin, io->dv},
+            {w.slab, sst, ns, P * cin, cin, cin, io->dW0},
+            {w.slab + (size_t)P * cin, sst, ns, FGC_M * cin, cin, cin, io->du},
+            {w.slab + (size_t)(P + 12) * cin, sst, ns, FGC_M * cin, cin, cin, io->dv},
             {w.db_part, (size_t)cout, w.nb_db, cout, cout, cout, io->db},
             {w.dc_part, (size_t)12, cdiv(d->n, TILE), 12, 12, FGC_M, io->dc},
         };

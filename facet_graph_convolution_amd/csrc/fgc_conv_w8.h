@@ -16,8 +16,8 @@ struct FwdEpilogue {
 struct DataEpilogue {
     const float* dl;      // [nnz, 12]
     float* dag;           // reads 0..8 (da), writes 12..20 (dg)
-    float* r;             // [n, 9*cout]
-    int rld;              // 9*cout
+    float* r;             // [n, rld]: 9*cout aggregate columns, then da (0..8) | dg (12..20) of the node
+    int rld;              // 9*cout + 24
     const float* u;       // [9, cin]
     const float* v;       // [9, cin]
     int cin, c0f, c1f;    // forward input split

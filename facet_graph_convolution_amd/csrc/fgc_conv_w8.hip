@@ -167,6 +167,14 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                     *reinterpret_cast<f32x4*>(o) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                     *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
+                    // da | dg behind the node's r row: [du; dv] = (da | dg)^T x rides in the dW0 GEMM
+                    float* rt = de.r + (size_t)i * de.rld + (de.rld - 24);
+                    *reinterpret_cast<f32x4*>(rt) = f32x4{da[0], da[1], da[2], da[3]};
+                    *reinterpret_cast<f32x4*>(rt + 4) = f32x4{da[4], da[5], da[6], da[7]};
+                    *reinterpret_cast<f32x4*>(rt + 8) = f32x4{da[8], 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(rt + 12) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
+                    *reinterpret_cast<f32x4*>(rt + 16) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
+                    *reinterpret_cast<f32x4*>(rt + 20) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
                 } else {
 #pragma unroll
                     for (int m = 0; m < 24; ++m) t[m] = 0.f;

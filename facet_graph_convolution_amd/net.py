@@ -220,12 +220,12 @@ class FacetDenoiser:
             B["y2"] = torch.empty(n2, 3, **f)
         # shared backward scratch, sized for the largest user
         max_ds = max((ns[l.level] + nh[l.level]) * self._cout(l) for l in self.layers)
-        max_r = max(ns[l.level] * self._cout(l) for l in self.layers)
+        max_r = max(ns[l.level] * (FGC_M * self._cout(l) + 24) for l in self.layers)
         max_dl = max(g.nnz + getattr(g, "n_cross_in", 0) for g in graphs)
         B["ds"] = torch.zeros(max_ds, **f)
         B["dl"] = torch.zeros(max(max_dl, 1) * DL_LD, **f)
         B["dag"] = torch.empty(max(ns) * AG_LD, **f)
-        B["r"] = torch.empty(max_r * FGC_M, **f)
+        B["r"] = torch.empty(max_r, **f)
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
         B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
         B["loss"] = torch.zeros(2, **f)

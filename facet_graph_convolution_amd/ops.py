@@ -101,7 +101,7 @@ def conv_bwd(graph, x0, x1, shift, params, ag, y, dy, bias_mask=True, act=0, alp
     ds = torch.empty(n, cout, **f32)
     dl = torch.empty(max(graph.nnz, 1), DL_LD, **f32)
     dag = torch.empty(n, AG_LD, **f32)
-    r = torch.empty(n, FGC_M * cout, **f32)
+    r = torch.empty(n, FGC_M * cout + 24, **f32)
     grads = [torch.empty_like(p) for p in params]
     if need_dx:
         if dx0 is None:

@@ -174,7 +174,7 @@ int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* y_pool, voi
  *   ds   [n, cout]           dy * lrelu'(y) / deg
  *   dl   [nnz, FGC_DL_LD]    per-edge d(logit)
  *   dag  [n, FGC_AG_LD]      d a (0..8) | d g (12..20) per node of this level
- *   r    [n, M*cout]         backward-side aggregate (feeds the dW reduction)
+ *   r    [n, M*cout + 24]    backward-side aggregate, then da | dg of the node (one GEMM gives dW0, du and dv)
  * Outputs: dW0,db,du,dc,dv (overwritten); dx0/dx1 [(n >> shift), c0/c1] either overwritten
  * (accumulate = 0) or added to (accumulate = 1); dx pointers may be NULL (conv1: no input grad). */
 typedef struct fgc_conv_bwd_io {

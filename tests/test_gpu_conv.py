@@ -197,7 +197,7 @@ def test_partial_calls_compose_to_the_whole_layer(golden_dir):
     io = _lib.ConvBwdIO()
     io.trowptr, io.tcol, io.tedge, io.max_in_deg = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr(), g.max_in_deg
     bufs = dict(ds=torch.empty(n, cout, **f32), dl=torch.empty(g.nnz, 12, **f32), dag=torch.empty(n, 24, **f32),
-                r=torch.empty(n, 9 * cout, **f32), dx=torch.full((n, cin), float("nan"), **f32))
+                r=torch.empty(n, 9 * cout + 24, **f32), dx=torch.full((n, cin), float("nan"), **f32))
     grads = [torch.empty_like(p) for p in params]
     io.ag, io.y, io.dy = ag_ref.data_ptr(), y_ref.data_ptr(), dy.data_ptr()
     io.ds, io.dl, io.dag, io.r = (bufs[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
