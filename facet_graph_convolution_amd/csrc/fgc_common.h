@@ -98,14 +98,9 @@ static inline ConvGeom conv_geom(int cin, int cout) {
     ConvGeom g;
     g.cin = cin;
     g.cout = cout;
-    // 8 lanes x 4 channels per node and pass for every width: narrow inputs (conv1: 6 channels) leave lanes idle in
-    // the gather but keep all 256 threads, the 32-channel z tile and the matrix-core kernels in play, which beats
-    // the 2- and 4-lane variants (kept for experiments: FGC_FORCE_LPN)
-    int lpn = 8;
-    if (const char* f = getenv("FGC_FORCE_LPN")) {   // developer experiment
-        const int v = atoi(f);
-        if ((v == 2 || v == 4 || v == 8) && v < lpn) lpn = v;
-    }
+    // 8 lanes x 4 channels per node and pass for every width the tiled kernels see (narrow inputs, cin <= 8, take
+    // fgc_conv_narrow.hip): keeps all 256 threads, the 32-channel z tile and the matrix-core kernels in play
+    const int lpn = 8;
     g.lpn = lpn;
     g.kc = 4 * lpn;
     g.passes = (cin + g.kc - 1) / g.kc;

@@ -1198,11 +1198,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             FGC_CHECK_LAUNCH("fgc_conv_bwd/logits_mfma");
             rc = 0;
         } else
-        switch (g1.lpn) {
-            case 2: rc = launch_logits<2>(p, lp, vec4, smem, st); break;
-            case 4: rc = launch_logits<4>(p, lp, vec4, smem, st); break;
-            default: rc = launch_logits<8>(p, lp, vec4, smem, st); break;
-        }
+            rc = launch_logits<8>(p, lp, vec4, smem, st);
         if (rc) return rc;   // dc partials: stage 8
     }
     // K2
@@ -1220,11 +1216,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             rc = launch_data_w8(p, ep, smem, st);
             if (rc) return rc;
         } else
-        switch (g2.lpn) {
-            case 2: rc = launch_data<2>(p, ep, vec4, smem, st); break;
-            case 4: rc = launch_data<4>(p, ep, vec4, smem, st); break;
-            default: rc = launch_data<8>(p, ep, vec4, smem, st); break;
-        }
+            rc = launch_data<8>(p, ep, vec4, smem, st);
         if (rc) return rc;
     }
     // K3: dW0 = r^T x ; [du; dv] = dag^T x

@@ -314,9 +314,5 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
     if (g.lpn == 8 && w8_supported(p, d->max_deg)) return launch_fwd_w8(p, ep, smem, st);
-    switch (g.lpn) {
-        case 2: return launch_fwd<2>(p, ep, vec4, smem, st);
-        case 4: return launch_fwd<4>(p, ep, vec4, smem, st);
-        default: return launch_fwd<8>(p, ep, vec4, smem, st);
-    }
+    return launch_fwd<8>(p, ep, vec4, smem, st);
 }
