@@ -84,6 +84,16 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             ctr[4] = a1[0]; ctr[5] = a1[1]; ctr[6] = a1[2]; ctr[7] = a1[3];
             ctr[8] = ar[8];
         }
+        // DATA: the node's da row (written by the d-logits kernel) is needed only after the dl sums below; asked for
+        // here it costs no extra memory round trip
+        f32x4 da0 = {0.f, 0.f, 0.f, 0.f}, da1 = {0.f, 0.f, 0.f, 0.f};
+        float da8 = 0.f;
+        if (DATA && kl == 0 && i < p.n) {
+            const float* dr = de.dag + (size_t)i * FGC_AG_LD;
+            da0 = *reinterpret_cast<const f32x4*>(dr);
+            da1 = *reinterpret_cast<const f32x4*>(dr + 4);
+            da8 = dr[8];
+        }
         if (kl == 0) s.deg[node] = d;
         if (FAST) {  // largest degree among the 4 nodes of this wave, rounded up to a whole batch of 8 edge slots
             const int dmax = max(max(__builtin_amdgcn_readlane(d, 0), __builtin_amdgcn_readlane(d, 16)),
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             if (kl == 0) {
                 float* t = dagt + node * 24;
                 if (i < p.n) {
-                    const float* da = de.dag + (size_t)i * FGC_AG_LD;
+                    const float da[FGC_M] = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3], da8};
 #pragma unroll
                     for (int m = 0; m < FGC_M; ++m) {
                         t[m] = da[m];
