@@ -299,6 +299,76 @@ extern "C" int fgc_faces_large_adj(const uint32_t* F, int32_t nf, int32_t nv, in
     return FGC_OK;
 }
 
+// utils.py:1508-1696.  Two FIFO queues (nodes to expand, already-covered "border" nodes), nodes renumbered in order of
+// discovery; growth stops at nodes_num nodes (or min_patch_size through the border queue when the region is exhausted).
+extern "C" int fgc_graph_patch(const int32_t* adj, int32_t n, int32_t K, int32_t nodes_num, int32_t seed,
+                               const int8_t* mask, int32_t min_patch_size, int32_t* out, int32_t* old_of,
+                               int32_t* patch_n, int32_t* next_seed) {
+    FGC_CHECK_ARG(adj && mask && out && old_of && patch_n && next_seed, "fgc_graph_patch: null pointer");
+    FGC_CHECK_ARG(n > 0 && K > 1 && nodes_num > 0 && seed >= 0 && seed < n, "fgc_graph_patch: n=%d K=%d nodes_num=%d seed=%d",
+                  n, K, nodes_num, seed);
+    FGC_CHECK_ARG(min_patch_size <= nodes_num, "fgc_graph_patch: min_patch_size=%d above nodes_num=%d", min_patch_size,
+                  nodes_num);
+    const int cap = nodes_num + K;
+    for (size_t t = 0; t < (size_t)cap * K; ++t) out[t] = 0;     // one-indexed output: 0 = empty slot
+    std::vector<int> new_of(n, -1);
+    std::vector<int> q, border;
+    size_t qh = 0, bh = 0;
+    int count = 0;
+    auto add = [&](int v) {
+        new_of[v] = count;
+        old_of[count] = v;
+        ++count;
+    };
+    auto nb_of = [&](int cur, int s) { return adj[(size_t)cur * K + s] - 1; };
+    // a node may be discovered while count < nodes_num only at loop entry, so at most K - 1 more fit: cap rows suffice
+    auto expand = [&](int cur, bool masked_to_border) {
+        const int r = new_of[cur];
+        out[(size_t)r * K] = r + 1;
+        for (int s = 1; s < K; ++s) {
+            const int nb = nb_of(cur, s);
+            if (nb == -1) break;
+            if (new_of[nb] == -1) {
+                add(nb);
+                if (masked_to_border && mask[nb] == 1) border.push_back(nb);
+                else q.push_back(nb);
+            }
+            out[(size_t)r * K + s] = new_of[nb] + 1;
+        }
+    };
+    add(seed);
+    q.push_back(seed);
+    while (count < nodes_num && qh < q.size()) expand(q[qh++], true);
+    int nxt = -1;
+    if (count < min_patch_size) {
+        while (count < min_patch_size && bh < border.size()) expand(border[bh++], false);
+        while (count < min_patch_size && qh < q.size()) expand(q[qh++], false);
+    }
+    FGC_CHECK_ARG(count <= cap, "fgc_graph_patch: patch overflow (%d > %d)", count, cap);
+    auto finish = [&](std::vector<int>& qq, size_t& head) {
+        while (head < qq.size()) {
+            const int cur = qq[head++];
+            const int r = new_of[cur];
+            out[(size_t)r * K] = r + 1;
+            int c = 1;
+            for (int s = 1; s < K; ++s) {
+                const int nb = nb_of(cur, s);
+                if (nb == -1) break;
+                if (new_of[nb] == -1) {
+                    if (mask[nb] == 0) nxt = nb;
+                    continue;
+                }
+                out[(size_t)r * K + c++] = new_of[nb] + 1;
+            }
+        }
+    };
+    finish(q, qh);
+    finish(border, bh);
+    *patch_n = count;
+    *next_seed = nxt;
+    return FGC_OK;
+}
+
 // utils.py:91-183.  Faces in order; (v1,v2) and (v1,v3) are searched among v1's edges, (v2,v3) among v2's; a found
 // edge takes this face as its second face, a missing one is created in the order 12, 13, 23.
 extern "C" int fgc_edge_map(const uint32_t* F, int32_t nf, int32_t nv, int32_t max_edges, int32_t* e_map,

@@ -9,9 +9,10 @@ Same attribute names and per-mesh list layout:
     edge_map int32 [1, E, 4], v_e_map int32 [1, V, MAX_EDGES]  (getEdgeMap, for the vertex update)
 
 Differences, by design: the adjacency / coarsening loops run natively (libfgc host routines) and a mesh is
-kept whole: the reference cuts meshes above MAX_PATCH_SIZE = 20 000 faces into BFS patches only because one
-TF graph could not hold more (settings.py:20-22); a 1M-facet mesh fits one MI355X many times over.  Patch
-mode is listed as a follow-up.
+kept whole by default (maxSize = 10^9): the reference cuts meshes above MAX_PATCH_SIZE = 20 000 faces into BFS
+patches only because one TF graph could not hold more (settings.py:20-22); a 1M-facet mesh fits one MI355X many times
+over.  Constructed with maxSize = MAX_PATCH_SIZE the reference's patch mode is reproduced (same patches for the same
+numpy seed; receptive fields truncated at patch borders, overlaps summed at inference).
 """
 import numpy as np
 
@@ -37,7 +38,7 @@ class PreprocessedData(object):
         self.seed = 0
 
     def addMesh_TimeEfficient(self, V0, faces0, GTV=None, seed=None, parents=None):
-        """dataClasses.py:34-233, small-mesh branch (:172-233)."""
+        """dataClasses.py:34-233: whole mesh (:172-233) or, above maxSize faces, breadth-first patches (:76-171)."""
         V0 = np.asarray(V0, dtype=np.float32)
         faces0 = np.asarray(faces0)
         facesNum = faces0.shape[0]
@@ -48,22 +49,42 @@ class PreprocessedData(object):
             self.v_e_map = np.expand_dims(self.v_e_map, axis=0)
         except RuntimeError:        # a vertex with more than MAX_EDGES edges: the reference dies here with an
             self.edge_map = self.v_e_map = None   # IndexError; normals can still be inferred, only the vertex update cannot
-        if facesNum > self.maxSize:
-            raise NotImplementedError(
-                "patch mode (dataClasses.py:76-171) is not built: meshes are processed whole on MI355X; "
-                "construct with maxSize >= number of faces")
         f_normals0, f_pos0 = utils.face_features(V0, faces0)
         f_adj0 = utils.getFacesLargeAdj(faces0, K_faces)
         f_normals_pos = np.concatenate((f_normals0, f_pos0), axis=1)        # float64 [F,6] (dataClasses.py:64)
         GTf_normals0 = utils.computeFacesNormals(GTV, faces0) if GTV is not None else None
-        old_N = facesNum
+        if facesNum > self.maxSize:
+            # dataClasses.py:76-171: breadth-first patches of patchSize faces (already covered faces join as context),
+            # seeds drawn with numpy's global RNG among the uncovered faces unless the previous patch proposed one
+            print("Dividing mesh into patches: %i faces (%i max allowed)" % (facesNum, self.maxSize))
+            faceCheck = np.zeros(facesNum)
+            faceRange = np.arange(facesNum)
+            nextSeed = -1
+            while np.any(faceCheck == 0):
+                toBeProcessed = faceRange[faceCheck == 0]
+                faceSeed = toBeProcessed[np.random.randint(toBeProcessed.shape[0])] if nextSeed == -1 else nextSeed
+                patchAdj, fOldInd, nextSeed = utils.getGraphPatch_wMask(f_adj0, self.patchSize, faceSeed, faceCheck,
+                                                                        self.minPatchSize)
+                faceCheck[fOldInd] = 1
+                if fOldInd.shape[0] < 100:      # small disjoint components are dropped (dataClasses.py:103-104)
+                    continue
+                self._add_graph(patchAdj, f_normals_pos[fOldInd],
+                                GTf_normals0[fOldInd] if GTf_normals0 is not None else None, fOldInd, seed, parents)
+        else:
+            self._add_graph(f_adj0, f_normals_pos, GTf_normals0, [], seed, parents)
+
+    def _add_graph(self, f_adj, f_normals_pos, GTf_normals, patch_index, seed, parents):
+        """One mesh or one patch: coarsen, pad with fake nodes, reorder, append (dataClasses.py:106-171,172-233)."""
+        old_N = f_adj.shape[0]
+        f_normals0, f_pos0 = f_normals_pos[:, :3], f_normals_pos[:, 3:]
+        GTf_normals0 = GTf_normals
         if self.coarseningLvlNum > 1:
             levels = (self.coarseningLvlNum - 1) * self.coarseningStepNum
             keep = tuple(self.coarseningStepNum * l for l in range(self.coarseningLvlNum))
             cur_seed = self.seed if seed is None else seed
             has_sat = True
             while has_sat:      # dataClasses.py:179-192: re-draw the pairing while a row saturates K
-                klists, newToOld, par, has_sat = utils.coarsen_klists(f_adj0, f_pos0, f_normals0, levels, K_faces,
+                klists, newToOld, par, has_sat = utils.coarsen_klists(f_adj, f_pos0, f_normals0, levels, K_faces,
                                                                       cur_seed, parents, keep)
                 if has_sat and parents is not None:
                     raise RuntimeError("recorded cluster assignments saturate K=%d" % K_faces)
@@ -77,10 +98,10 @@ class PreprocessedData(object):
                 GTf_normals0 = np.concatenate((GTf_normals0, np.zeros((new_N - old_N, 3))), axis=0)[newToOld]
             self.parents_list.append(par)
         else:
-            fAdjs = [f_adj0[np.newaxis].astype(np.int64)]
+            fAdjs = [f_adj[np.newaxis].astype(np.int64)]
             newToOld = None
         self.num_faces.append(old_N)
-        self.patch_indices.append([])
+        self.patch_indices.append(patch_index)
         if newToOld is not None:
             self.permutations.append(utils.inv_perm(newToOld))
         self.in_list.append(f_normals_pos[np.newaxis])
@@ -116,4 +137,4 @@ class InferenceMesh(PreprocessedData):
         self.vertices = np.asarray(V, dtype=np.float32)[np.newaxis]
         self.faces = np.asarray(faces)
         self.addMesh_TimeEfficient(V, faces, seed=seed, parents=parents)
-        self.normals = self.in_list[0][0, :, :3]
+        self.normals = utils.computeFacesNormals(self.vertices[0], self.faces)

@@ -125,11 +125,25 @@ def inferNetOld(inputMesh, net_or_checkpoint, device="cuda", update_vertices=Fal
     else:
         net = FacetDenoiser(device)
         load_checkpoint(net_or_checkpoint, net)
-    out = None
-    for i in range(len(inputMesh.in_list)):
-        net.bind_mesh(inputMesh.in_list[i], inputMesh.adj_list[i])
-        pred = net.infer_normals(inputMesh.permutations[i], inputMesh.num_faces[i])
-        out = pred if out is None else out
+    n_patches = len(inputMesh.in_list)
+    if n_patches == 1:
+        net.bind_mesh(inputMesh.in_list[0], inputMesh.adj_list[0])
+        out = net.infer_normals(inputMesh.permutations[0], inputMesh.num_faces[0])
+    else:
+        # train.py:92-126,136: every patch predicts its own faces (context faces included); predictions of faces
+        # covered by several patches are summed in the original face order, then normalised
+        F = inputMesh.faces.shape[0]
+        acc = torch.zeros(F, 3, dtype=torch.float32, device=net.device)
+        for i in range(n_patches):
+            net.bind_mesh(inputMesh.in_list[i], inputMesh.adj_list[i])
+            n_conv = net.forward(rotate=False)
+            perm = torch.as_tensor(np.asarray(inputMesh.permutations[i]).astype(np.int64), device=net.device)
+            outN = n_conv[perm][:inputMesh.num_faces[i]]
+            idx = torch.as_tensor(np.asarray(inputMesh.patch_indices[i]).astype(np.int64), device=net.device)
+            acc.index_add_(0, idx, outN)
+        out = acc
+        for _ in range(2):          # utils.normalize = normalizeOnce twice
+            out = out * (1.0 / (out.norm(dim=1, keepdim=True) + 1e-8))
     if update_vertices:
         if getattr(inputMesh, "edge_map", None) is None:
             raise RuntimeError("the mesh has a vertex with more than MAX_EDGES edges: no edge tables, no vertex update")

@@ -103,6 +103,23 @@ def getEdgeMap(faces, maxEdges=50):
     return e_map[:ne.value].copy(), v_e_map
 
 
+def getGraphPatch_wMask(fAdjIn, nodesNum, seed, mask, minPatchSize):
+    """utils.py:1508-1696: (patch K-list one-indexed [n, K], old index of every patch node [n], nextSeed), natively and
+    bit-exact (same breadth-first queue discipline)."""
+    from . import _lib
+    import ctypes as C
+    adj = np.ascontiguousarray(np.asarray(fAdjIn), dtype=np.int32)
+    n, K = adj.shape
+    m = np.ascontiguousarray(np.asarray(mask) == 1, dtype=np.int8)
+    out = np.empty((int(nodesNum) + K, K), dtype=np.int32)
+    old = np.empty(int(nodesNum) + K, dtype=np.int32)
+    cnt, nxt = C.c_int32(0), C.c_int32(-1)
+    _lib.check(_lib.lib().fgc_graph_patch(adj.ctypes.data, n, K, int(nodesNum), int(seed), m.ctypes.data,
+                                          int(minPatchSize), out.ctypes.data, old.ctypes.data, C.byref(cnt),
+                                          C.byref(nxt)), "fgc_graph_patch")
+    return out[:cnt.value].copy(), old[:cnt.value].copy(), int(nxt.value)
+
+
 def coarsen_klists(adj, pos, normals, levels=4, K=23, seed=0, parents=None, keep=(0, 2, 4)):
     """listToSparseWNormals + coarsen + sparseToList (utils.py:1753-1827, lib/coarsening.py:5-31).
 

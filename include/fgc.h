@@ -104,6 +104,17 @@ int fgc_hierarchy_parents(const fgc_hierarchy* h, int32_t level, int32_t* out_h)
  * utils.py:1799-1827); *saturated = 1 if a row had more than K-1 neighbours. */
 int fgc_hierarchy_klist(const fgc_hierarchy* h, int32_t level, int32_t K, int32_t* adj_h, int32_t* saturated);
 
+/* Breadth-first patch of a facet graph = getGraphPatch_wMask (utils.py:1508-1696), host: what the reference cuts
+ * meshes above MAX_PATCH_SIZE into (dataClasses.py:76-171).  adj_h [n, K] one-indexed K-list, mask_h [n] (1 = node
+ * already covered by an earlier patch: added as context, expanded only while the patch is below min_patch_size).
+ * Outputs: patch_adj_h [nodes_num + K, K] one-indexed K-list of the patch in discovery order (rows of expanded nodes
+ * keep their slots, rows of nodes still queued when growth stopped are compacted), old_index_h [nodes_num + K],
+ * *patch_n the number of nodes written, *next_seed an uncovered node seen just outside the patch or -1.
+ * Same queue discipline as the reference, so all three are bit-identical to its output. */
+int fgc_graph_patch(const int32_t* adj_h, int32_t n, int32_t K, int32_t nodes_num, int32_t seed, const int8_t* mask_h,
+                    int32_t min_patch_size, int32_t* patch_adj_h, int32_t* old_index_h, int32_t* patch_n,
+                    int32_t* next_seed);
+
 /* Edge map = getEdgeMap (utils.py:91-183), host.  e_map_h [3*nf, 4] receives [v1, v2, f1, f2] per edge (f2 = -1
  * on a boundary), *n_edges the number of edges written; v_e_map_h [nv, max_edges] the edge ids incident to every
  * vertex in creation order, -1 padded.  Same visiting order as the reference, so both tables are bit-identical to

@@ -213,3 +213,67 @@ def edge_map(faces, max_edges=20):
                 cnt[v] += 1
             eind += 1
     return e_map[:eind], v_e_map
+
+
+def graph_patch_wmask(adj, nodes_num, seed, mask, min_patch_size):
+    """ref: utils.py:1508-1696 (getGraphPatch_wMask).  Breadth-first patch of a one-indexed K-list `adj` grown from
+    node `seed` until it holds `nodes_num` nodes.  `mask[j] == 1` marks nodes already covered by earlier patches:
+    they are added to the patch (context) but their own neighbours are only expanded while the patch is smaller than
+    `min_patch_size`.  Nodes are renumbered in order of discovery.  Rows of nodes that were expanded keep their
+    neighbour slots (slot 0 = self); rows of nodes still queued when growth stops are compacted to the neighbours that
+    made it into the patch.  Returns (patch K-list one-indexed [n, K], old index of every patch node [n], next seed:
+    an uncovered node seen just outside the patch, or -1)."""
+    from collections import deque
+    adj = np.asarray(adj).astype(np.int64) - 1
+    N, K = adj.shape
+    out = -np.ones((nodes_num + K, K), dtype=np.int64)
+    new_of = -np.ones(N, dtype=np.int64)
+    old_of = -np.ones(N, dtype=np.int64)
+    count = [0]
+
+    def add(n):
+        new_of[n] = count[0]
+        old_of[count[0]] = n
+        count[0] += 1
+
+    q, border = deque([seed]), deque()
+    add(seed)
+
+    def expand(cur, masked_to_border):
+        r = new_of[cur]
+        out[r, 0] = r
+        for s in range(1, K):
+            nb = adj[cur, s]
+            if nb == -1:
+                break
+            if new_of[nb] == -1:
+                add(nb)
+                (border if (masked_to_border and mask[nb] == 1) else q).append(nb)
+            out[r, s] = new_of[nb]
+
+    while count[0] < nodes_num and q:
+        expand(q.popleft(), True)
+    next_seed = -1
+    if count[0] < min_patch_size:
+        while count[0] < min_patch_size and border:
+            expand(border.popleft(), False)
+        while count[0] < min_patch_size and q:
+            expand(q.popleft(), False)
+    for queue_ in (q, border):
+        while queue_:
+            cur = queue_.popleft()
+            r = new_of[cur]
+            out[r, 0] = r
+            c = 1
+            for s in range(1, K):
+                nb = adj[cur, s]
+                if nb == -1:
+                    break
+                if new_of[nb] == -1:
+                    if mask[nb] == 0:
+                        next_seed = nb
+                    continue
+                out[r, c] = new_of[nb]
+                c += 1
+    n = count[0]
+    return (out[:n] + 1), old_of[:n].copy(), int(next_seed)

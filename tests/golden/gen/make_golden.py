@@ -275,6 +275,33 @@ def vertex_case(tag, V_noisy, F, normals):
          normals=normals.astype(np.float32), edge_map=e_map, v_e_map=v_e_map, **out)
 
 
+def patch_case(tag, F, patch_size, min_patch_size, seed):
+    """getGraphPatch_wMask (utils.py:1508-1696) driven as dataClasses.py:76-95 drives it: seeds drawn with
+    np.random among the uncovered faces unless the previous patch proposed one; every patch is recorded."""
+    import contextlib, io
+    adj = ref_utils.getFacesLargeAdj(F, 23)
+    fnum = F.shape[0]
+    check = np.zeros(fnum)
+    rng = np.arange(fnum)
+    np.random.seed(seed)
+    next_seed = -1
+    out = {"faces": F.astype(np.int32), "adj": adj.astype(np.int32), "patch_size": patch_size,
+           "min_patch_size": min_patch_size}
+    k = 0
+    while np.any(check == 0):
+        todo = rng[check == 0]
+        s0 = todo[np.random.randint(todo.shape[0])] if next_seed == -1 else next_seed
+        mask_in = check.copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            padj, old, next_seed = ref_utils.getGraphPatch_wMask(adj, patch_size, s0, check, min_patch_size)
+        check[old] = 1
+        out["seed%d" % k], out["mask%d" % k] = int(s0), mask_in.astype(np.int8)
+        out["adj%d" % k], out["old%d" % k], out["next%d" % k] = padj.astype(np.int32), old.astype(np.int32), int(next_seed)
+        k += 1
+    out["num_patches"] = k
+    save("patch_%s.npz" % tag, **out)
+
+
 def random_klist(n, K, seed, zero_rows=(3,), dup=True):
     """Random one-indexed K-list with self slot, ragged degrees, duplicates and an isolated (all-zero) row."""
     rs = np.random.RandomState(seed)
@@ -333,6 +360,12 @@ def main():
             net_case("torus640", xt, adjst, gtt, seed=1, multi_scale=False)
     if want("infer") and not F64:
         infer_case("ico3", x, adjs, ds, seed=0)
+    if want("patch") and not F64:
+        Vp, Fp = torus(24, 20)          # 960 faces, patches of 300 (min 120)
+        patch_case("torus960", Fp, 300, 120, seed=11)
+        # two disjoint components (a fresh random seed is needed when a component is exhausted)
+        V2, F2 = icosphere(2)
+        patch_case("two_spheres", np.concatenate([F2, F2 + V2.shape[0]]), 150, 60, seed=12)
     if want("vertex"):
         # closed mesh: noisy icosphere, target normals = normals of the clean sphere
         Vn = add_noise(V, F)

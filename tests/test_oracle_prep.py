@@ -69,3 +69,14 @@ def test_vertex_update_restatement_matches_reference(golden_dir, tag):
         np.testing.assert_allclose(x, z["x_%d" % it], rtol=0, atol=1e-6)
     x64 = R.update_position2(torch.tensor(z["verts"]).double(), z["normals"], z["edge_map"], z["v_e_map"], 60).numpy()
     np.testing.assert_allclose(x64, z64["x_60"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["torus960", "two_spheres"])
+def test_graph_patch_restatement_matches_reference(golden_dir, tag):
+    """getGraphPatch_wMask (utils.py:1508-1696) over the whole patch sequence of a mesh, incl. the proposed next seeds
+    and (two_spheres) the jump to a second connected component."""
+    z = np.load(os.path.join(golden_dir, "patch_%s.npz" % tag))
+    for k in range(int(z["num_patches"])):
+        a, o, nx = O.graph_patch_wmask(z["adj"], int(z["patch_size"]), int(z["seed%d" % k]), z["mask%d" % k],
+                                       int(z["min_patch_size"]))
+        assert np.array_equal(a, z["adj%d" % k]) and np.array_equal(o, z["old%d" % k]) and nx == int(z["next%d" % k])

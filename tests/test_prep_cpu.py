@@ -206,3 +206,33 @@ def test_preprocess_folder_to_pickled_training_set(tmp_path):
     assert ts.mesh_count == 2 and len(ts.in_list) == 2 and ts.gt_list[0].shape[2] == 3
     assert ts.in_list[0].shape[1] == ts.adj_list[0][0].shape[1] and ts.num_faces == [F.shape[0]] * 2
     assert not (tmp_path / "dump" / "validSet.pkl").exists() and "trainingSet.pkl" in out
+
+
+@pytest.mark.parametrize("tag", ["torus960", "two_spheres"])
+def test_native_graph_patch_is_bit_exact(golden_dir, tag):
+    """fgc_graph_patch vs the reference's getGraphPatch_wMask outputs (utils.py:1508-1696)."""
+    z = np.load(os.path.join(golden_dir, "patch_%s.npz" % tag))
+    for k in range(int(z["num_patches"])):
+        a, o, nx = utils.getGraphPatch_wMask(z["adj"], int(z["patch_size"]), int(z["seed%d" % k]), z["mask%d" % k],
+                                             int(z["min_patch_size"]))
+        assert np.array_equal(a, z["adj%d" % k]) and np.array_equal(o, z["old%d" % k]) and nx == int(z["next%d" % k])
+
+
+def test_patch_mode_replays_the_reference_patch_sequence(golden_dir):
+    """dataClasses.py:76-171: with the same numpy seed the data class cuts the mesh into the reference's patches (seed
+    draws and next-seed chaining included) and every face is covered."""
+    z = np.load(os.path.join(golden_dir, "patch_torus960.npz"))
+    V, F = torus(24, 20)
+    assert np.array_equal(F, z["faces"])
+    im = InferenceMesh(maxSize=int(z["patch_size"]))
+    im.minPatchSize = int(z["min_patch_size"])
+    np.random.seed(11)
+    im.addMesh(add_noise(V, F), F, seed=0)
+    n = int(z["num_patches"])
+    assert len(im.in_list) == n == len(im.patch_indices)
+    covered = np.zeros(F.shape[0], bool)
+    for k in range(n):
+        assert np.array_equal(im.patch_indices[k], z["old%d" % k]) and im.num_faces[k] == len(z["old%d" % k])
+        assert im.in_list[k].shape[1] == im.adj_list[k][0].shape[1] and im.in_list[k].shape[1] % 16 == 0
+        covered[im.patch_indices[k]] = True
+    assert covered.all() and im.normals.shape == (F.shape[0], 3)
