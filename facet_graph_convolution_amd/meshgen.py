@@ -69,3 +69,57 @@ def add_noise(V, F, sigma_rel=0.2, seed=1):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     mag = rs.normal(scale=sigma_rel * mean_edge, size=(Vd.shape[0], 1))
     return (Vd + d * mag).astype(np.float32)
+
+
+def flip_edges(F, nflips, seed=0):
+    """Irregular connectivity for tests: `nflips` random edge flips on a closed manifold triangle mesh (the edge
+    shared by triangles (a,b,c) and (b,a,d) becomes (c,d); skipped when (c,d) already exists or a vertex would drop
+    below valence 3).  Vertex valences spread to about 3..10, facet degrees beyond 16."""
+    F = np.array(F, dtype=np.int64)
+    rs = np.random.RandomState(seed)
+    edge_faces = {}
+    for f, (a, b, c) in enumerate(F):
+        for u, v in ((a, b), (b, c), (c, a)):
+            edge_faces.setdefault((min(u, v), max(u, v)), []).append(f)
+    val = np.bincount(F.ravel())
+    done = 0
+    keys = list(edge_faces.keys())
+    for _ in range(nflips * 20):
+        if done >= nflips:
+            break
+        e = keys[rs.randint(len(keys))]
+        fs = edge_faces.get(e)
+        if fs is None or len(fs) != 2:
+            continue
+        f0, f1 = fs
+        a, b = e
+        c = [v for v in F[f0] if v != a and v != b]
+        d = [v for v in F[f1] if v != a and v != b]
+        if len(c) != 1 or len(d) != 1:
+            continue
+        c, d = c[0], d[0]
+        if c == d or (min(c, d), max(c, d)) in edge_faces or val[a] <= 3 or val[b] <= 3:
+            continue
+        # orientation of f0: does it run a -> b -> c ?
+        t = list(F[f0])
+        ia = t.index(a)
+        forward = t[(ia + 1) % 3] == b
+        new0, new1 = ((c, a, d), (d, b, c)) if forward else ((c, d, a), (d, c, b))
+        for f in (f0, f1):
+            x, y, z = F[f]
+            for u, v in ((x, y), (y, z), (z, x)):
+                lst = edge_faces[(min(u, v), max(u, v))]
+                lst.remove(f)
+        del edge_faces[e]
+        F[f0], F[f1] = new0, new1
+        for f in (f0, f1):
+            x, y, z = F[f]
+            for u, v in ((x, y), (y, z), (z, x)):
+                edge_faces.setdefault((min(u, v), max(u, v)), []).append(f)
+        keys.append((min(c, d), max(c, d)))
+        val[a] -= 1
+        val[b] -= 1
+        val[c] += 1
+        val[d] += 1
+        done += 1
+    return F.astype(np.int32)
