@@ -473,6 +473,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 // weight fragments of the dz GEMM are requested one k-group ahead.  LDS limits residency to 2 waves per SIMD, so
 // the 256-VGPR budget is there to be used.
 // ---------------------------------------------------------------------------------------------
+// LONG (some node of the graph has 17..24 edges: irregular meshes, where nearly every tile holds such a node): one sweep
+// that also carries the accumulators of the second edge tile (slots 16..23), paid for with the second gather register
+// set: the neighbour rows of nodes 4..7 are requested after the products of nodes 0..3, those of the second edge tile
+// on demand.  Without it such tiles took the two-sweep path below, i.e. the dz GEMM twice.
+template <bool LONG>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, p.zstride);
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
     const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
     // edges 0..15 of every node in sweep 0; a second sweep (block-uniform, rare) for nodes with 17..24 edges.  The
     // per-edge work is independent across edges, so a sweep is the whole computation for its 16 edge slots.
-    const int nsweeps = __syncthreads_or(dmine > 16) ? 2 : 1;
+    const int nsweeps = LONG ? (__syncthreads(), 1) : (__syncthreads_or(dmine > 16) ? 2 : 1);
 
     const int nct = p.kpass >> 4;   // 18
     const int okg = lp.opad >> 4;
@@ -506,6 +511,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
         // row id of this lane's edge slot (clamped into the node's list) for each node of the wave
         int rowid[NPW];
         f32x4 dq[NPW];
+        f32x4 dq_hi[LONG ? NPW : 1];    // LONG: edge slots 16..23
+#pragma unroll
+        for (int nn = 0; nn < (LONG ? NPW : 1); ++nn) dq_hi[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nn = 0; nn < NPW; ++nn) {
             const int node = wave * NPW + nn;
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                     loadw(g, w0);
                     mmw(g, w0);
                 }
-                gather(H, bxb);
+                if (!LONG) gather(H, bxb);
                 if (pass > 0 || sweep > 0) __syncthreads();  // the previous readers of ztile are done
 #pragma unroll
                 for (int c = 0; c < K1_CTW; ++c) {
@@ -600,7 +608,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 }
             };
             products(0, bxa);
-            products(H, bxb);
+            if (!LONG) {
+                products(H, bxb);
+            } else {
+                gather(H, bxa);
+                products(H, bxa);
+#pragma unroll
+                for (int nn = 0; nn < NPW; ++nn) {
+                    if (dn[nn] <= 16) continue;            // wave-uniform
+                    const int node = wave * NPW + nn;
+                    const int e = min(16 + lr, dn[nn] - 1);
+                    const int row = __float_as_int(s.qbuf[((size_t)node * KMAX + e) * QLD + 9]);
+                    const unsigned off = __umul24((unsigned)row, rowbytes) + laneoff;
+                    const f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                    const f32x4 x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64u, 0, 0));
+                    const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(zr + 16);
+                    f32x4 u0 = f32x4{0.f, 0.f, 0.f, 0.f}, u1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], x0[t], u0, 0, 0, 0);
+                        u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], x1[t], u1, 0, 0, 0);
+                    }
+                    dq_hi[nn] += u0 + u1;
+                }
+            }
         }
 
         // ---- softmax backward of this sweep's edge slots: lane (edge = ebase + lr, m0 = 4*lq) holds dq[m0..m0+3]
@@ -616,22 +649,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 continue;
             }
             const int e0 = s.deg[TILE + 4 + node];     // first edge id, left in LDS by the softmax phase
-            const int edge = ebase + lr;
-            const bool ok = edge < d;
-            const float* qr = s.qbuf + ((size_t)node * KMAX + min(edge, d - 1)) * QLD;
-            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
-            else if (lq == 2) q[0] = qr[8];
-            f32x4 g = dq[nn];
-            if (lq == 2) { g[1] = 0.f; g[2] = 0.f; g[3] = 0.f; }
-            if (lq == 3) g = f32x4{0.f, 0.f, 0.f, 0.f};
-            float dot = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
-            dot += __shfl_xor(dot, 16);
-            dot += __shfl_xor(dot, 32);
-            f32x4 da;
+            f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ntile = (LONG && d > 16) ? 2 : 1;
+            for (int et = 0; et < ntile; ++et) {
+                const int edge = ebase + 16 * et + lr;
+                const bool ok = edge < d;
+                const float* qr = s.qbuf + ((size_t)node * KMAX + min(edge, d - 1)) * QLD;
+                f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
+                else if (lq == 2) q[0] = qr[8];
+                f32x4 g = (LONG && et == 1) ? dq_hi[LONG ? nn : 0] : dq[nn];
+                if (lq == 2) { g[1] = 0.f; g[2] = 0.f; g[3] = 0.f; }
+                if (lq == 3) g = f32x4{0.f, 0.f, 0.f, 0.f};
+                float dot = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
+                dot += __shfl_xor(dot, 16);
+                dot += __shfl_xor(dot, 32);
+                f32x4 dl;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) da[t] = ok ? q[t] * (g[t] - dot) : 0.f;
-            if (ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = da;
+                for (int t = 0; t < 4; ++t) dl[t] = ok ? q[t] * (g[t] - dot) : 0.f;
+                if (ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = dl;
+                da += dl;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = da[t];
@@ -1185,10 +1223,17 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                               !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
             if (deep) {
                 // (__syncthreads_or owns 256 B of static LDS: ask for exactly what this launch needs)
-                hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem);
-                FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, conv_bwd_logits_deep_kernel, dim3(cdiv(d->n, TILE)),
-                           dim3(NTHREADS), smem, p, lp);
+                if (d->max_deg > 16) {
+                    hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, conv_bwd_logits_deep_kernel<true>, dim3(cdiv(d->n, TILE)),
+                               dim3(NTHREADS), smem, p, lp);
+                } else {
+                    hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, conv_bwd_logits_deep_kernel<false>, dim3(cdiv(d->n, TILE)),
+                               dim3(NTHREADS), smem, p, lp);
+                }
             } else if (vec4)
                 FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, (conv_bwd_logits_mfma_kernel<true>),
                            dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);
