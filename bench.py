@@ -74,9 +74,10 @@ def algorithmic_bytes_fwd_bwd(net):
     return fwd, fwd * 3879.0 / 1584.0
 
 
-def cpu_baseline(sample_faces=(70, 70)):
+def cpu_baseline(sample_faces=(140, 140)):
     """The oracle timed on this host: one forward+backward of the reference-shaped torch-CPU restatement on a
-    9 800-facet torus (bounded so that the default bench run stays within minutes), up to 32 host threads."""
+    39 200-facet torus (bounded: about 10 s of CPU work, so that the default bench run stays within minutes), up to 32
+    host threads."""
     import torch
     from oracle import model_ref as R
     ds, F = build_mesh(sample_faces[0], sample_faces[1], seed=7)
