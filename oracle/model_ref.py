@@ -275,3 +275,60 @@ def update_position2(x, face_normals, edge_map, v_edges, iter_num=20, lmbd=1.0 /
         upd = (nrm4 * dp).sum(2).sum(1)                                                           # :1545-1550
         x = x + lmbd * upd
     return x
+
+
+def avg_ignore_zeros_pool(x, steps=2):
+    """ref: model.py:792-814 (custom_binary_tree_pooling, pooltype='avg_ignore_zeros').  x [B, n, C]; per step pairs of
+    consecutive rows are averaged, a row that is zero in EVERY channel being replaced by its partner first (so a fake
+    node does not drag the average; two zero rows give zero)."""
+    px = x
+    for _ in range(steps):
+        B, n, C = px.shape
+        px = px.reshape(B, n // 2, 2, C)
+        l0, l1 = px[:, :, 0], px[:, :, 1]
+        z0 = (l0 == 0).all(-1, keepdim=True)
+        z1 = (l1 == 0).all(-1, keepdim=True)
+        c0 = torch.where(z0, l1, l0)
+        c1 = torch.where(z1, l0, l1)
+        px = torch.stack([c0, c1], 2).mean(2)
+    return px
+
+
+def update_faces_center(vertices, faces, coarsening_steps=2):
+    """ref: train.py:1768-1798.  vertices [V,3], faces [N0,3] int (-1 = fake face: its corners read a zero vertex).
+    Returns [fpos0 [1,N0,3], fpos1 [1,N0/4,3], fpos2 [1,N0/16,3]]."""
+    vz = torch.cat([torch.zeros(1, 3, dtype=vertices.dtype), vertices], 0)
+    fpos0 = vz[torch.as_tensor(np.asarray(faces)).long() + 1].mean(1).unsqueeze(0)
+    fpos1 = avg_ignore_zeros_pool(fpos0, coarsening_steps)
+    fpos2 = avg_ignore_zeros_pool(fpos1, coarsening_steps)
+    return [fpos0, fpos1, fpos2]
+
+
+def update_position_MS(x, face_normals_list, faces, v_faces0, coarsening_steps=2, iter_num_list=(80, 20, 20)):
+    """ref: train.py:1668-1764.  x [V,3]; face_normals_list = [n0 [N0,3], n1 [N0/4,3], n2 [N0/16,3]]; faces [N0,3];
+    v_faces0 [V,K] face (node) ids of every vertex at the finest level, -1 padded.  Coarse to fine: at scale s a
+    vertex is pulled towards the planes of the level-s nodes above its faces,
+        x_v += (1/#faces(v)) * sum_k n (n . (c - x_v)),   n, c = normal / centre of node floor(v_faces0[v,k] / 4^s),
+    the centres being recomputed from the current vertices in every iteration.  Returns (x [V,3], [dx per scale])."""
+    x = torch.as_tensor(x)
+    dt = x.dtype
+    vf0 = torch.as_tensor(np.asarray(v_faces0)).long()
+    numf = (vf0 != -1).sum(-1).to(dt)
+    lmbd = (1.0 / numf).reshape(-1, 1)
+    nscale = len(face_normals_list)
+    dx_list = []
+    for s in range(nscale):
+        cur = nscale - 1 - s
+        fn = torch.cat([torch.zeros(1, 3, dtype=dt), torch.as_tensor(face_normals_list[cur]).to(dt).reshape(-1, 3)], 0)
+        div = int((2 ** coarsening_steps) ** cur)
+        vf = torch.div(vf0, div, rounding_mode="floor") + 1          # -1 stays -1 (Python-2 division), then 0
+        v_fn = fn[vf]                                                # [V, K, 3]
+        x_init = x
+        for _ in range(iter_num_list[s]):
+            fpos = update_faces_center(x, faces, coarsening_steps)[cur].reshape(-1, 3)
+            fpos = torch.cat([torch.zeros(1, 3, dtype=dt), fpos], 0)
+            e = fpos[vf] - x[:, None, :]
+            n_w = (v_fn * e).sum(-1, keepdim=True)
+            x = x + lmbd * (n_w * v_fn).sum(1)
+        dx_list.append(x - x_init)
+    return x, dx_list

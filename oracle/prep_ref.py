@@ -277,3 +277,31 @@ def graph_patch_wmask(adj, nodes_num, seed, mask, min_patch_size):
                 c += 1
     n = count[0]
     return (out[:n] + 1), old_of[:n].copy(), int(next_seed)
+
+
+def vertices_faces(faces, k_v, vnum=0):
+    """ref: utils.py:370-395 (getVerticesFaces): for every vertex the faces (row indices of `faces`) that contain it,
+    in face order, -1 padded to k_v; rows whose first vertex is -1 (fake faces) are skipped."""
+    faces = np.asarray(faces).astype(np.int64)
+    if vnum == 0:
+        vnum = int(faces.max()) + 1
+    v_f = -np.ones((vnum, k_v), dtype=np.int32)
+    cnt = np.zeros(vnum, dtype=np.int64)
+    for f in range(faces.shape[0]):
+        if faces[f, 0] == -1:
+            continue
+        for t in range(3):
+            v = faces[f, t]
+            if cnt[v] >= k_v:
+                raise IndexError("vertex %d is in more than %d faces" % (v, k_v))
+            v_f[v, cnt[v]] = f
+            cnt[v] += 1
+    return v_f
+
+
+def normalize_point_sets(vl1, vl2):
+    """ref: utils.py:2077-2104: both point sets divided by the bounding-box diagonal of their union (not centred)."""
+    lo = np.minimum(vl1.min(0), vl2.min(0))
+    hi = np.maximum(vl1.max(0), vl2.max(0))
+    diag = math.sqrt(float(((hi - lo) ** 2).sum()))
+    return vl1 / diag, vl2 / diag

@@ -275,6 +275,42 @@ def vertex_case(tag, V_noisy, F, normals):
          normals=normals.astype(np.float32), edge_map=e_map, v_e_map=v_e_map, **out)
 
 
+def multiscale_vertex_case(tag, V_noisy, Vclean, F, seed):
+    """The multi-scale vertex pipeline on a whole mesh (dataClasses.py:374-440 small-mesh branch, train.py:1668-1798):
+    faces padded with -1 rows and re-ordered like the nodes, getVerticesFaces, normalizePointSets, then
+    avg_ignore_zeros pooling, updateFacesCenter and update_position_MS driven with clean-mesh normals pooled to the
+    three levels."""
+    prep = np.load(os.path.join(OUT, "prep_%s.npz" % tag))
+    perm = prep["permutations"]                       # old -> new
+    n0 = len(perm)
+    new_to_old = np.empty(n0, dtype=np.int64)
+    new_to_old[perm] = np.arange(n0)
+    faces_p = np.concatenate([F.astype(np.int64), -np.ones((n0 - F.shape[0], 3), dtype=np.int64)], 0)[new_to_old]
+    v_faces = ref_utils.getVerticesFaces(faces_p, 25, V_noisy.shape[0])
+    Vn, _ = ref_utils.normalizePointSets(V_noisy.astype(np.float32), V_noisy.astype(np.float32))
+    nrm = ref_utils.computeFacesNormals(Vclean, F)
+    nrm0 = np.concatenate([nrm, np.zeros((n0 - F.shape[0], 3))], 0)[new_to_old].astype(np.float32)
+    n0_t = torch.tensor(nrm0, dtype=FDT)[None]
+    n1_t = ref_utils.normalizeTensor(ref_model.custom_binary_tree_pooling(n0_t, steps=2, pooltype="avg_ignore_zeros"))
+    n2_t = ref_utils.normalizeTensor(ref_model.custom_binary_tree_pooling(n1_t, steps=2, pooltype="avg_ignore_zeros"))
+    x = torch.tensor(Vn.astype(np.float32), dtype=FDT)[None]
+    faces_t = torch.tensor(faces_p[None].astype(np.int32))
+    vf_t = torch.tensor(v_faces[None].astype(np.int32))
+    centers = ref_train.updateFacesCenter(x, faces_t, 2)
+    out = {"verts": V_noisy.astype(np.float32), "verts_norm": Vn.astype(np.float32), "faces_perm": faces_p.astype(np.int32),
+           "v_faces": v_faces.astype(np.int32), "n0": nrm0, "n1": n1_t.detach().numpy()[0], "n2": n2_t.detach().numpy()[0],
+           "fpos0": centers[0].detach().numpy()[0], "fpos1": centers[1].detach().numpy()[0],
+           "fpos2": centers[2].detach().numpy()[0]}
+    for its in ((2, 1, 1), (80, 20, 20)):
+        xr, dxl = ref_train.update_position_MS(x, [n0_t, n1_t, n2_t], faces_t, vf_t, coarsening_steps=2,
+                                               iter_num_list=list(its))
+        key = "_".join(str(i) for i in its)
+        out["x_" + key] = xr.detach().numpy()[0]
+        for k, dx in enumerate(dxl):
+            out["dx%d_%s" % (k, key)] = dx.detach().numpy()
+    save("msvertex_%s%s.npz" % (tag, "_f64" if F64 else ""), **out)
+
+
 def patch_case(tag, F, patch_size, min_patch_size, seed):
     """getGraphPatch_wMask (utils.py:1508-1696) driven as dataClasses.py:76-95 drives it: seeds drawn with
     np.random among the uncovered faces unless the previous patch proposed one; every patch is recorded."""
@@ -360,6 +396,8 @@ def main():
             net_case("torus640", xt, adjst, gtt, seed=1, multi_scale=False)
     if want("infer") and not F64:
         infer_case("ico3", x, adjs, ds, seed=0)
+    if want("msvertex"):
+        multiscale_vertex_case("ico3", add_noise(V, F), V, F, seed=0)
     if want("patch") and not F64:
         Vp, Fp = torus(24, 20)          # 960 faces, patches of 300 (min 120)
         patch_case("torus960", Fp, 300, 120, seed=11)

@@ -125,12 +125,12 @@ def reciprocal(x, name=None):
     return 1.0 / x
 
 
-def zeros_like(x, name=None):
-    return _t.zeros_like(x)
+def zeros_like(x, dtype=None, name=None):
+    return _t.zeros_like(x, dtype=dtype)
 
 
-def ones_like(x, name=None):
-    return _t.ones_like(x)
+def ones_like(x, dtype=None, name=None):
+    return _t.ones_like(x, dtype=dtype)
 
 
 def zeros(shape, dtype=None):
@@ -180,6 +180,13 @@ def multiply(a, b, name=None):
 
 
 def divide(a, b):
+    return a / b
+
+
+def div(a, b):
+    # tf.div: Python-2 division semantics, i.e. floor division for integer tensors
+    if not a.is_floating_point():
+        return _t.div(a, b, rounding_mode="floor")
     return a / b
 
 
