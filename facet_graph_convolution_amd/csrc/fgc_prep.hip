@@ -369,6 +369,23 @@ extern "C" int fgc_graph_patch(const int32_t* adj, int32_t n, int32_t K, int32_t
     return FGC_OK;
 }
 
+// utils.py:370-395
+extern "C" int fgc_vertices_faces(const int32_t* F, int32_t nf, int32_t nv, int32_t k_v, int32_t* out) {
+    FGC_CHECK_ARG(F && out && nf > 0 && nv > 0 && k_v > 0, "fgc_vertices_faces: bad arguments");
+    for (size_t t = 0; t < (size_t)nv * k_v; ++t) out[t] = -1;
+    std::vector<int> cnt(nv, 0);
+    for (int f = 0; f < nf; ++f) {
+        if (F[3 * (size_t)f] == -1) continue;
+        for (int t = 0; t < 3; ++t) {
+            const int v = F[3 * (size_t)f + t];
+            FGC_CHECK_ARG(v >= 0 && v < nv, "fgc_vertices_faces: face %d references vertex %d", f, v);
+            FGC_CHECK_ARG(cnt[v] < k_v, "fgc_vertices_faces: vertex %d is in more than %d faces", v, k_v);
+            out[(size_t)v * k_v + cnt[v]++] = f;
+        }
+    }
+    return FGC_OK;
+}
+
 // utils.py:91-183.  Faces in order; (v1,v2) and (v1,v3) are searched among v1's edges, (v2,v3) among v2's; a found
 // edge takes this face as its second face, a missing one is created in the order 12, 13, 23.
 extern "C" int fgc_edge_map(const uint32_t* F, int32_t nf, int32_t nv, int32_t max_edges, int32_t* e_map,

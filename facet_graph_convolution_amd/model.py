@@ -222,8 +222,15 @@ def custom_lin(input, out_channels):
 
 def custom_binary_tree_pooling(x, steps=1, pooltype='max'):
     """model.py:779-788.  steps=2 ('max') is what the network uses; other step counts chain 2:1 poolings."""
+    if pooltype == 'avg_ignore_zeros':      # model.py:792-814: inference-time pooling of positions / normals
+        if steps % 2 or x.requires_grad:
+            raise NotImplementedError("avg_ignore_zeros is built 4:1 per call and without a gradient")
+        xr = _rows(x)
+        for _ in range(steps // 2):
+            xr = ops.pool4_avg_iz(xr.contiguous())
+        return xr.unsqueeze(0)
     if pooltype != 'max':
-        raise NotImplementedError("only max pooling is on the denoising path (model.py:863,875)")
+        raise NotImplementedError("'max' (model.py:863,875) and 'avg_ignore_zeros' are built")
     xr = _rows(x)
     if steps % 2 == 0:
         for _ in range(steps // 2):

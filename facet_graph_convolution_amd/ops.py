@@ -300,3 +300,46 @@ def vertex_update(x, normals, e_map, v_e_map, iters, lmbd=1.0 / 18):
                                        ptr(e_map), e_map.shape[0], ptr(v_e_map), v_e_map.shape[1], int(iters),
                                        float(lmbd), stream_ptr()), "fgc_vertex_update")
     return out
+
+
+def pool4_avg_iz(x):
+    """custom_binary_tree_pooling(x, steps=2, 'avg_ignore_zeros') (model.py:792-814) on [n, c] rows."""
+    _req_cuda(x)
+    x = _f32c(x)
+    n, c = x.shape
+    y = torch.empty(n // 4, c, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_pool4_avg_iz(ptr(x), n, c, ptr(y), stream_ptr()), "fgc_pool4_avg_iz")
+    return y
+
+
+def face_centers(x, faces):
+    """Barycentres of faces [n0,3] (int, -1 = fake) of the vertices x [V,3] (train.py:1779-1787)."""
+    _req_cuda(x, faces)
+    x = _f32c(x)
+    faces = faces.to(torch.int32).contiguous()
+    out = torch.empty(faces.shape[0], 3, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_face_centers(ptr(x), x.shape[0], ptr(faces), faces.shape[0], ptr(out), stream_ptr()),
+          "fgc_face_centers")
+    return out
+
+
+def vertex_update_ms(x, normals, faces, v_faces, iters=(80, 20, 20)):
+    """update_position_MS (train.py:1668-1798), coarsening_steps = 2.  x [V,3]; normals = [n0 [N0,3], n1 [N0/4,3],
+    n2 [N0/16,3]]; faces int [N0,3] (-1 rows = fake nodes); v_faces int [V,K].  Returns (x_out [V,3], dx [3,V,3])."""
+    _req_cuda(x, faces, v_faces, *normals)
+    x = _f32c(x)
+    n0, n1, n2 = (_f32c(t.reshape(-1, 3)) for t in normals)
+    faces = faces.to(torch.int32).contiguous()
+    v_faces = v_faces.to(torch.int32).contiguous()
+    nv, N0 = x.shape[0], faces.shape[0]
+    if n0.shape[0] != N0 or n1.shape[0] * 4 != N0 or n2.shape[0] * 16 != N0:
+        raise ValueError("normals must have N0, N0/4 and N0/16 rows (N0 = %d)" % N0)
+    out = torch.empty_like(x)
+    dx = torch.empty(3, nv, 3, dtype=torch.float32, device=x.device)
+    nscr = 3 * (2 * nv + N0 + N0 // 4 + N0 // 16)
+    scr = torch.empty(nscr, dtype=torch.float32, device=x.device)
+    it = (C.c_int32 * 3)(*[int(i) for i in iters])
+    check(_lib.lib().fgc_vertex_update_ms(ptr(x), ptr(out), nv, ptr(faces), N0, ptr(v_faces), v_faces.shape[1], ptr(n0),
+                                          ptr(n1), ptr(n2), it, ptr(dx), ptr(scr), nscr, stream_ptr()),
+          "fgc_vertex_update_ms")
+    return out, dx

@@ -116,6 +116,29 @@ def update_position2(x, face_normals, edge_map, v_edges, iter_num=20, max_edges=
     return out.unsqueeze(0)
 
 
+def updateFacesCenter(vertices, faces, coarsening_steps):
+    """train.py:1768-1798: node centres of the three levels, [fpos0 [1,N0,3], fpos1 [1,N0/4,3], fpos2 [1,N0/16,3]]."""
+    from . import ops
+    if coarsening_steps != 2:
+        raise NotImplementedError("libfgc pools 4:1 (coarsening_steps = 2, settings.py:31)")
+    f0 = ops.face_centers(vertices.reshape(-1, 3), faces.reshape(-1, 3))
+    f1 = ops.pool4_avg_iz(f0)
+    f2 = ops.pool4_avg_iz(f1)
+    return [f0.unsqueeze(0), f1.unsqueeze(0), f2.unsqueeze(0)]
+
+
+def update_position_MS(x, face_normals_list, faces, v_faces0, coarsening_steps, iter_num_list=[80, 20, 20]):
+    """train.py:1668-1764, same arguments on torch GPU tensors: x [1,V,3], face_normals_list = [n0 [1,N0,3],
+    n1 [1,N0/4,3], n2 [1,N0/16,3]], faces int [1,N0,3] (fake nodes = -1 rows), v_faces0 int [1,V,K].  Returns
+    (x [1,V,3], [dx of the coarse, the middle and the fine stage, each [V,3]])."""
+    from . import ops
+    if coarsening_steps != 2 or len(face_normals_list) != 3:
+        raise NotImplementedError("three levels pooled 4:1, as the network has them (settings.py:31-32)")
+    out, dx = ops.vertex_update_ms(x.reshape(-1, 3), [t.reshape(-1, 3) for t in face_normals_list], faces.reshape(-1, 3),
+                                   v_faces0.reshape(x.reshape(-1, 3).shape[0], -1), iter_num_list)
+    return out.unsqueeze(0), [dx[0], dx[1], dx[2]]
+
+
 def inferNetOld(inputMesh, net_or_checkpoint, device="cuda", update_vertices=False):
     """train.py:29-144.  inputMesh: dataClasses.InferenceMesh.  Returns the predicted unit normals [F, 3] (numpy, face
     order); with update_vertices=True the reference's full return value (outPoints [V,3], predicted_normals): the

@@ -88,6 +88,28 @@ def getFacesLargeAdj(faces, K):
     return adj
 
 
+def getVerticesFaces(faces, k_v, vnum=0):
+    """utils.py:370-395: faces incident to every vertex (row indices of `faces`, -1 padded to k_v; rows starting with
+    -1 are fake faces and skipped), natively and bit-exact."""
+    from . import _lib
+    F = np.ascontiguousarray(np.asarray(faces).reshape(-1, 3), dtype=np.int32)
+    if vnum == 0:
+        vnum = int(F.max()) + 1
+    out = np.empty((int(vnum), int(k_v)), dtype=np.int32)
+    _lib.check(_lib.lib().fgc_vertices_faces(F.ctypes.data, F.shape[0], int(vnum), int(k_v), out.ctypes.data),
+               "fgc_vertices_faces")
+    return out
+
+
+def normalizePointSets(vl1, vl2):
+    """utils.py:2077-2104: both point sets divided by the bounding-box diagonal of their union (not centred)."""
+    vl1, vl2 = np.asarray(vl1), np.asarray(vl2)
+    lo = np.minimum(vl1.min(0), vl2.min(0))
+    hi = np.maximum(vl1.max(0), vl2.max(0))
+    diag = float(np.sqrt(((hi - lo).astype(np.float64) ** 2).sum()))
+    return vl1 / diag, vl2 / diag
+
+
 def getEdgeMap(faces, maxEdges=50):
     """utils.py:91-183: (e_map [E,4] = [v1, v2, f1, f2 or -1], v_e_map [V, maxEdges] edge ids per vertex, -1 padded),
     bit-exact (same visiting order), natively."""

@@ -115,6 +115,11 @@ int fgc_graph_patch(const int32_t* adj_h, int32_t n, int32_t K, int32_t nodes_nu
                     int32_t min_patch_size, int32_t* patch_adj_h, int32_t* old_index_h, int32_t* patch_n,
                     int32_t* next_seed);
 
+/* Faces incident to every vertex = getVerticesFaces (utils.py:370-395), host.  faces_h [nf,3] int32 with -1 rows for
+ * fake faces (skipped); v_faces_h [nv, k_v] receives the face (row) indices in face order, -1 padded.  -EINVAL if a
+ * vertex is in more than k_v faces (the reference raises IndexError). */
+int fgc_vertices_faces(const int32_t* faces_h, int32_t nf, int32_t nv, int32_t k_v, int32_t* v_faces_h);
+
 /* Edge map = getEdgeMap (utils.py:91-183), host.  e_map_h [3*nf, 4] receives [v1, v2, f1, f2] per edge (f2 = -1
  * on a boundary), *n_edges the number of edges written; v_e_map_h [nv, max_edges] the edge ids incident to every
  * vertex in creation order, -1 padded.  Same visiting order as the reference, so both tables are bit-identical to
@@ -311,6 +316,28 @@ int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_t count, in
 int fgc_vertex_update(const float* x, float* x_out, float* tmp, int32_t nv, const float* normals, int32_t nf,
                       const int32_t* e_map, int32_t ne, const int32_t* v_e_map, int32_t max_edges, int32_t iters,
                       float lambda, void* stream);
+
+/* 4:1 "average ignoring zero rows" pooling = custom_binary_tree_pooling(x, steps=2, 'avg_ignore_zeros')
+ * (model.py:792-814): two rounds of pairwise means in which a row that is zero in every channel is replaced by its
+ * partner first.  x [n, c] with n % 4 == 0 -> y [n/4, c]. */
+int fgc_pool4_avg_iz(const float* x, int32_t n, int32_t c, float* y, void* stream);
+
+/* Node centres of the finest level = first step of updateFacesCenter (train.py:1779-1787): barycentre of every face
+ * of faces [n0,3] (int32, -1 corners read a zero vertex) -> fpos [n0,3]. */
+int fgc_face_centers(const float* x, int32_t nv, const int32_t* faces, int32_t n0, float* fpos, void* stream);
+
+/* Multi-scale vertex update = update_position_MS with updateFacesCenter (train.py:1668-1798), coarsening_steps = 2.
+ * x [nv,3] positions; faces [n0,3] int32 in node order, -1 rows = fake nodes; v_faces [nv,k_v] finest-level node ids
+ * of every vertex, -1 padded; normals[s] [n0 / 4^s, 3] for s = 0,1,2.  Coarse to fine, iters[0] iterations with the
+ * level-2 nodes, iters[1] with level 1, iters[2] with level 0; in every iteration the node centres are recomputed
+ * from the current positions (face barycentres, then two avg_ignore_zeros poolings) and
+ *   x_v += (1 / #faces(v)) * sum_k n (n . (c - x_v)),  n, c of node floor(v_faces[v,k] / 4^s).
+ * x_out [nv,3] receives the result; dx_out (may be NULL) [3][nv,3] the displacement of each stage in execution
+ * order; scratch: at least 3*(nv*2 + n0 + n0/4 + n0/16) floats.  x may alias neither output. */
+int fgc_vertex_update_ms(const float* x, float* x_out, int32_t nv, const int32_t* faces, int32_t n0,
+                         const int32_t* v_faces, int32_t k_v, const float* normals0, const float* normals1,
+                         const float* normals2, const int32_t* iters, float* dx_out, float* scratch,
+                         size_t scratch_floats, void* stream);
 
 #ifdef __cplusplus
 }

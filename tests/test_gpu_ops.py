@@ -177,3 +177,35 @@ def test_vertex_update_large_mesh_against_oracle():
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
     # the update moves the noisy vertices towards the clean surface
     assert np.abs(got - V).mean() < 0.8 * np.abs(Vn - V).mean()
+
+
+def test_multiscale_vertex_update_matches_reference(golden_dir):
+    """avg_ignore_zeros pooling (model.py:792-814), updateFacesCenter and update_position_MS (train.py:1668-1798) on
+    the coarsened icosphere (fake nodes included), (2,1,1) and (80,20,20) iterations.  fp32 tolerance 3e-6 on
+    coordinates of a unit-size mesh (reference fp32 vs its float64 run: 1.2e-7)."""
+    import os
+    from facet_graph_convolution_amd import model as M, train as T
+    z = np.load(os.path.join(golden_dir, "msvertex_ico3.npz"))
+    z64 = np.load(os.path.join(golden_dir, "msvertex_ico3_f64.npz"))
+    dev = DEV
+    n0 = torch.tensor(z["n0"], device=dev)[None]
+    p1 = M.custom_binary_tree_pooling(n0, steps=2, pooltype="avg_ignore_zeros")
+    n1 = M.normalizeTensor(p1)
+    n2 = M.normalizeTensor(M.custom_binary_tree_pooling(n1, steps=2, pooltype="avg_ignore_zeros"))
+    np.testing.assert_allclose(n1[0].cpu().numpy(), z["n1"], atol=2e-6)
+    np.testing.assert_allclose(n2[0].cpu().numpy(), z["n2"], atol=2e-6)
+    x = torch.tensor(z["verts_norm"], device=dev)[None]
+    faces = torch.tensor(z["faces_perm"], device=dev)[None]
+    vf = torch.tensor(z["v_faces"], device=dev)[None]
+    c = T.updateFacesCenter(x, faces, 2)
+    for k in range(3):
+        np.testing.assert_allclose(c[k][0].cpu().numpy(), z["fpos%d" % k], atol=1e-7)
+    nl = [torch.tensor(z["n%d" % k], device=dev)[None] for k in range(3)]
+    for its in ((2, 1, 1), (80, 20, 20)):
+        key = "_".join(map(str, its))
+        xo, dxl = T.update_position_MS(x, nl, faces, vf, 2, iter_num_list=list(its))
+        assert xo.shape == x.shape and len(dxl) == 3
+        np.testing.assert_allclose(xo[0].cpu().numpy(), z["x_" + key], atol=3e-6)
+        for k in range(3):
+            np.testing.assert_allclose(dxl[k].cpu().numpy(), z["dx%d_%s" % (k, key)], atol=3e-6)
+    assert np.abs(xo[0].cpu().numpy().astype(np.float64) - z64["x_80_20_20"]).max() < 3e-6

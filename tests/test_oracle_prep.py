@@ -80,3 +80,32 @@ def test_graph_patch_restatement_matches_reference(golden_dir, tag):
         a, o, nx = O.graph_patch_wmask(z["adj"], int(z["patch_size"]), int(z["seed%d" % k]), z["mask%d" % k],
                                        int(z["min_patch_size"]))
         assert np.array_equal(a, z["adj%d" % k]) and np.array_equal(o, z["old%d" % k]) and nx == int(z["next%d" % k])
+
+
+def test_multiscale_vertex_restatements_match_reference(golden_dir):
+    """getVerticesFaces, normalizePointSets (utils.py:370-395, 2077-2104); avg_ignore_zeros pooling (model.py:792-814);
+    updateFacesCenter and update_position_MS (train.py:1668-1798) after (2,1,1) and (80,20,20) iterations."""
+    import torch
+    from oracle import model_ref as R
+    z = np.load(os.path.join(golden_dir, "msvertex_ico3.npz"))
+    z64 = np.load(os.path.join(golden_dir, "msvertex_ico3_f64.npz"))
+    assert np.array_equal(O.vertices_faces(z["faces_perm"], 25, z["verts"].shape[0]), z["v_faces"])
+    assert np.abs(O.normalize_point_sets(z["verts"], z["verts"])[0] - z["verts_norm"]).max() < 1e-7
+    n0 = torch.tensor(z["n0"])[None]
+    n1 = R.normalizeTensor(R.avg_ignore_zeros_pool(n0, 2))
+    n2 = R.normalizeTensor(R.avg_ignore_zeros_pool(n1, 2))
+    np.testing.assert_allclose(n1[0].numpy(), z["n1"], atol=1e-7)
+    np.testing.assert_allclose(n2[0].numpy(), z["n2"], atol=1e-7)
+    c = R.update_faces_center(torch.tensor(z["verts_norm"]), z["faces_perm"], 2)
+    for k in range(3):
+        np.testing.assert_allclose(c[k][0].numpy(), z["fpos%d" % k], atol=1e-7)
+    for its in ((2, 1, 1), (80, 20, 20)):
+        key = "_".join(map(str, its))
+        x, dxl = R.update_position_MS(torch.tensor(z["verts_norm"]), [z["n0"], z["n1"], z["n2"]], z["faces_perm"],
+                                      z["v_faces"], 2, its)
+        np.testing.assert_allclose(x.numpy(), z["x_" + key], atol=1e-6)
+        for k in range(3):
+            np.testing.assert_allclose(dxl[k].numpy(), z["dx%d_%s" % (k, key)], atol=1e-6)
+    x64, _ = R.update_position_MS(torch.tensor(z["verts_norm"]).double(), [z64["n0"], z64["n1"], z64["n2"]],
+                                  z["faces_perm"], z["v_faces"], 2, (80, 20, 20))
+    np.testing.assert_allclose(x64.numpy(), z64["x_80_20_20"], atol=1e-12)

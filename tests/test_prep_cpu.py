@@ -236,3 +236,15 @@ def test_patch_mode_replays_the_reference_patch_sequence(golden_dir):
         assert im.in_list[k].shape[1] == im.adj_list[k][0].shape[1] and im.in_list[k].shape[1] % 16 == 0
         covered[im.patch_indices[k]] = True
     assert covered.all() and im.normals.shape == (F.shape[0], 3)
+
+
+def test_native_vertices_faces_is_bit_exact(golden_dir):
+    """fgc_vertices_faces vs the reference's getVerticesFaces (utils.py:370-395) on faces in node order with fake rows."""
+    z = np.load(os.path.join(golden_dir, "msvertex_ico3.npz"))
+    assert (z["faces_perm"][:, 0] == -1).sum() > 0
+    vf = utils.getVerticesFaces(z["faces_perm"], 25, z["verts"].shape[0])
+    assert vf.dtype == np.int32 and np.array_equal(vf, z["v_faces"])
+    with pytest.raises(RuntimeError, match="more than 3 faces"):
+        utils.getVerticesFaces(z["faces_perm"], 3, z["verts"].shape[0])
+    a, b = utils.normalizePointSets(z["verts"], z["verts"] * 2)
+    assert abs(np.linalg.norm(np.maximum(a.max(0), b.max(0)) - np.minimum(a.min(0), b.min(0))) - 1) < 1e-6
