@@ -36,6 +36,12 @@ class PreprocessedData(object):
         self.coarseningLvlNum = coarseningLvlNum
         self.minPatchSize = MIN_PATCH_SIZE
         self.seed = 0
+        # multi-scale vertex pipeline (addMeshWithVertices, dataClasses.py:236-456)
+        self.v_list = []
+        self.faces_list = []
+        self.v_faces_list = []
+        self.vOldInd_list = []
+        self.fOldInd_list = []
 
     def addMesh_TimeEfficient(self, V0, faces0, GTV=None, seed=None, parents=None):
         """dataClasses.py:34-233: whole mesh (:172-233) or, above maxSize faces, breadth-first patches (:76-171)."""
@@ -72,6 +78,36 @@ class PreprocessedData(object):
                                 GTf_normals0[fOldInd] if GTf_normals0 is not None else None, fOldInd, seed, parents)
         else:
             self._add_graph(f_adj0, f_normals_pos, GTf_normals0, [], seed, parents)
+
+    def addMeshWithVertices(self, V0, faces0, GTV=None, seed=None, parents=None):
+        """dataClasses.py:236-456, whole-mesh branch (:374-440): what the multi-scale network + update_position_MS
+        consume.  On top of addMesh_TimeEfficient: the faces padded with -1 rows for the fake nodes and re-ordered like
+        the nodes (faces_list), the node ids of the faces around every vertex (v_faces_list, 25 slots) and the vertices
+        divided by the bounding-box diagonal (v_list).  Returns (vNum, facesNum)."""
+        V0 = np.asarray(V0, dtype=np.float32)
+        faces0 = np.asarray(faces0)
+        if faces0.shape[0] > self.maxSize:
+            raise NotImplementedError("the multi-scale pipeline is built for whole meshes (patches: dataClasses.py:270-372)")
+        first = len(self.in_list)
+        self.addMesh_TimeEfficient(V0, faces0, GTV=GTV, seed=seed, parents=parents)
+        oldToNew = self.permutations[first]
+        new_N = len(oldToNew)
+        newToOld = np.empty(new_N, dtype=np.int64)
+        newToOld[oldToNew] = np.arange(new_N)
+        faces_p = np.concatenate((faces0.astype(np.int64), -np.ones((new_N - faces0.shape[0], 3), dtype=np.int64)),
+                                 axis=0)[newToOld]
+        v_faces = utils.getVerticesFaces(faces_p, 25, V0.shape[0])
+        if GTV is not None:
+            Vn, GTn = utils.normalizePointSets(V0, np.asarray(GTV, dtype=np.float32))
+            self.__dict__.setdefault("gtv_list", []).append(GTn[np.newaxis])
+        else:
+            Vn, _ = utils.normalizePointSets(V0, V0)
+        self.v_list.append(Vn[np.newaxis])
+        self.faces_list.append(faces_p[np.newaxis])
+        self.v_faces_list.append(v_faces[np.newaxis])
+        self.fOldInd_list.append([])
+        self.vOldInd_list.append([])
+        return V0.shape[0], faces0.shape[0]
 
     def _add_graph(self, f_adj, f_normals_pos, GTf_normals, patch_index, seed, parents):
         """One mesh or one patch: coarsen, pad with fake nodes, reorder, append (dataClasses.py:106-171,172-233)."""
@@ -138,3 +174,15 @@ class InferenceMesh(PreprocessedData):
         self.faces = np.asarray(faces)
         self.addMesh_TimeEfficient(V, faces, seed=seed, parents=parents)
         self.normals = utils.computeFacesNormals(self.vertices[0], self.faces)
+
+    def addMeshWithVertices(self, V, faces=None, seed=None, parents=None):
+        """dataClasses.py:521-531 (file form addMeshWithVertices(inputFilePath, filename), or arrays)."""
+        if isinstance(V, str):
+            V, _, _, faces, _ = utils.load_mesh(V, faces, 0, False)
+        V = np.asarray(V, dtype=np.float32)
+        self.fNum, self.vNum = np.asarray(faces).shape[0], V.shape[0]
+        PreprocessedData.addMeshWithVertices(self, V, faces, seed=seed, parents=parents)
+        self.vertices = V[np.newaxis]
+        self.faces = np.asarray(faces)
+        self.normals = utils.computeFacesNormals(V, self.faces)
+        return self.vNum, self.fNum

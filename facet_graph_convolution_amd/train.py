@@ -139,6 +139,55 @@ def update_position_MS(x, face_normals_list, faces, v_faces0, coarsening_steps, 
     return out.unsqueeze(0), [dx[0], dx[1], dx[2]]
 
 
+def inferNet(inputMesh, net_or_checkpoint, device="cuda"):
+    """train.py:147-376, whole-mesh case: the multi-scale network (three heads), its three normal fields normalised,
+    update_position_MS with [80, 20, 20] iterations.  inputMesh: InferenceMesh filled by addMeshWithVertices; the
+    network must have been built with multi_scale=True.  Returns the reference's 9-tuple
+    (points, points_mid, points_coarse, fine / mid / coarse normals [F,3] in face order, fine / mid / coarse positions
+    [F,3]; as in the reference the three position arrays are the input barycentre channels)."""
+    from . import ops
+    if isinstance(net_or_checkpoint, FacetDenoiser):
+        net = net_or_checkpoint
+    else:
+        net = FacetDenoiser(device, multi_scale=True)
+        load_checkpoint(net_or_checkpoint, net)
+    if not net.multi_scale:
+        raise ValueError("inferNet needs a network with the multi-scale heads (multi_scale=True)")
+    if len(inputMesh.in_list) != 1 or not inputMesh.v_list:
+        raise NotImplementedError("whole meshes prepared by addMeshWithVertices")
+    x, adjs = inputMesh.in_list[0], inputMesh.adj_list[0]
+    net.bind_mesh(x, adjs)
+    net.forward(rotate=False)
+    B = net.buffers
+    dev = net.device
+    n0 = B["nconv"]                                              # normalizeTensor(y0), done by forward()
+    n1 = _normalize_rows_like_reference(B["y1"])                 # train.py:192-193
+    n2 = _normalize_rows_like_reference(B["y2"])
+    xp = torch.as_tensor(inputMesh.v_list[0][0], dtype=torch.float32, device=dev)
+    faces = torch.as_tensor(np.asarray(inputMesh.faces_list[0][0]).astype(np.int32), device=dev)
+    vf = torch.as_tensor(np.asarray(inputMesh.v_faces_list[0][0]).astype(np.int32), device=dev)
+    pts, dx = ops.vertex_update_ms(xp, [n0, n1, n2], faces, vf, (80, 20, 20))
+    pts_mid = pts - dx[2]                                        # train.py:249-250
+    pts_coarse = pts_mid - dx[1]
+    perm = torch.as_tensor(np.asarray(inputMesh.permutations[0]).astype(np.int64), device=dev)
+    nf = inputMesh.num_faces[0]
+    up1 = n1.repeat_interleave(4, dim=0)                         # custom_upsampling, train.py:222-223
+    up2 = n2.repeat_interleave(16, dim=0)
+    fine = n0[perm][:nf]
+    mid = _normalize_rows_like_reference(up1)[perm][:nf]
+    coarse = _normalize_rows_like_reference(up2)[perm][:nf]
+    pos = torch.as_tensor(np.asarray(x)[0, :, 3:].astype(np.float32), device=dev)[perm][:nf]   # train.py:288,296-297
+    torch.cuda.synchronize()
+    c = lambda t: t.cpu().numpy()
+    return c(pts), c(pts_mid), c(pts_coarse), c(fine), c(mid), c(coarse), c(pos), c(pos), c(pos)
+
+
+def _normalize_rows_like_reference(t):
+    """utils.normalizeTensor (utils.py:1700-1715) on [n,3] rows through the library's kernels."""
+    from .model import normalizeTensor
+    return normalizeTensor(t.unsqueeze(0))[0]
+
+
 def inferNetOld(inputMesh, net_or_checkpoint, device="cuda", update_vertices=False):
     """train.py:29-144.  inputMesh: dataClasses.InferenceMesh.  Returns the predicted unit normals [F, 3] (numpy, face
     order); with update_vertices=True the reference's full return value (outPoints [V,3], predicted_normals): the
