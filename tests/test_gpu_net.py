@@ -283,3 +283,17 @@ def test_tiny_mesh_one_coarsest_node():
     for i, (g, p) in enumerate(zip(net.params.grads, params)):
         scale = max(p.grad.abs().max().item(), 1e-3)
         assert (g.cpu() - p.grad).abs().max().item() / scale < 2e-3, "grad %d" % i
+
+
+@pytest.mark.parametrize("switches", [
+    {"FGC_NO_W8": "1", "FGC_NO_K1DEEP": "1", "FGC_NO_TNSTREAM": "1", "FGC_NO_NARROW": "1"},   # 4-wave / generic kernels
+    {"FGC_NO_W8FAST": "1", "FGC_NO_K1M": "1"},                                               # 8-wave generic, VALU logits
+])
+def test_fallback_kernels_pass_the_smoke_check(switches):
+    """The fast paths have switches (FGC_NO_*); with them off the same train step runs on the fallback kernels that
+    odd shapes and long edge lists take, and must still match the oracle (__graft_entry__.smoke)."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=repo,
+                         env=dict(os.environ, **switches), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
