@@ -52,6 +52,7 @@ _SIGS = {
     "fgc_last_error": (C.c_char_p, []),
     "fgc_version": (C.c_int, []),
     "fgc_struct_size": (C.c_size_t, [C.c_int32]),
+    "fgc_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "fgc_profile_enable": (C.c_int, [C.c_int]),
     "fgc_profile_tag": (C.c_int, [C.c_char_p]),
     "fgc_profile_collect": (C.c_int, [C.c_char_p, C.c_int32]),

@@ -155,3 +155,40 @@ extern "C" int fgc_csr_transpose(const int32_t* rowptr_h, const int32_t* col_h, 
     }
     return FGC_OK;
 }
+
+// ---- CRC-32C, slicing-by-8 --------------------------------------------------------------
+namespace fgc {
+struct Crc32cTables {
+    uint32_t t[8][256];
+    Crc32cTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xffu];
+    }
+};
+}  // namespace fgc
+
+extern "C" uint32_t fgc_crc32c(uint32_t crc, const void* data, size_t n) {
+    static const fgc::Crc32cTables T;
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = ~crc;
+    while (n && (reinterpret_cast<uintptr_t>(p) & 7u)) {
+        c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xffu];
+        --n;
+    }
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        w ^= c;
+        c = T.t[7][w & 0xff] ^ T.t[6][(w >> 8) & 0xff] ^ T.t[5][(w >> 16) & 0xff] ^ T.t[4][(w >> 24) & 0xff] ^
+            T.t[3][(w >> 32) & 0xff] ^ T.t[2][(w >> 40) & 0xff] ^ T.t[1][(w >> 48) & 0xff] ^ T.t[0][w >> 56];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xffu];
+    return ~c;
+}

@@ -39,7 +39,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("noisy_dir")
     ap.add_argument("results_dir")
-    ap.add_argument("network", help="checkpoint written by train.save_checkpoint / trainNet")
+    ap.add_argument("network", help="TensorFlow checkpoint directory / prefix (as the reference writes them) or a .pt file")
     ap.add_argument("--overwrite", action="store_true")
     args = ap.parse_args(argv)
     from .net import FacetDenoiser

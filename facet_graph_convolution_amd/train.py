@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, tfckpt
 from .net import FacetDenoiser, COST_SAMPLES
 from .settings import SAVEITER
 from .utils import rand_rotation_matrix
@@ -39,14 +39,26 @@ def faceNormalsLoss(fn, gt_fn):
 
 
 def save_checkpoint(path, net, iteration):
-    """Weights + Adam moments + step (what tf.train.Saver keeps by default, train.py:522,551-552)."""
+    """saver.save(sess, path, global_step=iteration) (train.py:551-552,626): weights + Adam moments + step as the
+    TensorFlow bundle `<path>-<iteration>.index/.data-00000-of-00001` plus the `checkpoint` state file (tfckpt.py).
+    A path ending in ".pt" keeps the same state as one torch file instead."""
     os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    if not path.endswith(".pt"):
+        return tfckpt.save_network(path, net, global_step=iteration)
     P = net.params
     torch.save({"theta": P.theta.cpu(), "m": P.m.cpu(), "v": P.v.cpu(), "step": P.step, "iteration": iteration,
                 "multi_scale": net.multi_scale}, path)
+    return path
 
 
 def load_checkpoint(path, net):
+    """saver.restore (train.py:79-87,522-534).  path: a TensorFlow checkpoint prefix, its .index file or a directory
+    with a `checkpoint` state file - written by the reference or by save_checkpoint - or a ".pt" file.  Returns the
+    iteration the checkpoint was taken at."""
+    if tfckpt.is_tf_checkpoint(path):
+        return tfckpt.load_network(path, net)
+    if not os.path.isfile(path):
+        raise FileNotFoundError("no checkpoint at %s" % path)
     ck = torch.load(path, map_location="cpu")
     P = net.params
     if ck["theta"].numel() != P.theta.numel():
@@ -67,9 +79,17 @@ def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device
         meshes.append((trainSet.in_list[i], trainSet.adj_list[i], trainSet.gt_list[i]))
     net = FacetDenoiser(device, seed=seed)
     start = 0
-    ckpt = os.path.join(network_path, net_name + ".pt") if network_path else None
-    if ckpt and os.path.exists(ckpt):
-        start = load_checkpoint(ckpt, net)
+    ckpt = os.path.join(network_path, net_name) if network_path else None
+    if ckpt:
+        # resume from the directory's latest checkpoint if it belongs to this network (train.py:525-533)
+        st = tfckpt.get_checkpoint_state(network_path)
+        if st and st.model_checkpoint_path:
+            split = os.path.basename(st.model_checkpoint_path).split('-')
+            if split[0] == net_name:
+                load_checkpoint(st.model_checkpoint_path, net)
+                start = int(split[1]) if len(split) > 1 and split[1].isdigit() else 0
+        elif os.path.exists(ckpt + ".pt"):
+            start = load_checkpoint(ckpt + ".pt", net)
     rs = np.random.RandomState(seed + 1)
     evalStepNum = 50
     lossArray = np.zeros([max(num_iterations // evalStepNum, 1), 2])
@@ -108,7 +128,7 @@ def update_position2(x, face_normals, edge_map, v_edges, iter_num=20, max_edges=
     """train.py:1467-1557, same argument layout on torch GPU tensors: x [1,V,3], face_normals [1,F,3], edge_map
     int [1,E,4], v_edges int [1,V,max_edges] (-1 = unused slot); returns the updated positions [1,V,3].
     lambda = 1/18 as in the reference (:1469)."""
-    from . import ops
+    from . import ops, tfckpt
     if v_edges.shape[-1] != max_edges:
         raise ValueError("v_edges has %d slots per vertex, max_edges says %d" % (v_edges.shape[-1], max_edges))
     out = ops.vertex_update(x.reshape(-1, 3), face_normals.reshape(-1, 3), edge_map.reshape(-1, 4),
@@ -118,7 +138,7 @@ def update_position2(x, face_normals, edge_map, v_edges, iter_num=20, max_edges=
 
 def updateFacesCenter(vertices, faces, coarsening_steps):
     """train.py:1768-1798: node centres of the three levels, [fpos0 [1,N0,3], fpos1 [1,N0/4,3], fpos2 [1,N0/16,3]]."""
-    from . import ops
+    from . import ops, tfckpt
     if coarsening_steps != 2:
         raise NotImplementedError("libfgc pools 4:1 (coarsening_steps = 2, settings.py:31)")
     f0 = ops.face_centers(vertices.reshape(-1, 3), faces.reshape(-1, 3))
@@ -131,7 +151,7 @@ def update_position_MS(x, face_normals_list, faces, v_faces0, coarsening_steps, 
     """train.py:1668-1764, same arguments on torch GPU tensors: x [1,V,3], face_normals_list = [n0 [1,N0,3],
     n1 [1,N0/4,3], n2 [1,N0/16,3]], faces int [1,N0,3] (fake nodes = -1 rows), v_faces0 int [1,V,K].  Returns
     (x [1,V,3], [dx of the coarse, the middle and the fine stage, each [V,3]])."""
-    from . import ops
+    from . import ops, tfckpt
     if coarsening_steps != 2 or len(face_normals_list) != 3:
         raise NotImplementedError("three levels pooled 4:1, as the network has them (settings.py:31-32)")
     out, dx = ops.vertex_update_ms(x.reshape(-1, 3), [t.reshape(-1, 3) for t in face_normals_list], faces.reshape(-1, 3),
@@ -145,7 +165,7 @@ def inferNet(inputMesh, net_or_checkpoint, device="cuda"):
     network must have been built with multi_scale=True.  Returns the reference's 9-tuple
     (points, points_mid, points_coarse, fine / mid / coarse normals [F,3] in face order, fine / mid / coarse positions
     [F,3]; as in the reference the three position arrays are the input barycentre channels)."""
-    from . import ops
+    from . import ops, tfckpt
     if isinstance(net_or_checkpoint, FacetDenoiser):
         net = net_or_checkpoint
     else:

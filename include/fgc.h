@@ -339,6 +339,15 @@ int fgc_vertex_update_ms(const float* x, float* x_out, int32_t nv, const int32_t
                          const float* normals2, const int32_t* iters, float* dx_out, float* scratch,
                          size_t scratch_floats, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Checkpoint files (CPU; HOST pointers)
+ * ---------------------------------------------------------------------------------- */
+
+/* CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of data[0..n) continued from crc (0 to start): the
+ * checksum of the TensorFlow tensor-bundle files tf.train.Saver writes and restores (train.py:79-87,522-534,
+ * 551-552): every block of `<prefix>.index` and every tensor of `<prefix>.data-*` carries it.  Unmasked value. */
+uint32_t fgc_crc32c(uint32_t crc, const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,9 +71,18 @@ def test_train_and_infer_drivers(tmp_path):
     from oracle import model_ref as R
     ref = R.update_position2(torch.tensor(im.vertices[0]), pred, im.edge_map[0], im.v_e_map[0], 60).numpy()
     np.testing.assert_allclose(pts, ref, rtol=0, atol=2e-6)
+    # trainNet leaves what saver.save leaves (train.py:551-552,626): t-110.index/.data + the `checkpoint` file
+    assert sorted(os.listdir(str(tmp_path))) == ["checkpoint", "t-110.data-00000-of-00001", "t-110.index", "t.csv"]
     net2 = FacetDenoiser("cuda:0")
-    assert load_checkpoint(os.path.join(str(tmp_path), "t.pt"), net2) == 110
-    assert torch.equal(net2.params.theta, net.params.theta)
+    assert load_checkpoint(str(tmp_path), net2) == 110
+    assert torch.equal(net2.params.theta, net.params.theta) and torch.equal(net2.params.v, net.params.v)
+    assert net2.params.step == 110
+    # a second call resumes from it (train.py:525-533): 10 more steps = the same as 120 in one go on Adam's clock
+    net3, _ = trainNet(ts, 10, network_path=str(tmp_path), net_name="t", log=lambda *_: None)
+    assert net3.params.step == 120 and os.path.exists(os.path.join(str(tmp_path), "t-120.index"))
+    # another network's checkpoint in the directory is not picked up
+    net4, _ = trainNet(ts, 1, network_path=str(tmp_path), net_name="u", log=lambda *_: None)
+    assert net4.params.step == 1
 
 
 def test_multiscale_heads_train_through_the_operator_api(golden_dir):
@@ -120,6 +129,11 @@ def test_obj_in_obj_out_inference(tmp_path):
     ckpt = str(tmp_path / "net.pt")
     save_checkpoint(ckpt, net, 0)
     infer.main([str(noisy), str(tmp_path / "out"), ckpt])
+    # the same weights as a TensorFlow-format checkpoint directory give the same mesh
+    save_checkpoint(str(tmp_path / "tfnet" / "net"), net, 500)
+    infer.main([str(noisy), str(tmp_path / "out_tf"), str(tmp_path / "tfnet")])
+    assert open(str(tmp_path / "out" / "ball_denoised.obj")).read() == \
+        open(str(tmp_path / "out_tf" / "ball_denoised.obj")).read()
     V2, _, _, F2, _ = utils.load_mesh(str(tmp_path / "out"), "ball_denoised.obj")
     assert np.array_equal(F2, F) and V2.shape == V.shape and np.isfinite(V2).all()
     nrm = np.loadtxt(str(tmp_path / "out" / "ball_normals.txt"))
