@@ -13,6 +13,12 @@ constexpr int MLP_T = FGC_MLP_T;   // rows per tile (forward kernel)
 constexpr int MLP_RT = MLP_T / 16;
 constexpr int MLP_COUT_MAX = 4;
 constexpr int MLP_THREADS = 256;
+// LDS row strides (floats).  ds_read_b32 / ds_write_b32 bank = dword % 32 within a 32-lane half, ds_read_b128 bank =
+// dword % 64 within a 16-lane group: a stride == 4 mod 8 keeps both the row-per-lane b128 reads (16 rows -> 16
+// distinct 16-byte slots) and the 4-rows-apart b32 accesses of lanes l, l+16 (4 * stride == 16 mod 32) conflict free.
+constexpr int MLP_XPAD = 4;    // x tile rows: kpad + 4
+constexpr int MLP_DHS = 20;    // transposed dh rows
+
 
 // W1 [cin, hidden] -> Wp1[k/4][hidden][k%4], k padded to a multiple of 16 with zeros
 __global__ void mlp_pack_kernel(const float* __restrict__ W1, float* __restrict__ Wp, int cin, int kpad, int hidden) {
@@ -39,12 +45,16 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int n, 
 }
 
 // hidden pre-activation slab for column tile ct: h[rt] (C layout: col = lane&15, row = rt*16 + (lane>>4)*4 + reg)
-template <int RT>
+// KG > 0: the number of 16-wide k groups is known at compile time (the loop unrolls and all fragment loads are issued
+// before the first MFMA); KG == 0: runtime kg
+template <int RT, int KG = 0>
 __device__ __forceinline__ void hidden_slab(const float* xt, int xs, int kg, const f32x4* __restrict__ Wp4, int hidden,
                                             int ct, f32x4 (&h)[RT]) {
     const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int r = 0; r < RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KG > 0) kg = KG;
+#pragma unroll KG > 0 ? KG : 1
     for (int g = 0; g < kg; ++g) {
         const f32x4 b = Wp4[(size_t)(g * 4 + lq) * hidden + ct * 16 + lr];
         f32x4 a[RT];
@@ -66,7 +76,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
                                                               const float* __restrict__ b2, float alpha,
                                                               float* __restrict__ y, float* __restrict__ abs_partial) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int xs = kpad + 8;  // == 8 mod 16
+    const int xs = kpad + MLP_XPAD;
     float* xt = reinterpret_cast<float*>(smem_raw);
     float* ypart = xt + MLP_T * xs;  // [4 waves][MLP_T][4]
     float* red = ypart + 4 * MLP_T * 4;  // [4]
@@ -164,6 +174,9 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 #ifndef FGC_MLP_BWD_T
 #define FGC_MLP_BWD_T 32
 #endif
+#ifndef FGC_MLP_BWD_KG
+#define FGC_MLP_BWD_KG(mt) 0
+#endif
 #ifndef FGC_MLP_BWD_WAVES
 #define FGC_MLP_BWD_WAVES 2
 #endif
@@ -178,16 +191,37 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
     float* __restrict__ dW1_slab /* [gridDim.x][cin][hidden] */, float* __restrict__ db1_slab /* [gridDim.x][hidden] */,
     float* __restrict__ dW2_slab /* [gridDim.x][hidden][4] */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int xs = kpad + 8;
+    constexpr int KP = MLP_BWD_MT * 16;                             // == kpad
+    constexpr int HCW = 4 * MLP_BWD_CTW * 16;                       // hidden columns of this workgroup
+    constexpr int WLD = HCW + 1;                                    // f32x4 per k-group row of the weight slice
+    constexpr int XPT = BWD_T * KP / MLP_THREADS;                   // x elements per thread per tile
+    constexpr int xs = KP + MLP_XPAD;      // kpad == KP: strides are compile-time so LDS offsets fold into the instructions
     float* xt = reinterpret_cast<float*>(smem_raw);                // [BWD_T][xs]
     float* dyt = xt + BWD_T * xs;                                   // [BWD_T][4]
-    float* dht = dyt + BWD_T * 4;                                   // [4 waves][BWD_T][24]  (stride 24 == 8 mod 16)
-    float* dxp = dht + 4 * BWD_T * 24;                              // [4 waves][BWD_T][kpad+1]  ([1][..] when MT > 2)
+    float* dht = dyt + BWD_T * 4;                                   // [4 waves][BWD_T][MLP_DHS]
+    float* dxp = dht + 4 * BWD_T * MLP_DHS;                              // [4 waves][BWD_T][kpad+4]  ([1][..] when MT > 2)
+    float* Ws = dxp + (MLP_BWD_MT <= 2 ? 4 : 1) * BWD_T * (KP + MLP_XPAD) + 3;  // [KP/4][WLD][4], 16-byte aligned below
+    Ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Ws)) & ~(uintptr_t)15);
+    float* b1s = Ws + (KP / 4) * WLD * 4;                           // [HCW]
+    float* W2s = b1s + HCW;                                         // [HCW][4]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int kg = kpad >> 4;
+    constexpr int kg = MLP_BWD_MT;
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(Wp);
-    const int hc0 = blockIdx.y * (4 * MLP_BWD_CTW * 16);
+    const int hc0 = blockIdx.y * HCW;
     const int ntiles = (n + BWD_T - 1) / BWD_T;
+
+    // this workgroup's weight slice stays in LDS for the whole walk: W1 columns [hc0, hc0+HCW) in the packed
+    // [k/4][col][k%4] layout (the +1 row pad spreads the transposed reads of the dx product over the banks), b1, W2
+    f32x4* Ws4 = reinterpret_cast<f32x4*>(Ws);
+    for (int t = threadIdx.x; t < (KP / 4) * HCW; t += MLP_THREADS) {
+        const int k4 = t / HCW, jl = t % HCW;
+        Ws4[k4 * WLD + jl] = Wp4[(size_t)k4 * hidden + hc0 + jl];
+    }
+    for (int t = threadIdx.x; t < HCW; t += MLP_THREADS) {
+        b1s[t] = b1[hc0 + t];
+#pragma unroll
+        for (int o = 0; o < MLP_COUT_MAX; ++o) W2s[t * 4 + o] = o < cout ? W2[(size_t)(hc0 + t) * cout + o] : 0.f;
+    }
 
     f32x4 dW1acc[MLP_BWD_CTW][MLP_BWD_MT];
     float dW2acc[MLP_BWD_CTW][MLP_COUT_MAX];
@@ -201,14 +235,42 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
         for (int m = 0; m < MLP_BWD_MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // the next tile's rows travel through registers while the current tile is being worked on: addresses are clamped
+    // so the loads are unconditional (no exec-masked load, no early wait); out-of-range elements are zeroed on store
+    float xpre[XPT], dypre;
+    auto fetch_tile = [&](int tl) {
+        const int r0 = tl * BWD_T;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int t = threadIdx.x + i * MLP_THREADS;
+            const int r = t / KP, c = t % KP;
+            xpre[i] = x[(size_t)min(r0 + r, n - 1) * cin + min(c, cin - 1)];
+        }
+        const int t = threadIdx.x & (BWD_T * 4 - 1);
+        dypre = dy[(size_t)min(r0 + (t >> 2), n - 1) * cout + min(t & 3, cout - 1)];
+    };
+    auto store_tile = [&](int tl) {
+        const int r0 = tl * BWD_T;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int t = threadIdx.x + i * MLP_THREADS;
+            const int r = t / KP, c = t % KP;
+            xt[r * xs + c] = (r0 + r < n && c < cin) ? xpre[i] : 0.f;
+        }
+        if (threadIdx.x < BWD_T * 4) {
+            const int t = threadIdx.x;
+            dyt[t] = (r0 + (t >> 2) < n && (t & 3) < cout) ? dypre : 0.f;
+        }
+    };
+    constexpr bool PREFETCH = XPT <= 8;     // the 128-wide head has no registers to spare for it
+    if (PREFETCH && (int)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * BWD_T;
         __syncthreads();
-        load_x_tile<BWD_T>(x, n, cin, kpad, xs, row0, xt);
-        for (int t = threadIdx.x; t < BWD_T * 4; t += MLP_THREADS) {
-            const int r = t >> 2, o = t & 3;
-            dyt[t] = (row0 + r < n && o < cout) ? dy[(size_t)(row0 + r) * cout + o] : 0.f;
-        }
+        if (!PREFETCH) fetch_tile(tile);
+        store_tile(tile);
+        if (PREFETCH && tile + (int)gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
         __syncthreads();
         f32x4 dxacc[BWD_RT][MLP_BWD_MT];
 #pragma unroll
@@ -222,14 +284,11 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
             // overlap their loads and the live fragments of all of them push the kernel past 256 registers
             // (384 = one wave per SIMD, every memory wait exposed)
             __builtin_amdgcn_sched_barrier(0);
-            const int ct = (hc0 >> 4) + wave * MLP_BWD_CTW + c;
-            const int col = ct * 16 + lr;
+            const int ctl = wave * MLP_BWD_CTW + c;          // column tile within the workgroup's slice
             f32x4 h[BWD_RT];
-            hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
-            const float bb = b1[col];
-            float w2[MLP_COUT_MAX];
-#pragma unroll
-            for (int o = 0; o < MLP_COUT_MAX; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
+            hidden_slab<BWD_RT, FGC_MLP_BWD_KG(MLP_BWD_MT)>(xt, xs, kg, Ws4, WLD, ctl, h);
+            const float bb = b1s[ctl * 16 + lr];
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(W2s + (ctl * 16 + lr) * 4);
             f32x4 dh[BWD_RT];
 #pragma unroll
             for (int r = 0; r < BWD_RT; ++r)
@@ -264,21 +323,24 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
                     }
                 }
             // dx += dh[T x 16] * W1^T[16 x cin]: transpose dh through LDS into the A-fragment layout
-            float* dhw = dht + wave * BWD_T * 24;
+            float* dhw = dht + wave * BWD_T * MLP_DHS;
 #pragma unroll
             for (int r = 0; r < BWD_RT; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dhw[(r * 16 + lq * 4 + t) * 24 + lr] = dh[r][t];
+                for (int t = 0; t < 4; ++t) dhw[(r * 16 + lq * 4 + t) * MLP_DHS + lr] = dh[r][t];
             // same wave wrote and reads: LDS ops of one wave are ordered; the compiler inserts the lgkmcnt wait
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
             for (int m = 0; m < MLP_BWD_MT; ++m) {
+                // b[t] = W1[m*16+lr][slice col ctl*16 + lq*4 + t] out of the packed slice (zero beyond cin)
                 const int cc = m * 16 + lr;
-                f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (cc < cin) b = *reinterpret_cast<const f32x4*>(W1 + (size_t)cc * hidden + ct * 16 + lq * 4);
+                const float* wrow = Ws + ((cc >> 2) * WLD + ctl * 16 + lq * 4) * 4 + (cc & 3);
+                f32x4 b;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = wrow[t * 4];
                 f32x4 a[BWD_RT];
 #pragma unroll
-                for (int r = 0; r < BWD_RT; ++r) a[r] = *reinterpret_cast<const f32x4*>(dhw + (r * 16 + lr) * 24 + lq * 4);
+                for (int r = 0; r < BWD_RT; ++r) a[r] = *reinterpret_cast<const f32x4*>(dhw + (r * 16 + lr) * MLP_DHS + lq * 4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -287,7 +349,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
             }
         }
         // reduce dx over the 4 waves (fixed order) and write this hidden-range's slab
-        const int dxs = kpad + 1;
+        constexpr int dxs = KP + MLP_XPAD;
         if constexpr (MLP_BWD_MT <= 2) {
             float* dxw = dxp + wave * BWD_T * dxs;
 #pragma unroll
@@ -297,12 +359,28 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dxw[(r * 16 + lq * 4 + t) * dxs + m * 16 + lr] = dxacc[r][m][t];
             __syncthreads();
-            for (int t = threadIdx.x; t < BWD_T * cin; t += MLP_THREADS) {
-                const int r = t / cin, c = t % cin;
-                if (row0 + r < n) {
-                    const float v = (dxp[(0 * BWD_T + r) * dxs + c] + dxp[(1 * BWD_T + r) * dxs + c]) +
-                                    (dxp[(2 * BWD_T + r) * dxs + c] + dxp[(3 * BWD_T + r) * dxs + c]);
-                    dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = v;
+            if (cin == KP) {
+                // full-width rows: four floats per thread, one 16-byte store, no division by a runtime cin
+#pragma unroll
+                for (int i = 0; i < BWD_T * KP / 4 / MLP_THREADS; ++i) {
+                    const int t = threadIdx.x + i * MLP_THREADS;
+                    const int r = t / (KP / 4), c = (t % (KP / 4)) * 4;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(dxp + (0 * BWD_T + r) * dxs + c);
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(dxp + (1 * BWD_T + r) * dxs + c);
+                    const f32x4 p2 = *reinterpret_cast<const f32x4*>(dxp + (2 * BWD_T + r) * dxs + c);
+                    const f32x4 p3 = *reinterpret_cast<const f32x4*>(dxp + (3 * BWD_T + r) * dxs + c);
+                    const f32x4 v = (p0 + p1) + (p2 + p3);
+                    if (row0 + r < n)
+                        *reinterpret_cast<f32x4*>(dx_slab + ((size_t)blockIdx.y * n + row0 + r) * KP + c) = v;
+                }
+            } else {
+                for (int t = threadIdx.x; t < BWD_T * cin; t += MLP_THREADS) {
+                    const int r = t / cin, c = t % cin;
+                    if (row0 + r < n) {
+                        const float v = (dxp[(0 * BWD_T + r) * dxs + c] + dxp[(1 * BWD_T + r) * dxs + c]) +
+                                        (dxp[(2 * BWD_T + r) * dxs + c] + dxp[(3 * BWD_T + r) * dxs + c]);
+                        dx_slab[((size_t)blockIdx.y * n + row0 + r) * cin + c] = v;
+                    }
                 }
             }
         } else {
@@ -417,7 +495,7 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
     float* Wp = (float*)workspace;
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_fwd/pack");
-    const size_t smem = (size_t)(MLP_T * (kpad + 8) + 4 * MLP_T * 4 + 4) * 4;
+    const size_t smem = (size_t)(MLP_T * (kpad + MLP_XPAD) + 4 * MLP_T * 4 + 4) * 4;
     FGC_LAUNCH("mlp_fwd_kernel", st, mlp_fwd_kernel, dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, x, n, cin, kpad, hidden, cout,
                        Wp, b1, W2, b2, alpha, y, abs_partial);
     FGC_CHECK_LAUNCH("fgc_mlp_fwd");
@@ -456,7 +534,9 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
 
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
-    const size_t smem = (size_t)(BWD_T * (kpad + 8) + BWD_T * 4 + 4 * BWD_T * 24 + (ctw == 4 ? 4 : 1) * BWD_T * (kpad + 1)) * 4;
+    const int hcw = 64 * ctw;   // + the workgroup's weight slice [kpad/4][hcw+1][4], b1 [hcw], W2 [hcw][4]
+    const size_t smem = (size_t)(BWD_T * (kpad + MLP_XPAD) + BWD_T * 4 + 4 * BWD_T * MLP_DHS + (ctw == 4 ? 4 : 1) * BWD_T * (kpad + MLP_XPAD) +
+                                 4 + (kpad / 4) * (hcw + 1) * 4 + hcw * 5) * 4;
 #define FGC_MLP_BWD_LAUNCH(MT, CTW)                                                                                       \
     do {                                                                                                                  \
         hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
