@@ -69,7 +69,10 @@ __device__ __forceinline__ void hidden_slab(const float* xt, int xs, int kg, con
     }
 }
 
-__global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __restrict__ x, int n, int cin, int kpad,
+// KG = kpad / 16 when the next column tile's weight fragments are prefetched (narrow inputs), 0 = generic
+// CO = number of output columns carried in registers (cout <= CO <= CO)
+template <int KG, int CO>
+__global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(const float* __restrict__ x, int n, int cin, int kpad,
                                                               int hidden, int cout, const float* __restrict__ Wp,
                                                               const float* __restrict__ b1,
                                                               const float* __restrict__ W2,
@@ -88,22 +91,59 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
     const int kg = kpad >> 4;
     const int nct = hidden >> 4;
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(Wp);
-    float yp[MLP_RT][4][MLP_COUT_MAX];
+    float yp[MLP_RT][4][CO];
 #pragma unroll
     for (int r = 0; r < MLP_RT; ++r)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int o = 0; o < MLP_COUT_MAX; ++o) yp[r][t][o] = 0.f;
+            for (int o = 0; o < CO; ++o) yp[r][t][o] = 0.f;
 
+    constexpr int NB = KG > 0 ? KG : 1;
+    f32x4 bnext[NB];
+    float bbn = 0.f, w2n[CO];
+    auto fetch_weights = [&](int ct) {   // W1 fragments, b1 and W2 rows of column tile ct (clamped: always a valid load)
+        ct = min(ct, nct - 1);
+#pragma unroll
+        for (int g = 0; g < NB; ++g) bnext[g] = Wp4[(size_t)(g * 4 + lq) * hidden + ct * 16 + lr];
+        bbn = b1[ct * 16 + lr];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) w2n[o] = W2[(size_t)(ct * 16 + lr) * cout + min(o, cout - 1)];
+    };
+    if constexpr (KG > 0) fetch_weights(wave);
     for (int ct = wave; ct < nct; ct += 4) {
         f32x4 h[MLP_RT];
-        hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
-        const int col = ct * 16 + lr;
-        const float bb = b1[col];
-        float w2[MLP_COUT_MAX];
+        float bb, w2[CO];
+        if constexpr (KG > 0) {
+            // this tile's weights arrived while the previous one was computed; ask for the next tile's before the MFMAs
+            f32x4 bcur[NB];
 #pragma unroll
-        for (int o = 0; o < MLP_COUT_MAX; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
+            for (int g = 0; g < NB; ++g) bcur[g] = bnext[g];
+            bb = bbn;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) w2[o] = o < cout ? w2n[o] : 0.f;
+            fetch_weights(ct + 4);
+#pragma unroll
+            for (int r = 0; r < MLP_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                f32x4 a[MLP_RT];
+#pragma unroll
+                for (int r = 0; r < MLP_RT; ++r)
+                    a[r] = *reinterpret_cast<const f32x4*>(xt + (r * 16 + lr) * xs + g * 16 + lq * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < MLP_RT; ++r)
+                        h[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], bcur[g][t], h[r], 0, 0, 0);
+            }
+        } else {
+            hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
+            const int col = ct * 16 + lr;
+            bb = b1[col];
+#pragma unroll
+            for (int o = 0; o < CO; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < MLP_RT; ++r)
 #pragma unroll
@@ -111,7 +151,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
                 float v = h[r][t] + bb;
                 v = fmaxf(v, 0.f) - alpha * fmaxf(-v, 0.f);
 #pragma unroll
-                for (int o = 0; o < MLP_COUT_MAX; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
+                for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
             }
     }
     // reduce over the 16 column lanes
@@ -120,7 +160,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int o = 0; o < MLP_COUT_MAX; ++o) {
+            for (int o = 0; o < CO; ++o) {
                 float v = yp[r][t][o];
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
@@ -134,7 +174,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int o = 0; o < MLP_COUT_MAX; ++o)
+                for (int o = 0; o < CO; ++o)
                     ypart[(wave * MLP_T + r * 16 + lq * 4 + t) * 4 + o] = yp[r][t][o];
     }
     __syncthreads();
@@ -183,7 +223,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_fwd_kernel(const float* __res
 constexpr int BWD_T = FGC_MLP_BWD_T;   // rows per tile of the backward kernel
 constexpr int BWD_RT = BWD_T / 16;
 
-template <int MLP_BWD_MT, int MLP_BWD_CTW>
+template <int MLP_BWD_MT, int MLP_BWD_CTW, int CO>
 __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int n, int cin, int kpad, int hidden, int cout,
     const float* __restrict__ Wp, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -220,17 +260,17 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
     for (int t = threadIdx.x; t < HCW; t += MLP_THREADS) {
         b1s[t] = b1[hc0 + t];
 #pragma unroll
-        for (int o = 0; o < MLP_COUT_MAX; ++o) W2s[t * 4 + o] = o < cout ? W2[(size_t)(hc0 + t) * cout + o] : 0.f;
+        for (int o = 0; o < 4; ++o) W2s[t * 4 + o] = o < cout ? W2[(size_t)(hc0 + t) * cout + o] : 0.f;
     }
 
     f32x4 dW1acc[MLP_BWD_CTW][MLP_BWD_MT];
-    float dW2acc[MLP_BWD_CTW][MLP_COUT_MAX];
+    float dW2acc[MLP_BWD_CTW][CO];
     float db1acc[MLP_BWD_CTW];
 #pragma unroll
     for (int c = 0; c < MLP_BWD_CTW; ++c) {
         db1acc[c] = 0.f;
 #pragma unroll
-        for (int o = 0; o < MLP_COUT_MAX; ++o) dW2acc[c][o] = 0.f;
+        for (int o = 0; o < CO; ++o) dW2acc[c][o] = 0.f;
 #pragma unroll
         for (int m = 0; m < MLP_BWD_MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -302,7 +342,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
                     const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
                     float g = 0.f;
 #pragma unroll
-                    for (int o = 0; o < MLP_COUT_MAX; ++o) {
+                    for (int o = 0; o < CO; ++o) {
                         g = fmaf(dyr[o], w2[o], g);
                         dW2acc[c][o] = fmaf(hact, dyr[o], dW2acc[c][o]);
                     }
@@ -424,7 +464,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
         v += __shfl_xor(v, 32);
         if (lq == 0) db1_slab[(size_t)blockIdx.x * hidden + col] = v;
 #pragma unroll
-        for (int o = 0; o < MLP_COUT_MAX; ++o) {
+        for (int o = 0; o < CO; ++o) {
             float w = dW2acc[c][o];
             w += __shfl_xor(w, 16);
             w += __shfl_xor(w, 32);
@@ -496,8 +536,19 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
     FGC_CHECK_LAUNCH("fgc_mlp_fwd/pack");
     const size_t smem = (size_t)(MLP_T * (kpad + MLP_XPAD) + 4 * MLP_T * 4 + 4) * 4;
-    FGC_LAUNCH("mlp_fwd_kernel", st, mlp_fwd_kernel, dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, x, n, cin, kpad, hidden, cout,
-                       Wp, b1, W2, b2, alpha, y, abs_partial);
+#define FGC_MLP_FWD_LAUNCH(KG)                                                                                     \
+    do {                                                                                                           \
+        if (cout <= 3)                                                                                             \
+            FGC_LAUNCH("mlp_fwd_kernel", st, (mlp_fwd_kernel<KG, 3>), dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, x, n, \
+                       cin, kpad, hidden, cout, Wp, b1, W2, b2, alpha, y, abs_partial);                            \
+        else                                                                                                       \
+            FGC_LAUNCH("mlp_fwd_kernel", st, (mlp_fwd_kernel<KG, 4>), dim3(cdiv(n, MLP_T)), dim3(MLP_THREADS), smem, x, n, \
+                       cin, kpad, hidden, cout, Wp, b1, W2, b2, alpha, y, abs_partial);                            \
+    } while (0)
+    if (kpad == 16) FGC_MLP_FWD_LAUNCH(1);
+    else if (kpad == 32) FGC_MLP_FWD_LAUNCH(2);
+    else FGC_MLP_FWD_LAUNCH(0);
+#undef FGC_MLP_FWD_LAUNCH
     FGC_CHECK_LAUNCH("fgc_mlp_fwd");
     return FGC_OK;
 }
@@ -539,9 +590,17 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                                  4 + (kpad / 4) * (hcw + 1) * 4 + hcw * 5) * 4;
 #define FGC_MLP_BWD_LAUNCH(MT, CTW)                                                                                       \
     do {                                                                                                                  \
-        hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        FGC_LAUNCH("mlp_bwd_kernel", st, (mlp_bwd_kernel<MT, CTW>), dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy, n, cin,  \
-                   kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);                     \
+        if (cout <= 3) {                                                                                                  \
+            hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)smem);                                                                               \
+            FGC_LAUNCH("mlp_bwd_kernel", st, (mlp_bwd_kernel<MT, CTW, 3>), dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy,  \
+                       n, cin, kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);         \
+        } else {                                                                                                          \
+            hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)smem);                                                                               \
+            FGC_LAUNCH("mlp_bwd_kernel", st, (mlp_bwd_kernel<MT, CTW, 4>), dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy,  \
+                       n, cin, kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);         \
+        }                                                                                                                 \
     } while (0)
     if (ctw == 4) FGC_MLP_BWD_LAUNCH(2, 4);
     else if (ctw == 2) FGC_MLP_BWD_LAUNCH(4, 2);
