@@ -46,6 +46,7 @@ class ConvBwdIO(C.Structure):
 
 
 CONV_PACKED = 1
+CONV_DEFER_REDUCE = 2
 
 
 _SIGS = {
@@ -88,6 +89,10 @@ _SIGS = {
     "fgc_conv_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "fgc_conv_bwd_needs_exchange": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO)]),
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fgc_conv_pack": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "fgc_conv_bwd_reduce": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)),
+                                      C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "fgc_mlp_num_partials": (C.c_int32, [C.c_int32]),
     "fgc_mlp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "fgc_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -18,6 +18,7 @@
 #include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
 #include "fgc_reduce.h"
+#include "fgc_pack.h"
 
 namespace fgc {
 
@@ -68,20 +69,32 @@ __global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_logit_weight_kernel(const float* __restrict__ W0, float* __restrict__ Wq, int cin, int cout,
                                          int opad, int kc, int kpass, int passes) {
-    const size_t total = (size_t)passes * opad * kpass;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 3;
-        const size_t v4 = idx >> 2;
-        const int kk = v4 % kpass;
-        const size_t rest = v4 / kpass;
-        const int o4 = rest % (opad >> 2);
-        const int pass = (int)(rest / (opad >> 2));
-        const int o = o4 * 4 + e;
-        const int m = kk / kc, cl = kk % kc;
-        const int c = pass * kc + cl;
-        Wq[idx] = (m < FGC_M && o < cout && c < cin) ? W0[((size_t)m * cout + o) * cin + c] : 0.f;
-    }
+    pack_logit_weight_body(W0, Wq, cin, cout, opad, kc, kpass, passes, blockIdx.x, gridDim.x);
+}
+
+// every packed operand of several layers in one launch (fgc_conv_pack)
+struct PackJob {
+    const float* W0;
+    float* dst;
+    int kind;   // 0: forward operand, 1: data-gradient operand (transposed), 2: d-logits operand
+    int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
+    int block0;
+};
+constexpr int PACK_MAX_JOBS = 24;
+struct PackJobs {
+    PackJob job[PACK_MAX_JOBS];
+    int njobs, nblocks;
+};
+__global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < PACK_MAX_JOBS; ++t)
+        if (t < J.njobs && (int)blockIdx.x >= J.job[t].block0) q = t;
+    const PackJob& j = J.job[q];
+    const int bid = blockIdx.x - j.block0;
+    const int nb = (q + 1 < J.njobs ? J.job[q + 1].block0 : J.nblocks) - j.block0;
+    if (j.kind == 2) pack_logit_weight_body(j.W0, j.dst, j.cin, j.cout, j.opad, j.kc, j.kpass, j.passes, bid, nb);
+    else pack_weight_body(j.W0, j.dst, j.cin, j.cout, j.kdim, j.ncols, j.npad, j.kc, j.kpass, j.passes, j.kind, bid, nb);
 }
 
 struct LogitParams {
@@ -1099,6 +1112,21 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     return w;
 }
 
+static int tn_rows_per_slab(int n, int splits) { return cdiv(cdiv(n, splits), 4) * 4; }
+
+// the five fixed-order sums behind a layer's parameter gradients (slabs of the weight-gradient GEMM, db and dc partials)
+static void conv_param_jobs(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, const BwdWorkspace& w, RedJob* jobs) {
+    const int cin = d->c0 + d->c1, cout = d->cout;
+    const int P = FGC_M * cout, PL = P + 24;
+    const int ns = cdiv(d->n, tn_rows_per_slab(d->n, w.splitW));
+    const size_t sst = (size_t)PL * cin;
+    jobs[0] = RedJob{w.slab, sst, ns, P * cin, cin, cin, io->dW0, w.rtmp};
+    jobs[1] = RedJob{w.slab + (size_t)P * cin, sst, ns, FGC_M * cin, cin, cin, io->du};
+    jobs[2] = RedJob{w.slab + (size_t)(P + 12) * cin, sst, ns, FGC_M * cin, cin, cin, io->dv};
+    jobs[3] = RedJob{w.db_part, (size_t)cout, w.nb_db, cout, cout, cout, io->db};
+    jobs[4] = RedJob{w.dc_part, (size_t)12, cdiv(d->n, TILE), 12, 12, FGC_M, io->dc};
+}
+
 }  // namespace fgc
 
 using namespace fgc;
@@ -1185,7 +1213,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             if (rc) return rc;
         }
         if (stages & 8) {
-            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, st);
+            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, (io->flags & FGC_CONV_DEFER_REDUCE) ? 1 : 7, nullptr,
+                                   st);
             if (rc) return rc;
         }
         return FGC_OK;
@@ -1270,7 +1299,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         // one GEMM over the rows of r = [9*cout aggregate columns | da | dg]: rows 0..P-1 of the product are dW0^T
         // blocks, rows P..P+8 du, rows P+12..P+20 dv
         const int P = FGC_M * cout, PL = P + 24;
-        const int rps = cdiv(cdiv(d->n, w.splitW), 4) * 4;
+        const int rps = tn_rows_per_slab(d->n, w.splitW);
         const int ns = cdiv(d->n, rps);
         const dim3 g1(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
@@ -1282,17 +1311,108 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                         d->c0, d->c1, d->shift, d->n, rps, w.slab);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
         // every parameter gradient of the layer in two launches (fixed summation order).  The db / dc partials were
-        // left in the workspace by stages 1 and 2: a staged caller keeps the workspace untouched between its calls.
-        const size_t sst = (size_t)PL * cin;
-        const RedJob jobs[5] = {
-            {w.slab, sst, ns, P * cin, cin, cin, io->dW0},
-            {w.slab + (size_t)P * cin, sst, ns, FGC_M * cin, cin, cin, io->du},
-            {w.slab + (size_t)(P + 12) * cin, sst, ns, FGC_M * cin, cin, cin, io->dv},
-            {w.db_part, (size_t)cout, w.nb_db, cout, cout, cout, io->db},
-            {w.dc_part, (size_t)12, cdiv(d->n, TILE), 12, 12, FGC_M, io->dc},
-        };
-        rc = reduce_jobs("reduce:params", jobs, 5, w.rtmp, st);
+        // left in the workspace by stages 1 and 2: a staged caller keeps the workspace untouched between its calls;
+        // with FGC_CONV_DEFER_REDUCE also until fgc_conv_bwd_reduce sums the layers of the whole network at once.
+        if (!(io->flags & FGC_CONV_DEFER_REDUCE)) {
+            RedJob jobs[5];
+            conv_param_jobs(d, io, w, jobs);
+            rc = reduce_jobs("reduce:params", jobs, 5, nullptr, st);
+            if (rc) return rc;
+        }
+    }
+    return FGC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// whole-network helpers: one launch where every layer used to bring its own
+// ---------------------------------------------------------------------------------------------
+extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* fwd_ws,
+                             void* const* bwd_ws, int32_t count, void* stream) {
+    FGC_CHECK_ARG(descs && count >= 0, "fgc_conv_pack: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    PackJobs J;
+    J.njobs = 0;
+    J.nblocks = 0;
+    auto flush = [&]() {
+        if (J.njobs == 0) return;
+        FGC_LAUNCH("pack_many_kernel", st, pack_many_kernel, dim3(J.nblocks), dim3(256), 0, J);
+        J.njobs = 0;
+        J.nblocks = 0;
+    };
+    auto add = [&](const PackJob& j, size_t total) {
+        if (J.njobs == PACK_MAX_JOBS) flush();
+        PackJob& q = J.job[J.njobs++];
+        q = j;
+        q.block0 = J.nblocks;
+        J.nblocks += cdiv((int)total, 1024);
+    };
+    for (int i = 0; i < count; ++i) {
+        const fgc_conv_desc* d = descs[i];
+        int rc = validate_conv_desc(d, "fgc_conv_pack");
         if (rc) return rc;
+        const int cin = d->c0 + d->c1, cout = d->cout;
+        const bool narrow = narrow_supported(d);
+        if (fwd_ws && fwd_ws[i] && !narrow) {
+            const ConvGeom g = conv_geom(cin, cout);
+            FGC_CHECK_ARG((uintptr_t)fwd_ws[i] % 16 == 0, "fgc_conv_pack: workspace %d misaligned", i);
+            add(PackJob{d->W0, (float*)fwd_ws[i], 0, cin, cout, cin, cout, g.npad, g.kc, g.kpass, g.passes, 0, 0},
+                (size_t)g.passes * g.kpass * g.npad);
+        }
+        const bool narrow_bwd = narrow && ios && ios[i] && ios[i]->dx0 == nullptr;   // vector-ALU path: nothing to pack
+        if (bwd_ws && bwd_ws[i] && !narrow_bwd) {
+            FGC_CHECK_ARG((uintptr_t)bwd_ws[i] % 16 == 0, "fgc_conv_pack: workspace %d misaligned", i);
+            const BwdWorkspace w = plan_bwd(d, (char*)bwd_ws[i]);
+            const ConvGeom g1 = conv_geom(cin, cout), g2 = conv_geom(cout, cin);
+            const int opad = (cout + 15) / 16 * 16;
+            add(PackJob{d->W0, w.Wq, 2, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
+                (size_t)g1.passes * opad * g1.kpass);
+            add(PackJob{d->W0, w.Wpt, 1, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},
+                (size_t)g2.passes * g2.kpass * g2.npad);
+        }
+    }
+    flush();
+    FGC_CHECK_LAUNCH("fgc_conv_pack");
+    return FGC_OK;
+}
+
+extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios,
+                                   void* const* bwd_ws, int32_t count, void* stream) {
+    FGC_CHECK_ARG(descs && ios && bwd_ws && count >= 0, "fgc_conv_bwd_reduce: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    RedJob jobs[RED_MAX_JOBS];
+    int nj = 0, rc = 0;
+    auto flush = [&]() {
+        const int r = nj ? reduce_jobs("reduce:params", jobs, nj, nullptr, st) : FGC_OK;
+        nj = 0;
+        return r;
+    };
+    for (int i = 0; i < count; ++i) {
+        const fgc_conv_desc* d = descs[i];
+        const fgc_conv_bwd_io* io = ios[i];
+        rc = validate_conv_desc(d, "fgc_conv_bwd_reduce");
+        if (rc) return rc;
+        FGC_CHECK_ARG(io && bwd_ws[i] && io->dW0 && io->db && io->du && io->dc && io->dv,
+                      "fgc_conv_bwd_reduce: layer %d: null io / workspace / gradient pointer", i);
+        const BwdWorkspace w = plan_bwd(d, (char*)bwd_ws[i]);
+        if (nj + 5 > RED_MAX_JOBS && (rc = flush())) return rc;
+        if (io->dx0 == nullptr && w.narrow) {
+            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, 0, jobs + nj, st);
+            if (rc) return rc;
+            nj += 3;
+        } else {
+            conv_param_jobs(d, io, w, jobs + nj);
+            nj += 5;
+        }
+    }
+    if ((rc = flush())) return rc;
+    // the narrow first layer turns its reduced sums into dW0 / du / dv / dc
+    for (int i = 0; i < count; ++i) {
+        const BwdWorkspace w = plan_bwd(descs[i], (char*)bwd_ws[i]);
+        if (ios[i]->dx0 == nullptr && w.narrow) {
+            rc = narrow_bwd_params(descs[i], ios[i], w.narrow, w.db_part, w.nb_db, 4, nullptr, st);
+            if (rc) return rc;
+        }
     }
     return FGC_OK;
 }

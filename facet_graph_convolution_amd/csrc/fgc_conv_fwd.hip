@@ -5,6 +5,7 @@
 
 #include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
+#include "fgc_pack.h"
 
 namespace fgc {
 
@@ -16,22 +17,7 @@ namespace fgc {
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ W0, float* __restrict__ Wp, int cin, int cout,
                                    int kdim, int ncols, int npad, int kc, int kpass, int passes, int transposed) {
-    const size_t total = (size_t)passes * kpass * npad;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 3;
-        const size_t v4 = idx >> 2;
-        const int colp = v4 % npad;
-        const int kk = (int)(v4 / npad) * 4 + e;
-        const int pass = kk / kpass, kin = kk % kpass;
-        const int m = kin / kc, cl = kin % kc;
-        const int kch = pass * kc + cl;
-        float val = 0.f;
-        if (m < FGC_M && kch < kdim && colp < ncols) {
-            val = transposed ? W0[((size_t)m * cout + kch) * cin + colp] : W0[((size_t)m * cout + colp) * cin + kch];
-        }
-        Wp[idx] = val;
-    }
+    pack_weight_body(W0, Wp, cin, cout, kdim, ncols, npad, kc, kpass, passes, transposed, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -422,7 +422,7 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
 
 // stage 8: dW0 = sum_i s_i (x) z_i through the streaming GEMM, then every partial in two reduction launches
 int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
-                      int nb_db, hipStream_t st) {
+                      int nb_db, int parts, RedJob* jobs_out, hipStream_t st) {
     const int cin = d->c0, cout = d->cout, zld = narrow_zld(cin), CIN = narrow_cin_pad(cin);
     const int nblk = cdiv(d->n, NB);
     const int splits = narrow_splits(d);
@@ -434,19 +434,28 @@ int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     float* rtmp = uvc + NARROW_PART + 64;
     const int rps = cdiv(cdiv(d->n, splits), 4) * 4;
     const int ns = cdiv(d->n, rps);
-    int rc = launch_gemm_tn_stream("gemm_tn_kernel:dW", zbuf, zld, zld, io->ds, cout, d->n, rps, ns, slab, st);
-    if (rc) return rc;
+    int rc = 0;
+    if (parts & 1) {
+        rc = launch_gemm_tn_stream("gemm_tn_kernel:dW", zbuf, zld, zld, io->ds, cout, d->n, rps, ns, slab, st);
+        if (rc) return rc;
+    }
     const RedJob jobs[3] = {
-        {slab, (size_t)zld * cout, ns, zld * cout, cout, cout, T},
+        {slab, (size_t)zld * cout, ns, zld * cout, cout, cout, T, rtmp},
         {part, (size_t)NARROW_PART, nblk, NARROW_PART, NARROW_PART, NARROW_PART, uvc},
         {db_part, (size_t)cout, nb_db, cout, cout, cout, io->db},
     };
-    rc = reduce_jobs("reduce:params", jobs, 3, rtmp, st);
-    if (rc) return rc;
-    const int total = FGC_M * cout * cin;
-    FGC_LAUNCH("narrow_finish_kernel", st, narrow_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, uvc, T, CIN, cin,
-               cout, io->du, io->dv, io->dc, io->dW0);
-    FGC_CHECK_LAUNCH("narrow_finish_kernel");
+    if (jobs_out)
+        for (int q = 0; q < 3; ++q) jobs_out[q] = jobs[q];
+    if (parts & 2) {
+        rc = reduce_jobs("reduce:params", jobs, 3, nullptr, st);
+        if (rc) return rc;
+    }
+    if (parts & 4) {
+        const int total = FGC_M * cout * cin;
+        FGC_LAUNCH("narrow_finish_kernel", st, narrow_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, uvc, T, CIN, cin,
+                   cout, io->du, io->dv, io->dc, io->dW0);
+        FGC_CHECK_LAUNCH("narrow_finish_kernel");
+    }
     return FGC_OK;
 }
 

@@ -4,7 +4,7 @@
 
 namespace fgc {
 constexpr int RED_GROUP = 64;  // slabs summed by one workgroup
-constexpr int RED_MAX_JOBS = 6;
+constexpr int RED_MAX_JOBS = 48;  // one launch pair covers the parameter gradients of a whole network (5 per layer)
 // floats of scratch reduce_slabs needs
 static inline size_t reduce_tmp_floats(int nslabs, size_t count) {
     size_t tot = 0;
@@ -30,7 +30,10 @@ struct RedJob {
     int count;           // elements per slab that are reduced (j < count)
     int in_ld, out_ld;   // as in reduce_slabs
     float* out;
+    float* tmp = nullptr;   // when set: this job's (and the following jobs') stage-1 results go here instead of
+                            // continuing in the scratch of the job before
 };
-// scratch: sum over jobs of reduce_tmp_floats(nslabs, count) (an upper bound: at most RED_GROUP * count per job)
+// scratch: sum over jobs of reduce_tmp_floats(nslabs, count) (an upper bound: at most RED_GROUP * count per job);
+// tmp may be NULL when the first job names its own
 int reduce_jobs(const char* what, const RedJob* jobs, int njobs, float* tmp, hipStream_t st);
 }  // namespace fgc

@@ -40,21 +40,27 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const float* __restri
     }
 }
 
-struct RedJobs {
-    RedJob job[RED_MAX_JOBS];
-    float* stage_out[RED_MAX_JOBS];   // where this stage writes (tmp, or the job's out when `fin`)
-    int fin[RED_MAX_JOBS];
-    int block0[RED_MAX_JOBS + 1];     // first workgroup of each job
-    int xblocks[RED_MAX_JOBS];        // workgroups along the element axis
-    int group[RED_MAX_JOBS];          // slabs per workgroup (RED_GROUP unless the job has more than RED_GROUP^2 slabs)
+// The job table travels as a kernel argument and every workgroup scans it for its job: a short table (MAXJ = 6) for the
+// few-jobs-many-workgroups calls, the long one only for the whole-network call.
+template <int MAXJ>
+struct RedJobsT {
+    RedJob job[MAXJ];
+    float* stage_out[MAXJ];   // where this stage writes (tmp, or the job's out when `fin`)
+    int fin[MAXJ];
+    int block0[MAXJ + 1];     // first workgroup of each job
+    int xblocks[MAXJ];        // workgroups along the element axis
+    int group[MAXJ];          // slabs per workgroup (RED_GROUP unless the job has more than RED_GROUP^2 slabs)
     int njobs;
 };
+constexpr int RED_FEW_JOBS = 6;
+static_assert(sizeof(RedJobsT<RED_MAX_JOBS>) <= 4096, "the job table travels as a kernel argument");
 
-__global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobs J) {
+template <int MAXJ>
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobsT<MAXJ> J) {
     __shared__ float part[4][64];
     int q = 0;
 #pragma unroll
-    for (int t = 1; t < RED_MAX_JOBS; ++t)
+    for (int t = 1; t < MAXJ; ++t)
         if (t < J.njobs && (int)blockIdx.x >= J.block0[t]) q = t;
     const RedJob& job = J.job[q];
     const int b = blockIdx.x - J.block0[q];
@@ -92,24 +98,25 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobs J) {
     }
 }
 
-int reduce_jobs(const char* what, const RedJob* jobs, int njobs, float* tmp, hipStream_t st) {
-    if (njobs <= 0) return FGC_OK;
-    if (njobs > RED_MAX_JOBS) {
-        set_error("reduce_jobs: %d jobs (max %d)", njobs, RED_MAX_JOBS);
-        return FGC_EINVAL;
-    }
-    RedJobs A, B;
+template <int MAXJ>
+static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, float* tmp, hipStream_t st) {
+    RedJobsT<MAXJ> A, B;
     A.njobs = njobs;
     B.njobs = 0;
     int nb = 0, nb2 = 0;
     float* t = tmp;
     for (int q = 0; q < njobs; ++q) {
         const RedJob& j = jobs[q];
+        if (j.tmp) t = j.tmp;
         // two stages always suffice: very long slab lists get proportionally larger groups
         const int group = std::max(RED_GROUP, (j.nslabs + RED_GROUP - 1) / RED_GROUP);
         const int groups = (j.nslabs + group - 1) / group;
         if (j.nslabs <= 0 || j.count <= 0) {
             set_error("reduce_jobs: job %d has %d slabs of %d elements", q, j.nslabs, j.count);
+            return FGC_EINVAL;
+        }
+        if (groups > 1 && !t) {
+            set_error("reduce_jobs: job %d needs scratch and none was given", q);
             return FGC_EINVAL;
         }
         A.job[q] = j;
@@ -135,13 +142,23 @@ int reduce_jobs(const char* what, const RedJob* jobs, int njobs, float* tmp, hip
         }
     }
     A.block0[njobs] = nb;
-    FGC_LAUNCH(what, st, reduce_jobs_kernel, dim3(nb), dim3(256), 0, A);
+    FGC_LAUNCH(what, st, reduce_jobs_kernel<MAXJ>, dim3(nb), dim3(256), 0, A);
     if (B.njobs) {
         B.block0[B.njobs] = nb2;
-        FGC_LAUNCH(what, st, reduce_jobs_kernel, dim3(nb2), dim3(256), 0, B);
+        FGC_LAUNCH(what, st, reduce_jobs_kernel<MAXJ>, dim3(nb2), dim3(256), 0, B);
     }
     FGC_CHECK_LAUNCH("reduce_jobs");
     return FGC_OK;
+}
+
+int reduce_jobs(const char* what, const RedJob* jobs, int njobs, float* tmp, hipStream_t st) {
+    if (njobs <= 0) return FGC_OK;
+    if (njobs > RED_MAX_JOBS) {
+        set_error("reduce_jobs: %d jobs (max %d)", njobs, RED_MAX_JOBS);
+        return FGC_EINVAL;
+    }
+    return njobs <= RED_FEW_JOBS ? reduce_jobs_impl<RED_FEW_JOBS>(what, jobs, njobs, tmp, st)
+                                 : reduce_jobs_impl<RED_MAX_JOBS>(what, jobs, njobs, tmp, st);
 }
 
 int reduce_slabs(const char* what, const float* slab, int nslabs, size_t count, int in_ld, int out_ld, float* out,

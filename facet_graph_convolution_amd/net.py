@@ -132,6 +132,9 @@ class FacetDenoiser:
         # facet-sharded runs: compute the interior tiles of a layer while its halo rows travel (FGC_NO_OVERLAP=1: the
         # whole layer after a blocking exchange, for A/B timing)
         self.overlap = os.environ.get("FGC_NO_OVERLAP", "0") != "1"
+        # one launch packs the weight operands of all layers, one pair sums all parameter gradients (each small launch
+        # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
+        self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
         # parameter slots
         k = 0
         self.slot = {}
@@ -237,6 +240,7 @@ class FacetDenoiser:
         # descriptors + workspace
         vals, grads = self.params.values, self.params.grads
         descs, ios, ws_f, ws_b = {}, {}, 0, 0
+        wsf, wsb = {}, {}    # a workspace of its own per layer: packed operands and partial sums stay put for the step
         for lay in self.layers:
             g = graphs[lay.level]
             W0, b, u, c, v = vals[lay.pidx:lay.pidx + 5]
@@ -254,8 +258,10 @@ class FacetDenoiser:
             d.src_rows = B[lay.x0].shape[0]
             d.max_deg = g.max_deg
             descs[lay.name] = d
-            ws_f = max(ws_f, self.L.fgc_conv_workspace_bytes(C.byref(d)))
-            ws_b = max(ws_b, self.L.fgc_conv_bwd_workspace_bytes(C.byref(d)))
+            wsf[lay.name] = torch.empty(self.L.fgc_conv_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
+            if gt is not None:
+                wsb[lay.name] = torch.empty(self.L.fgc_conv_bwd_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8,
+                                            device=dev)
             trow, tcol, tedge = g.transposed()
             io = ConvBwdIO()
             io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
@@ -278,9 +284,20 @@ class FacetDenoiser:
         ios["conv1"].dx1 = None
         ws_f = max(ws_f, self.L.fgc_mlp_workspace_bytes(128, HIDDEN, 3))
         ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n0, 32, HIDDEN, 3))
-        B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)
+        B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)     # the MLP heads
+        for k, t in wsf.items():
+            B["wsf_" + k] = t
+        for k, t in wsb.items():
+            B["wsb_" + k] = t
+        names = [lay.name for lay in self.layers]
+        nl = len(names)
+        arrays = dict(
+            descs=(C.POINTER(ConvDesc) * nl)(*[C.pointer(descs[k]) for k in names]),
+            ios=(C.POINTER(ConvBwdIO) * nl)(*[C.pointer(ios[k]) for k in names]),
+            wsf=(C.c_void_p * nl)(*[wsf[k].data_ptr() for k in names]),
+            wsb=(C.c_void_p * nl)(*[wsb[k].data_ptr() for k in names]) if wsb else None, count=nl)
         self._mesh = dict(graphs=graphs, B=B, descs=descs, ios=ios, ns=ns, nh=nh, has_gt=gt is not None,
-                          plan=plan, n_total=n_total, own_lo=own_lo)
+                          plan=plan, n_total=n_total, own_lo=own_lo, arrays=arrays)
         self.comm = comm
         self._graph_fb = None
         return self
@@ -343,10 +360,18 @@ class FacetDenoiser:
         early = {"conv1": ("h1", 0, "dconv1"), "conv2": ("h2", 1, "dconv2")}
         wait_before = {v[2]: v[0] for v in early.values()}
         split = self.sharded and self.overlap
+        packed = 0
+        if self.batched:
+            A = M["arrays"]
+            self._tag("fwd:pack")
+            _lib.check(L.fgc_conv_pack(A["descs"], A["ios"], A["wsf"], A["wsb"], A["count"], st), "pack")
+            packed = _lib.CONV_PACKED
         for lay in self.layers:
             d = M["descs"][lay.name]
-            args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(ws),
-                    ws.numel(), st)
+            lws = B["wsf_" + lay.name]
+            d.flags = packed
+            args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(lws),
+                    lws.numel(), st)
             reqs = halo_before.get(lay.name, []) if self.sharded else []
             if split and reqs:
                 # interior tiles (they gather owned rows only) run while the halo rows travel; then the rest
@@ -356,7 +381,7 @@ class FacetDenoiser:
                 own_src = d.n >> d.shift
                 self._tag("fwd:" + lay.name)
                 d.tile_list, d.n_tiles = g.tiles["tiles_int"][0].data_ptr(), g.tiles["tiles_int"][1]
-                d.proj_row0, d.proj_rows, d.flags = 0, own_src, 0
+                d.proj_row0, d.proj_rows = 0, own_src
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
                 for name, level, parent in reqs:
                     yield ("wait", name)
@@ -366,7 +391,7 @@ class FacetDenoiser:
                 d.proj_row0, d.proj_rows = own_src, (d.src_rows - own_src) or -1
                 d.flags = _lib.CONV_PACKED
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
-                d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, 0
+                d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, packed
             else:
                 for name, level, parent in reqs:
                     yield ("rows", level, B[name], parent)
@@ -453,17 +478,19 @@ class FacetDenoiser:
                 _lib.check(L.fgc_pool4_bwd(_p(B["h1"]), _p(B["p1"]), _p(B["g_p1"]), _p(B["g_h1"]), ns[1], 32, 1, st),
                            "pool1 bwd")
             d, io = M["descs"][name], M["ios"][name]
+            lws = B["wsb_" + name]
+            base = (_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0
             if not self.sharded:
-                io.stages = 0
-                _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st), name + " bwd")
+                io.stages, io.flags = 0, base
+                _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st), name + " bwd")
                 continue
             lay = next(l for l in self.layers if l.name == name)
             cout = d.cout
             nloc = ns[lay.level] + M["nh"][lay.level]
             g = M["graphs"][lay.level]
-            call = lambda what: _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(ws), ws.numel(), st),
+            call = lambda what: _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st),
                                            name + " bwd/" + what)
-            io.stages, io.flags = 1, 0   # s = dy * lrelu'(y) / deg on owned rows
+            io.stages, io.flags = 1, base   # s = dy * lrelu'(y) / deg on owned rows
             call("ds")
             if not L.fgc_conv_bwd_needs_exchange(C.byref(d), C.byref(io)):
                 # first layer over a narrow input: its parameter gradients are sums over owned nodes, nothing to
@@ -480,7 +507,7 @@ class FacetDenoiser:
                 # d-logits of incoming cross-shard edges travel under the data kernel of the interior tiles
                 # (all in-edges from owned rows); boundary tiles and the weight gradients follow
                 yield ("edges_begin", lay.level, "dl")
-                io.stages, io.flags = 4, _lib.CONV_PACKED
+                io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_int"][0].data_ptr(), g.tiles["ttiles_int"][1]
                 call("data/interior")
                 yield ("wait", "ds")
@@ -492,9 +519,13 @@ class FacetDenoiser:
             else:
                 yield ("wait", "ds")
                 yield ("edges", lay.level)
-                io.stages, io.flags = 4 | 8, _lib.CONV_PACKED
+                io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("data")
                 io.flags = 0
+        if self.batched:
+            A = M["arrays"]
+            self._tag("bwd:reduce")
+            _lib.check(L.fgc_conv_bwd_reduce(A["descs"], A["ios"], A["wsb"], A["count"], st), "reduce")
         if self.sharded:
             yield ("sum", self.params.grad)     # every rank summed its own facets: one flat all-reduce
 

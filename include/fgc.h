@@ -176,6 +176,7 @@ typedef struct fgc_conv_desc {
 
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
 #define FGC_CONV_PACKED 1
+#define FGC_CONV_DEFER_REDUCE 2   /* fgc_conv_bwd_io.flags: stage 8 leaves its partial sums for fgc_conv_bwd_reduce */
 
 /* bytes of scratch the conv entry points need for this descriptor (packed weights) */
 size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d);
@@ -221,7 +222,8 @@ typedef struct fgc_conv_bwd_io {
     const int32_t* data_tile_list; /* device, [n_data_tiles]: 32-row tiles stage 4 computes; NULL = all.  Tiles whose
                                       in-edges all come from owned rows need neither halo rows of ds nor remote dl */
     int32_t n_data_tiles;
-    int32_t flags;                 /* FGC_CONV_PACKED: an earlier stage call already packed the operands */
+    int32_t flags;                 /* FGC_CONV_PACKED: the operands are already packed (an earlier stage call, or
+                                    * fgc_conv_pack); FGC_CONV_DEFER_REDUCE: see fgc_conv_bwd_reduce */
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
@@ -231,6 +233,24 @@ size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
 int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* io);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);
+
+/* Whole-network helpers for a caller that runs the same `count` layers every step (train.py:558-575 runs the graph of
+ * model.py:853-941 once per iteration) and gives every layer a workspace of its own that stays untouched from the
+ * first call of a step to the last: the per-layer housekeeping launches (each costs about 5 us on an idle MI355X
+ * whatever its size) collapse into one.
+ *
+ * fgc_conv_pack: the packed weight operands of all layers in ONE launch - forward operands into fwd_ws[i], the two
+ * backward operands into bwd_ws[i] (either array, or single entries, may be NULL to skip; ios may be NULL, it only
+ * tells which layer takes the narrow first-layer path and has nothing to pack).  Call it after the weights change;
+ * then pass FGC_CONV_PACKED in fgc_conv_desc.flags / fgc_conv_bwd_io.flags.
+ *
+ * fgc_conv_bwd_reduce: with FGC_CONV_DEFER_REDUCE in fgc_conv_bwd_io.flags stage 8 leaves the partial sums of the
+ * parameter gradients in the layer's workspace; this call sums them for all layers in two launches, in the same
+ * fixed order as the per-layer path (bit-identical gradients). */
+int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* fwd_ws,
+                  void* const* bwd_ws, int32_t count, void* stream);
+int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* bwd_ws,
+                        int32_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-facet MLP  cin -> hidden -> cout with leaky ReLU in between

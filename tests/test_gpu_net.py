@@ -288,6 +288,7 @@ def test_tiny_mesh_one_coarsest_node():
 @pytest.mark.parametrize("switches", [
     {"FGC_NO_W8": "1", "FGC_NO_K1DEEP": "1", "FGC_NO_TNSTREAM": "1", "FGC_NO_NARROW": "1"},   # 4-wave / generic kernels
     {"FGC_NO_W8FAST": "1", "FGC_NO_K1M": "1"},                                               # 8-wave generic, VALU logits
+    {"FGC_NO_BATCHED": "1"},                                                                 # per-layer packs / reductions
 ])
 def test_fallback_kernels_pass_the_smoke_check(switches):
     """The fast paths have switches (FGC_NO_*); with them off the same train step runs on the fallback kernels that
@@ -297,3 +298,27 @@ def test_fallback_kernels_pass_the_smoke_check(switches):
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=repo,
                          env=dict(os.environ, **switches), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_whole_network_pack_and_reduce_match_the_per_layer_path():
+    """fgc_conv_pack + FGC_CONV_PACKED / FGC_CONV_DEFER_REDUCE + fgc_conv_bwd_reduce (one launch for what every layer
+    used to launch itself) give bit-identical outputs, losses and gradients to per-layer packing and reduction."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = icosphere(3)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    out = []
+    for batched in (True, False):
+        net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+        net.batched = batched
+        losses = [net.train_step(sample_ind=samp, R=Rm)[0].item() for _ in range(3)]
+        out.append((losses, net.params.grad.clone(), net.params.theta.clone(), net.buffers["nconv"].clone()))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert torch.equal(a, b)
