@@ -101,19 +101,24 @@ __global__ __launch_bounds__(256) void abs_partial_kernel(const float* __restric
     v = block_sum(v, red);
     if (threadIdx.x == 0) part[blockIdx.x] = v;
 }
-// scratch[0] = mean|x| + eps  (single block, fixed order)
-__global__ __launch_bounds__(256) void finish_mean_kernel(const float* __restrict__ part, int nparts, float count,
-                                                          float* __restrict__ scratch) {
+// FUSED: every workgroup sums the partials itself (same fixed order everywhere, so the same value) instead of waiting
+// for a one-workgroup launch to do it; workgroup 0 leaves the mean in scratch[0] for the backward pass
+template <bool FUSED>
+__global__ __launch_bounds__(256) void normalize_fwd_kernel(const float* __restrict__ x, int n,
+                                                            float* __restrict__ scratch, float* __restrict__ y,
+                                                            const float* __restrict__ part, int nparts, float count) {
     __shared__ float red[4];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
-    v = block_sum(v, red);
-    if (threadIdx.x == 0) scratch[0] = v / count + 1e-5f;
-}
-__global__ void normalize_fwd_kernel(const float* __restrict__ x, int n, const float* __restrict__ scratch,
-                                     float* __restrict__ y) {
     const float eps = 1e-5f;
-    const float s = scratch[0];
+    float s;
+    if (FUSED) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
+        v = block_sum(v, red);
+        s = v / count + 1e-5f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = s;
+    } else {
+        s = scratch[0];
+    }
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const float a = x[3 * r] / s, b = x[3 * r + 1] / s, c = x[3 * r + 2] / s;
         const float norm = sqrtf(eps + (a * a + b * b + c * c));
@@ -157,21 +162,24 @@ __global__ __launch_bounds__(256) void normalize_bwd_stage1(const float* __restr
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(256) void normalize_bwd_finish(const float* __restrict__ part, int nparts,
-                                                            float* __restrict__ scratch) {
+template <bool FUSED>
+__global__ __launch_bounds__(256) void normalize_bwd_stage2(const float* __restrict__ x, int64_t count,
+                                                            float* __restrict__ scratch, float inv_count,
+                                                            float* __restrict__ dx, const float* __restrict__ part,
+                                                            int nparts) {
     __shared__ float red[4];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
-    v = block_sum(v, red);
-    if (threadIdx.x == 0) {
-        const float s = scratch[0];
-        scratch[1] = -v / (s * s);  // d s
-    }
-}
-__global__ void normalize_bwd_stage2(const float* __restrict__ x, int64_t count, const float* __restrict__ scratch,
-                                     float inv_count, float* __restrict__ dx) {
     const float s = scratch[0];
-    const float ds = scratch[1] * inv_count;
+    float ds;
+    if (FUSED) {   // as normalize_bwd_finish, in every workgroup
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
+        v = block_sum(v, red);
+        ds = -v / (s * s);
+        if (blockIdx.x == 0 && threadIdx.x == 0) scratch[1] = ds;
+        ds *= inv_count;
+    } else {
+        ds = scratch[1] * inv_count;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const float xv = x[i];
         const float sg = xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f);
@@ -180,22 +188,35 @@ __global__ void normalize_bwd_stage2(const float* __restrict__ x, int64_t count,
 }
 
 // ---- angular loss on sampled rows (train.py:509-517, 1272-1294) ---------------------------------
-__global__ __launch_bounds__(256) void angular_loss_fwd_kernel(const float* __restrict__ fn,
-                                                               const float* __restrict__ gt,
-                                                               const int* __restrict__ idx, int ns,
-                                                               float* __restrict__ out) {
-    __shared__ float red[4];
+// one workgroup of 1024 threads; the sample gathers (index -> two rows) are dependent round trips, so each thread issues
+// all of its (up to four per sweep) before using any
+__global__ __launch_bounds__(1024) void angular_loss_fwd_kernel(const float* __restrict__ fn,
+                                                                const float* __restrict__ gt,
+                                                                const int* __restrict__ idx, int ns,
+                                                                float* __restrict__ out) {
+    __shared__ float red[16];
     const float close = 0.9999999f;
     float lsum = 0.f, rsum = 0.f;
-    for (int s = threadIdx.x; s < ns; s += 256) {
-        const int r = idx[s];
-        const float g0 = gt[3 * r], g1 = gt[3 * r + 1], g2 = gt[3 * r + 2];
-        const float f0 = fn[3 * r], f1 = fn[3 * r + 1], f2 = fn[3 * r + 2];
-        const bool fake = (fabsf(g0) + fabsf(g1) + fabsf(g2)) <= 10e-4f;
-        if (!fake) {
-            const float dt = f0 * g0 + f1 * g1 + f2 * g2;
-            lsum += 180.f * acosf(fminf(fmaxf(dt, -close), close)) / 3.14159265358979323846f;
-            rsum += 1.f;
+    for (int s0 = 0; s0 < ns; s0 += 4096) {
+        int r[4];
+        float g[4][3], f[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = idx[min(s0 + (int)threadIdx.x + k * 1024, ns - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                g[k][c] = gt[3 * r[k] + c];
+                f[k][c] = fn[3 * r[k] + c];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool fake = (fabsf(g[k][0]) + fabsf(g[k][1]) + fabsf(g[k][2])) <= 10e-4f;
+            if (s0 + (int)threadIdx.x + k * 1024 < ns && !fake) {
+                const float dt = f[k][0] * g[k][0] + f[k][1] * g[k][1] + f[k][2] * g[k][2];
+                lsum += 180.f * acosf(fminf(fmaxf(dt, -close), close)) / 3.14159265358979323846f;
+                rsum += 1.f;
+            }
         }
     }
     lsum = block_sum(lsum, red);
@@ -348,14 +369,15 @@ extern "C" int fgc_normalize_fwd(const float* x, int32_t n, const float* abs_par
                                  float* scratch, void* stream) {
     FGC_CHECK_ARG(x && y && scratch && n > 0, "fgc_normalize_fwd: bad arguments");
     const float inv_count = 3.0f * (float)n;  // element count (the kernel divides)
-    if (abs_partial && num_partials > 0) {
-        FGC_LAUNCH("finish_mean_kernel", ST, finish_mean_kernel, dim3(1), dim3(256), 0, abs_partial, num_partials, inv_count, scratch);
-    } else {
-        const int np = fgc_norm_num_partials(n);
+    const float* part = abs_partial;
+    int np = num_partials;
+    if (!(abs_partial && num_partials > 0)) {
+        np = fgc_norm_num_partials(n);
         FGC_LAUNCH("abs_partial_kernel", ST, abs_partial_kernel, dim3(np), dim3(256), 0, x, (int64_t)n * 3, scratch + 2);
-        FGC_LAUNCH("finish_mean_kernel", ST, finish_mean_kernel, dim3(1), dim3(256), 0, scratch + 2, np, inv_count, scratch);
+        part = scratch + 2;
     }
-    FGC_LAUNCH("normalize_fwd_kernel", ST, normalize_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, x, n, scratch, y);
+    FGC_LAUNCH("normalize_fwd_kernel", ST, normalize_fwd_kernel<true>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, x, n, scratch, y,
+               part, np, inv_count);
     FGC_CHECK_LAUNCH("fgc_normalize_fwd");
     return FGC_OK;
 }
@@ -365,16 +387,16 @@ extern "C" int fgc_normalize_bwd(const float* x, const float* dy, int32_t n, flo
     // scratch[0] (= mean|x| + eps) is the value left by fgc_normalize_fwd on the same x
     const int np = fgc_norm_num_partials(n);
     FGC_LAUNCH("normalize_bwd_stage1", ST, normalize_bwd_stage1, dim3(np), dim3(256), 0, x, dy, n, scratch, dx, scratch + 2);
-    FGC_LAUNCH("normalize_bwd_finish", ST, normalize_bwd_finish, dim3(1), dim3(256), 0, scratch + 2, np, scratch);
-    FGC_LAUNCH("normalize_bwd_stage2", ST, normalize_bwd_stage2, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, x, (int64_t)n * 3,
-                       scratch, 1.0f / (3.0f * (float)n), dx);
+    FGC_LAUNCH("normalize_bwd_stage2", ST, normalize_bwd_stage2<true>, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, x,
+               (int64_t)n * 3, scratch, 1.0f / (3.0f * (float)n), dx, scratch + 2, np);
     FGC_CHECK_LAUNCH("fgc_normalize_bwd");
     return FGC_OK;
 }
 
 extern "C" int fgc_normalize_apply(const float* x, int32_t n, const float* scratch, float* y, void* stream) {
     FGC_CHECK_ARG(x && y && scratch && n > 0, "fgc_normalize_apply: bad arguments");
-    FGC_LAUNCH("normalize_fwd_kernel", ST, normalize_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, x, n, scratch, y);
+    FGC_LAUNCH("normalize_fwd_kernel", ST, normalize_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, x, n,
+               const_cast<float*>(scratch), y, nullptr, 0, 1.f);
     FGC_CHECK_LAUNCH("fgc_normalize_apply");
     return FGC_OK;
 }
@@ -389,8 +411,8 @@ extern "C" int fgc_normalize_bwd_partial(const float* x, const float* dy, int32_
 extern "C" int fgc_normalize_bwd_apply(const float* x, int32_t n, float total_count, const float* scratch, float* dx,
                                        void* stream) {
     FGC_CHECK_ARG(x && dx && scratch && n > 0 && total_count > 0, "fgc_normalize_bwd_apply: bad arguments");
-    FGC_LAUNCH("normalize_bwd_stage2", ST, normalize_bwd_stage2, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, x,
-               (int64_t)n * 3, scratch, 1.0f / total_count, dx);
+    FGC_LAUNCH("normalize_bwd_stage2", ST, normalize_bwd_stage2<false>, dim3(ew_grid((int64_t)n * 3)), dim3(EW_THREADS), 0, x,
+               (int64_t)n * 3, const_cast<float*>(scratch), 1.0f / total_count, dx, nullptr, 0);
     FGC_CHECK_LAUNCH("fgc_normalize_bwd_apply");
     return FGC_OK;
 }
@@ -398,7 +420,7 @@ extern "C" int fgc_normalize_bwd_apply(const float* x, int32_t n, float total_co
 extern "C" int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns,
                                     float* loss_out, void* stream) {
     FGC_CHECK_ARG(fn && gt && sample_ind && loss_out && ns > 0, "fgc_angular_loss_fwd: bad arguments");
-    FGC_LAUNCH("angular_loss_fwd_kernel", ST, angular_loss_fwd_kernel, dim3(1), dim3(256), 0, fn, gt, sample_ind, ns, loss_out);
+    FGC_LAUNCH("angular_loss_fwd_kernel", ST, angular_loss_fwd_kernel, dim3(1), dim3(1024), 0, fn, gt, sample_ind, ns, loss_out);
     FGC_CHECK_LAUNCH("fgc_angular_loss_fwd");
     return FGC_OK;
 }

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
     const float* __restrict__ Wp, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, float alpha, float* __restrict__ dx_slab /* [gridDim.y][n][cin] */,
     float* __restrict__ dW1_slab /* [gridDim.x][cin][hidden] */, float* __restrict__ db1_slab /* [gridDim.x][hidden] */,
-    float* __restrict__ dW2_slab /* [gridDim.x][hidden][4] */) {
+    float* __restrict__ dW2_slab /* [gridDim.x][hidden][4] */, float* __restrict__ db2_slab /* [gridDim.x][4] */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int KP = MLP_BWD_MT * 16;                             // == kpad
     constexpr int HCW = 4 * MLP_BWD_CTW * 16;                       // hidden columns of this workgroup
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
 
     // the next tile's rows travel through registers while the current tile is being worked on: addresses are clamped
     // so the loads are unconditional (no exec-masked load, no early wait); out-of-range elements are zeroed on store
-    float xpre[XPT], dypre;
+    float xpre[XPT], dypre, db2acc = 0.f;
     auto fetch_tile = [&](int tl) {
         const int r0 = tl * BWD_T;
 #pragma unroll
@@ -299,7 +299,9 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
         }
         if (threadIdx.x < BWD_T * 4) {
             const int t = threadIdx.x;
-            dyt[t] = (r0 + (t >> 2) < n && (t & 3) < cout) ? dypre : 0.f;
+            const float v = (r0 + (t >> 2) < n && (t & 3) < cout) ? dypre : 0.f;
+            dyt[t] = v;
+            db2acc += v;     // db2 = column sums of dy: every workgroup row-walk sees each dy row once per hidden slice
         }
     };
     constexpr bool PREFETCH = XPT <= 8;     // the 128-wide head has no registers to spare for it
@@ -445,6 +447,17 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
             }
         }
     }
+    // db2 partial of this row walk (hidden slice 0 only; rows of the tile in a fixed order)
+    if (blockIdx.y == 0) {
+        __syncthreads();
+        if (threadIdx.x < BWD_T * 4) dyt[threadIdx.x] = db2acc;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float v = 0.f;
+            for (int r = 0; r < BWD_T; ++r) v += dyt[r * 4 + threadIdx.x];
+            db2_slab[blockIdx.x * 4 + threadIdx.x] = v;
+        }
+    }
     // parameter-gradient slabs of this workgroup
 #pragma unroll
     for (int c = 0; c < MLP_BWD_CTW; ++c) {
@@ -470,18 +483,6 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
             w += __shfl_xor(w, 32);
             if (lq == 0) dW2_slab[((size_t)blockIdx.x * hidden + col) * 4 + o] = w;
         }
-    }
-}
-
-// column sums of a [rows, c] matrix in two deterministic stages
-__global__ void colsum_stage1_kernel(const float* __restrict__ a, int rows, int c, int rows_per_block,
-                                     float* __restrict__ part /* [gridDim.x][c] */) {
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(rows, r0 + rows_per_block);
-    for (int col = threadIdx.x; col < c; col += blockDim.x) {
-        float v = 0.f;
-        for (int r = r0; r < r1; ++r) v += a[(size_t)r * c + col];
-        part[(size_t)blockIdx.x * c + col] = v;
     }
 }
 
@@ -594,12 +595,12 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
             hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 (int)smem);                                                                               \
             FGC_LAUNCH("mlp_bwd_kernel", st, (mlp_bwd_kernel<MT, CTW, 3>), dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy,  \
-                       n, cin, kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);         \
+                       n, cin, kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab, db2_part); \
         } else {                                                                                                          \
             hipFuncSetAttribute((const void*)mlp_bwd_kernel<MT, CTW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 (int)smem);                                                                               \
             FGC_LAUNCH("mlp_bwd_kernel", st, (mlp_bwd_kernel<MT, CTW, 4>), dim3(gx, gy), dim3(MLP_THREADS), smem, x, dy,  \
-                       n, cin, kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab);         \
+                       n, cin, kpad, hidden, cout, Wp, W1, b1, W2, alpha, dx_slab, dW1_slab, db1_slab, dW2_slab, db2_part); \
         }                                                                                                                 \
     } while (0)
     if (ctw == 4) FGC_MLP_BWD_LAUNCH(2, 4);
@@ -607,17 +608,13 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     else FGC_MLP_BWD_LAUNCH(8, 1);
 #undef FGC_MLP_BWD_LAUNCH
     FGC_CHECK_LAUNCH("fgc_mlp_bwd");
-    // db2 = column sums of dy (stage 1 here, summed with the other partials below)
-    const int nb = n < 1024 * 64 ? cdiv(n, 64) : 1024;
-    const int rpb = cdiv(n, nb);
-    FGC_LAUNCH("colsum_stage1_kernel", st, colsum_stage1_kernel, dim3(nb), dim3(64), 0, dy, n, cout, rpb, db2_part);
     // fixed-order reductions, all five in two launches
     const RedJob jobs[5] = {
         {dx_slab, (size_t)n * cin, gy, n * cin, cin, cin, dx},
         {dW1_slab, (size_t)cin * hidden, gx, cin * hidden, hidden, hidden, dW1},
         {db1_slab, (size_t)hidden, gx, hidden, hidden, hidden, db1},
         {dW2_slab, (size_t)hidden * 4, gx, hidden * 4, 4, cout, dW2},
-        {db2_part, (size_t)cout, nb, cout, cout, cout, db2},
+        {db2_part, (size_t)4, gx, 4, 4, cout, db2},
     };
     const int rc = reduce_jobs("reduce:mlp", jobs, 5, rtmp, st);
     if (rc) return rc;
