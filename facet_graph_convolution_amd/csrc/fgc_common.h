@@ -74,6 +74,12 @@ __device__ __forceinline__ float fgc_dpp_c(float v) {
 
 // ---- geometry of the fused "edge-aggregate + MFMA" kernels ------------------------------
 // A node's input row is processed KC = 4*LPN channels per pass by LPN lanes (float4 each).
+// The tiled conv kernels gather 8 lanes x 4 channels per node and pass; the numbers that follow from it are compile-time
+// constants in device code (LDS offsets fold into the instructions) and are mirrored by conv_geom for the host.
+constexpr int KC = 32;        // channels per pass
+constexpr int KPASS = 288;    // FGC_M * KC, a multiple of 16
+constexpr int ZSTRIDE = 296;  // LDS row stride of the aggregate tile: == 8 mod 16, >= KPASS
+
 struct ConvGeom {
     int cin, cout;
     int lpn;        // lanes per node: 2,4,8
@@ -108,6 +114,7 @@ static inline ConvGeom conv_geom(int cin, int cout) {
     g.zstride = lds_stride_for(g.kpass);
     g.npad = (cout + 15) / 16 * 16;
     g.T = 32;
+    static_assert(KC == 32 && KPASS == (FGC_M * KC + 15) / 16 * 16 && ZSTRIDE >= KPASS && ZSTRIDE % 16 == 8, "geometry");
     return g;
 }
 

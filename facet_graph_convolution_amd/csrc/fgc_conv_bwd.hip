@@ -111,7 +111,7 @@ constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> cei
 template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, p.zstride);
+    const Smem s = carve(smem_raw, ZSTRIDE);
     float* dst = s.extra;                       // ds tile [TILE][ostride]
     float* red = dst + TILE * lp.ostride;       // [4][12] block reduction scratch
     const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p,
 #pragma unroll
     for (int m = 0; m < FGC_M; ++m) daacc[m] = 0.f;
 
-    const int nct = p.kpass >> 4;
+    const int nct = KPASS >> 4;
     const int okg = lp.opad >> 4;
     const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p,
                 for (int c = 0; c < K1_CTW; ++c) {
                     const int ct = wave + c * 4;
                     if (ct >= nct) continue;
-                    const f32x4 b = Wq4[((size_t)pass * (lp.opad >> 2) + g * 4 + lq) * p.kpass + ct * 16 + lr];
+                    const f32x4 b = Wq4[((size_t)pass * (lp.opad >> 2) + g * 4 + lq) * KPASS + ct * 16 + lr];
 #pragma unroll
                     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -187,17 +187,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p,
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        s.ztile[(size_t)(r * 16 + lq * 4 + t) * p.zstride + ct * 16 + lr] = acc[r][c][t];
+                        s.ztile[(size_t)(r * 16 + lq * 4 + t) * ZSTRIDE + ct * 16 + lr] = acc[r][c][t];
             }
             __syncthreads();
             // ---- per edge: dq[m] += <dz_i[m, chunk], x_j[chunk]>
             if (worker) {
                 f32x4 dz[FGC_M];
-                const float* zr = s.ztile + (size_t)node * p.zstride + cl * 4;
+                const float* zr = s.ztile + (size_t)node * ZSTRIDE + cl * 4;
 #pragma unroll
-                for (int m = 0; m < FGC_M; ++m) dz[m] = *reinterpret_cast<const f32x4*>(zr + m * p.kc);
+                for (int m = 0; m < FGC_M; ++m) dz[m] = *reinterpret_cast<const f32x4*>(zr + m * KC);
                 const int d = min(max(s.deg[node] - kbase, 0), KMAX);
-                const int cbase = pass * p.kc + cl * 4;
+                const int cbase = pass * KC + cl * 4;
                 const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) {
@@ -304,7 +304,7 @@ constexpr int NPW = TILE / 4;  // nodes per wave
 template <bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, p.zstride);
+    const Smem s = carve(smem_raw, ZSTRIDE);
     float* dst = s.extra;                       // ds tile [TILE][ostride]
     float* red = dst + TILE * lp.ostride;       // [4][12]
     const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
     softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
     __syncthreads();
 
-    const int nct = p.kpass >> 4;   // 18
+    const int nct = KPASS >> 4;   // 18
     const int okg = lp.opad >> 4;
     const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
 
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 #pragma unroll
                 for (int c = 0; c < K1_CTW; ++c) {
                     const int ct = min(wave + c * 4, nct - 1);
-                    const f32x4 b = Wq4[((size_t)pass * (lp.opad >> 2) + g * 4 + lq) * p.kpass + ct * 16 + lr];
+                    const f32x4 b = Wq4[((size_t)pass * (lp.opad >> 2) + g * 4 + lq) * KPASS + ct * 16 + lr];
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -364,12 +364,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        s.ztile[(size_t)(r * 16 + lq * 4 + t) * p.zstride + ct * 16 + lr] = acc[r][c][t];
+                        s.ztile[(size_t)(r * 16 + lq * 4 + t) * ZSTRIDE + ct * 16 + lr] = acc[r][c][t];
             }
         }
         __syncthreads();
         // ---- per node: dq += dz_i (9 x 32) . X_i (32 x d)
-        const int cpass = pass * p.kc;
+        const int cpass = pass * KC;
         auto rowof = [&](int node, int d, int et) {
             const int e = min(et * 16 + lr, d - 1);
             return __float_as_int(s.qbuf[((size_t)node * KMAX + e) * QLD + 9]);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
                 bn[0] = load_chunk<VEC4>(p, row, cpass + 4 * lq);
                 bn[1] = load_chunk<VEC4>(p, row, cpass + 16 + 4 * lq);
             }
-            const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
+            const float* zr = s.ztile + (size_t)node * ZSTRIDE + mrow * KC + 4 * lq;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(zr + 16);
             if (d > 0) {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 template <bool LONG>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, p.zstride);
+    const Smem s = carve(smem_raw, ZSTRIDE);
     float* dst = s.extra;                       // ds tile [TILE][ostride]
     float* red = dst + TILE * lp.ostride;       // [4][12]
     const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
     // per-edge work is independent across edges, so a sweep is the whole computation for its 16 edge slots.
     const int nsweeps = LONG ? (__syncthreads(), 1) : (__syncthreads_or(dmine > 16) ? 2 : 1);
 
-    const int nct = p.kpass >> 4;   // 18
+    const int nct = KPASS >> 4;   // 18
     const int okg = lp.opad >> 4;
     const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
     int dn[NPW];
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
             dq[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int pass = 0; pass < p.passes; ++pass) {
-            const int cpass = pass * p.kc;
+            const int cpass = pass * KC;
             const bool first = cpass < p.c0;                                            // block-uniform
             const float* base = first ? p.src0 : p.src1;
             const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * 4u;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c) {
                         const int ct = min(wave + c * 4, nct - 1);
-                        b[c] = Wq4[((size_t)pass * (lp.opad >> 2) + gg * 4 + lq) * p.kpass + ct * 16 + lr];
+                        b[c] = Wq4[((size_t)pass * (lp.opad >> 2) + gg * 4 + lq) * KPASS + ct * 16 + lr];
                     }
                 };
                 auto mmw = [&](int g, const f32x4 (&b)[K1_CTW]) {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                     for (int r = 0; r < RT; ++r)
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
-                            s.ztile[(size_t)(r * 16 + lq * 4 + t) * p.zstride + ct * 16 + lr] = acc[r][c][t];
+                            s.ztile[(size_t)(r * 16 + lq * 4 + t) * ZSTRIDE + ct * 16 + lr] = acc[r][c][t];
                 }
             }
             __syncthreads();
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
                 for (int nn = 0; nn < H; ++nn) {
                     const int node = wave * NPW + n0 + nn;
-                    const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
+                    const float* zr = s.ztile + (size_t)node * ZSTRIDE + mrow * KC + 4 * lq;
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(zr + 16);
                     f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                     const unsigned off = __umul24((unsigned)row, rowbytes) + laneoff;
                     const f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                     const f32x4 x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64u, 0, 0));
-                    const float* zr = s.ztile + (size_t)node * p.zstride + mrow * p.kc + 4 * lq;
+                    const float* zr = s.ztile + (size_t)node * ZSTRIDE + mrow * KC + 4 * lq;
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(zr);
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(zr + 16);
                     f32x4 u0 = f32x4{0.f, 0.f, 0.f, 0.f}, u1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, DataEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, p.zstride);
+    const Smem s = carve(smem_raw, ZSTRIDE);
     float* dagt = s.extra;  // [TILE][24]: da | dg of the tile's nodes
     const int tile0 = block_tile0(p);
     const int tid = threadIdx.x;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
         {
             const int node = tid / LPN, cl = tid % LPN;
             const int j = tile0 + node;
-            const int ch0 = pass * p.kc + cl * 4;
+            const int ch0 = pass * KC + cl * 4;
             if (node < TILE && j < p.n && ch0 < p.cg) {
                 float* rr = ep.r + (size_t)j * ep.rld + ch0;
                 if (VEC4) {

@@ -258,7 +258,7 @@ __device__ __forceinline__ void early_row_ids(const CoreParams& p, int tile0, in
 template <int LPN, bool VEC4>
 __device__ __forceinline__ void issue_rows(const CoreParams& p, const int (&rows)[RB], int pass, f32x4 (&xv)[RB]) {
     const int cl = threadIdx.x % LPN;
-    const int cbase = pass * p.kc + cl * 4;
+    const int cbase = pass * KC + cl * 4;
 #pragma unroll
     for (int t = 0; t < RB; ++t) xv[t] = load_chunk<VEC4>(p, rows[t], cbase);
 }
@@ -273,7 +273,7 @@ __device__ __forceinline__ void aggregate_pass(const CoreParams& p, const Smem& 
     const int node = tid / LPN, cl = tid % LPN;
     if (node >= TILE) return;
     const int d = min(max(s.deg[node] - kbase, 0), KMAX);
-    const int cbase = pass * p.kc + cl * 4;
+    const int cbase = pass * KC + cl * 4;
     const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
     for (int k0 = 0; k0 < d; k0 += RB) {
         f32x4 xv[RB];
@@ -287,18 +287,18 @@ __device__ __forceinline__ void store_ztile(const CoreParams& p, const Smem& s, 
     const int tid = threadIdx.x;
     const int node = tid / LPN, cl = tid % LPN;
     if (node >= TILE) return;
-    float* zr = s.ztile + (size_t)node * p.zstride + cl * 4;
+    float* zr = s.ztile + (size_t)node * ZSTRIDE + cl * 4;
 #pragma unroll
-    for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x4*>(zr + m * p.kc) = z[m];
+    for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x4*>(zr + m * KC) = z[m];
 }
 
 // zero the k padding columns [M*kc, kpass) of the z tile (only LPN = 2 has any)
 __device__ __forceinline__ void zero_zpad(const CoreParams& p, const Smem& s) {
-    const int padw = p.kpass - FGC_M * p.kc;
+    const int padw = KPASS - FGC_M * KC;
     if (padw <= 0) return;
     for (int t = threadIdx.x; t < TILE * padw; t += NTHREADS) {
         const int r = t / padw, c = t % padw;
-        s.ztile[(size_t)r * p.zstride + FGC_M * p.kc + c] = 0.f;
+        s.ztile[(size_t)r * ZSTRIDE + FGC_M * KC + c] = 0.f;
     }
 }
 
@@ -326,13 +326,13 @@ __device__ __forceinline__ void gemm_pass(const CoreParams& p, const Smem& s, in
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int nct = p.npad >> 4;
-    const int kg_total = p.kpass >> 4;
+    const int kg_total = KPASS >> 4;
     // wave-uniform by construction; readfirstlane makes that provable, so the k loop is a scalar loop (no exec
     // masking) and the compiler can emit counted s_waitcnt vmcnt(N) for the fragment ring instead of vmcnt(0)
     const int kg0 = __builtin_amdgcn_readfirstlane(kg_total * wt.kpart / wt.kparts);
     const int kg1 = __builtin_amdgcn_readfirstlane(kg_total * (wt.kpart + 1) / wt.kparts);
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(p.Wp);
-    const size_t wrow0 = (size_t)pass * (p.kpass >> 2);
+    const size_t wrow0 = (size_t)pass * (KPASS >> 2);
     bool ctv[CTW];
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
@@ -359,7 +359,7 @@ __device__ __forceinline__ void gemm_pass(const CoreParams& p, const Smem& s, in
         const int gg = min(g, kg1 - 1);
 #pragma unroll
         for (int r = 0; r < RT; ++r)
-            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + gg * 16 + lq * 4);
+            a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * ZSTRIDE + gg * 16 + lq * 4);
     };
     auto mm = [&](const f32x4 (&a)[RT], const f32x4 (&bb)[CTW]) {
 #pragma unroll

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void proj_mfma_kernel(const float* __restrict_
 template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(CoreParams p, FwdEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, p.zstride);
+    const Smem s = carve(smem_raw, ZSTRIDE);
     const int tile0 = block_tile0(p);
     const WaveTiling wt = wave_tiling(p.npad, threadIdx.x >> 6);
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ void edge_batch(__amdgpu_buffer_rsrc_t rsrc, unsigned
 template <bool DATA, bool FAST>
 __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, p.zstride);
+    const Smem s = carve(smem_raw, ZSTRIDE);
     float* dagt = s.extra;  // DATA: [TILE][24]
     const int tile0 = block_tile0(p);
     const int tid = threadIdx.x;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
     const int kparts = 8 / nct;
     const int ct = __builtin_amdgcn_readfirstlane(wave % nct);
     const int kpart = __builtin_amdgcn_readfirstlane(wave / nct);
-    const int kg_total = p.kpass >> 4;
+    const int kg_total = KPASS >> 4;
     const int kg0 = __builtin_amdgcn_readfirstlane(kg_total * kpart / kparts);
     const int kg1 = __builtin_amdgcn_readfirstlane(kg_total * (kpart + 1) / kparts);
     const f32x4* Wp4 = reinterpret_cast<const f32x4*>(p.Wp);
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         f32x2 z[FGC_M];
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) z[m] = f32x2{0.f, 0.f};
-        const int cbase = pass * p.kc + 2 * cl;
+        const int cbase = pass * KC + 2 * cl;
         if (FAST) {
-            const bool first = pass * p.kc < p.c0;                                   // wave-uniform
+            const bool first = pass * KC < p.c0;                                   // wave-uniform
             const float* base = first ? p.src0 : p.src1;
             const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * 4u;
             const unsigned laneoff = (unsigned)(first ? cbase : cbase - p.c0) * 4u;
@@ -266,14 +266,14 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         }
         if (pass > 0) __syncthreads();  // previous pass' MFMA reads of ztile are done
         {
-            float* zr = s.ztile + (size_t)node * p.zstride + 2 * cl;
+            float* zr = s.ztile + (size_t)node * ZSTRIDE + 2 * cl;
 #pragma unroll
-            for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(zr + m * p.kc) = z[m];
+            for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(zr + m * KC) = z[m];
         }
         __syncthreads();
         // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
         {
-            const size_t wrow0 = (size_t)pass * (p.kpass >> 2);
+            const size_t wrow0 = (size_t)pass * (KPASS >> 2);
             auto loadb = [&](int g) {
                 const int gg = min(g, kg1 - 1);
                 return Wp4[(wrow0 + gg * 4 + lq) * p.npad + ct * 16 + lr];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 const int gg = min(g, kg1 - 1);
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
-                    a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * p.zstride + gg * 16 + lq * 4);
+                    a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * ZSTRIDE + gg * 16 + lq * 4);
             };
             auto mm = [&](const f32x4 (&a)[RT], const f32x4& b) {
 #pragma unroll
