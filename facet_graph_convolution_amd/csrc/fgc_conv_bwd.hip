@@ -490,20 +490,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 // that also carries the accumulators of the second edge tile (slots 16..23), paid for with the second gather register
 // set: the neighbour rows of nodes 4..7 are requested after the products of nodes 0..3, those of the second edge tile
 // on demand.  Without it such tiles took the two-sweep path below, i.e. the dz GEMM twice.
-template <bool LONG>
+// OKG = cout / 16 for cout = 32 and 64 (strides of the ds tile become compile-time, its load one coalesced dwordx4
+// stream issued up front), 0 = any cout (measured faster than OKG = 8 for the 128-wide layers of the coarsest level)
+template <bool LONG, int OKG>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, ZSTRIDE);
+    const int opad = OKG ? OKG * 16 : lp.opad;
+    const int ostride = OKG ? OKG * 16 + 8 : lp.ostride;
     float* dst = s.extra;                       // ds tile [TILE][ostride]
-    float* red = dst + TILE * lp.ostride;       // [4][12]
+    float* red = dst + TILE * ostride;          // [4][12]
     const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
 
-    for (int t = tid; t < TILE * lp.opad; t += NTHREADS) {
-        const int r = t / lp.opad, o = t % lp.opad;
-        const int i = tile0 + r;
-        dst[r * lp.ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
+    if constexpr (OKG > 0) {
+        // rows tile0 .. tile0+31 of ds are one contiguous run of 32 * cout floats (cout == opad)
+        constexpr int V4 = TILE * OKG * 16 / 4;          // float4s in the tile: 128 * OKG
+        constexpr int PER = (V4 + NTHREADS - 1) / NTHREADS;
+        const f32x4* src = reinterpret_cast<const f32x4*>(lp.ds + (size_t)tile0 * (OKG * 16));
+        const int vmax = (min(p.n - tile0, TILE) * OKG * 16) / 4 - 1;     // last valid float4 (n > tile0)
+        f32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = src[min(tid + k * NTHREADS, vmax)];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int t = tid + k * NTHREADS;
+            if (V4 % NTHREADS == 0 || t < V4) {
+                const int r = t / (OKG * 4), o4 = t % (OKG * 4);
+                *reinterpret_cast<f32x4*>(dst + r * ostride + o4 * 4) = t <= vmax ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    } else {
+        for (int t = tid; t < TILE * opad; t += NTHREADS) {
+            const int r = t / opad, o = t % opad;
+            const int i = tile0 + r;
+            dst[r * ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
+        }
     }
     const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
     // edges 0..15 of every node in sweep 0; a second sweep (block-uniform, rare) for nodes with 17..24 edges.  The
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
     const int nsweeps = LONG ? (__syncthreads(), 1) : (__syncthreads_or(dmine > 16) ? 2 : 1);
 
     const int nct = KPASS >> 4;   // 18
-    const int okg = lp.opad >> 4;
+    const int okg = opad >> 4;
     const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
     int dn[NPW];
 #pragma unroll
@@ -568,14 +591,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c) {
                         const int ct = min(wave + c * 4, nct - 1);
-                        b[c] = Wq4[((size_t)pass * (lp.opad >> 2) + gg * 4 + lq) * KPASS + ct * 16 + lr];
+                        b[c] = Wq4[((size_t)pass * (opad >> 2) + gg * 4 + lq) * KPASS + ct * 16 + lr];
                     }
                 };
                 auto mmw = [&](int g, const f32x4 (&b)[K1_CTW]) {
                     f32x4 a[RT];
 #pragma unroll
                     for (int r = 0; r < RT; ++r)
-                        a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * lp.ostride + g * 16 + lq * 4);
+                        a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * ostride + g * 16 + lq * 4);
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c)
 #pragma unroll
@@ -584,6 +607,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                             for (int r = 0; r < RT; ++r)
                                 acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
                 };
+#pragma unroll OKG == 2 ? 2 : 1
                 for (int g = 0; g < okg; ++g) {
                     f32x4 w0[K1_CTW];
                     loadw(g, w0);
@@ -1252,17 +1276,19 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                               !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
             if (deep) {
                 // (__syncthreads_or owns 256 B of static LDS: ask for exactly what this launch needs)
-                if (d->max_deg > 16) {
-                    hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                    FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, conv_bwd_logits_deep_kernel<true>, dim3(cdiv(d->n, TILE)),
-                               dim3(NTHREADS), smem, p, lp);
-                } else {
-                    hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                    FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, conv_bwd_logits_deep_kernel<false>, dim3(cdiv(d->n, TILE)),
-                               dim3(NTHREADS), smem, p, lp);
-                }
+#define FGC_DEEP_LAUNCH(LONG_, OKG_)                                                                                  \
+    do {                                                                                                             \
+        hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<LONG_, OKG_>,                                   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
+        FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, (conv_bwd_logits_deep_kernel<LONG_, OKG_>),                    \
+                   dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);                                             \
+    } while (0)
+                const bool lng = d->max_deg > 16;
+                const bool al16 = ((uintptr_t)io->ds % 16) == 0;
+                if (cout == 32 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 2); else FGC_DEEP_LAUNCH(false, 2); }
+                else if (cout == 64 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 4); else FGC_DEEP_LAUNCH(false, 4); }
+                else { if (lng) FGC_DEEP_LAUNCH(true, 0); else FGC_DEEP_LAUNCH(false, 0); }
+#undef FGC_DEEP_LAUNCH
             } else if (vec4)
                 FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, (conv_bwd_logits_mfma_kernel<true>),
                            dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);
