@@ -334,8 +334,12 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
     }
     __syncthreads();
     if (!DATA) {
-        for (int t = tid; t < (TILE / 4) * p.nout; t += W8_THREADS) {
-            const int pr = t / p.nout, o = t % p.nout;
+        // thread -> (pooled row group, column): W8_THREADS is a multiple of every supported width, so a thread keeps its
+        // column over the walk and the bias is read once
+        const int o = tid % p.nout, pstep = W8_THREADS / p.nout;
+        const float bias_o = fe.bias[o];
+        // (threads past the last whole row of columns sit out: widths that do not divide W8_THREADS)
+        for (int pr = tid < pstep * p.nout ? tid / p.nout : TILE; pr < TILE / 4; pr += pstep) {
             float mx = -INFINITY;
             bool any = false;
 #pragma unroll
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 // deg was clamped to KMAX for the edge loops; the true degree equals it here (host guarantees <= 24)
                 const float inv = dd > 0 ? 1.0f / (float)dd : 0.f;
                 val *= inv;
-                if (!fe.bias_mask || dd > 0) val += fe.bias[o];
+                if (!fe.bias_mask || dd > 0) val += bias_o;
                 if (fe.act) val = fmaxf(val, 0.f) - fe.alpha * fmaxf(-val, 0.f);
                 fe.y[(size_t)i * p.nout + o] = val;
                 mx = fmaxf(mx, val);
@@ -360,8 +364,16 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
     } else {
         const int group = 1 << de.shiftf;
         const int nsrc = TILE / group;
-        for (int t = tid; t < nsrc * de.cin; t += W8_THREADS) {
-            const int sr = t / de.cin, c = t % de.cin;
+        // thread -> (source row, input channel): the channel stays put over the walk (W8_THREADS is a multiple of every
+        // supported width), so the 18 u / v entries of the logit term are read once per thread, not once per element
+        const int c = tid % de.cin, sstep = W8_THREADS / de.cin;
+        float uc[FGC_M], vc[FGC_M];
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m) {
+            uc[m] = de.u[m * de.cin + c];
+            vc[m] = de.v[m * de.cin + c];
+        }
+        for (int sr = tid < sstep * de.cin ? tid / de.cin : nsrc; sr < nsrc; sr += sstep) {
             float val = 0.f;
             bool any = false;
             for (int q = 0; q < group; ++q) {
@@ -373,8 +385,8 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 const float* dg = dagt + row * 24;
 #pragma unroll
                 for (int m = 0; m < FGC_M; ++m) {
-                    g = fmaf(dg[m], de.u[m * de.cin + c], g);
-                    g = fmaf(dg[12 + m], de.v[m * de.cin + c], g);
+                    g = fmaf(dg[m], uc[m], g);
+                    g = fmaf(dg[12 + m], vc[m], g);
                 }
                 val += g;
             }
