@@ -28,6 +28,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see facet_graph_convolution_amd/__init__.py
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -106,9 +108,10 @@ def main():
     ap.add_argument("--nu", type=int, default=250)
     ap.add_argument("--nv", type=int, default=200)
     ap.add_argument("--graph", type=int, default=0,
-                    help="replay the forward+backward enqueue as one hipGraph (same speed as eager here: the step is "
-                         "GPU-bound; off by default because back-to-back replays without a host sync between them gave "
-                         "run-to-run different losses on this ROCm stack, see DESIGN.md section 6)")
+                    help="replay the forward+backward enqueue as one hipGraph (1 %% faster than eager here: the step is "
+                         "GPU-bound).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
+                         "the runtime's pre-built graph packets a replay after a stream synchronise computes garbage on "
+                         "this ROCm stack (DESIGN.md section 6), so the timed default stays on eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", type=str, default="", help="write the full per-kernel table to this file")

@@ -322,3 +322,42 @@ def test_whole_network_pack_and_reduce_match_the_per_layer_path():
     assert out[0][0] == out[1][0]
     for a, b in zip(out[0][1:], out[1][1:]):
         assert torch.equal(a, b)
+
+
+def test_graph_replay_survives_a_device_synchronise():
+    """forward_backward(capture=True) replays one hipGraph per step.  With ROCm's pre-built graph packets a replay
+    enqueued after a hipDeviceSynchronize went wrong (loss 88 deg instead of 33); the package turns that runtime
+    feature off at import.  Here: the same 8 training steps eager and replayed, with a device synchronise after
+    step 3, must agree bit for bit."""
+    import subprocess, sys, textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import numpy as np, torch
+        import facet_graph_convolution_amd
+        from facet_graph_convolution_amd.net import FacetDenoiser
+        from facet_graph_convolution_amd.dataClasses import TrainingSet
+        from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+        from facet_graph_convolution_amd.utils import rand_rotation_matrix
+        V, F = icosphere(4)
+        ds = TrainingSet(); ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+        x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+        rs = np.random.RandomState(1)
+        S = torch.tensor(np.stack([rs.randint(x.shape[1], size=4000) for _ in range(8)]).astype(np.int32)).cuda()
+        R = torch.tensor(np.stack([rand_rotation_matrix(randnums=rs.uniform(size=3)).reshape(9) for _ in range(8)])
+                         .astype(np.float32)).cuda()
+        out = []
+        for capture in (False, True):
+            net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+            for k in range(8):
+                net.set_step_inputs_device(S[k], R[k])
+                net.forward_backward(rotate=True, capture=capture)
+                net.adam_step()
+                if k == 2:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            out.append((net.buffers["loss"][0].item(), net.params.theta.clone()))
+        assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]), (out[0][0], out[1][0])
+        print("replay ok", out[0][0])
+    """)
+    r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "replay ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

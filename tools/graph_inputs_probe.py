@@ -5,6 +5,7 @@ from bench import build_mesh
 from facet_graph_convolution_amd.net import FacetDenoiser
 from facet_graph_convolution_amd.utils import rand_rotation_matrix
 mode, inputs = sys.argv[1], sys.argv[2]
+variant = sys.argv[4] if len(sys.argv) > 4 else ""
 ds, F = build_mesh(250, 200, 0)
 net = FacetDenoiser("cuda:0", seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
 n0 = ds.in_list[0].shape[1]
@@ -21,8 +22,17 @@ for k in range(N):
     else:
         net.set_samples(samp[k]); net.set_rotation(rot[k])
     net.forward_backward(rotate=True, capture=(mode == "graph"))
+    if variant == "fence":      # an explicit (semantically empty) dependency between the replay and what follows
+        e = torch.cuda.Event(); e.record(); torch.cuda.current_stream().wait_event(e)
     net.adam_step()
     if len(sys.argv) > 3 and k == int(sys.argv[3]) - 1:
-        torch.cuda.synchronize()
+        if variant == "streamsync":
+            torch.cuda.current_stream().synchronize()
+        elif variant == "eventsync":
+            e = torch.cuda.Event(); e.record(); e.synchronize()
+        else:
+            torch.cuda.synchronize()
+        if variant == "recapture":
+            net._graph_fb = None
 torch.cuda.synchronize()
-print(mode, inputs, "loss %.4f" % net.buffers["loss"][0].item())
+print(mode, inputs, variant, "loss %.4f" % net.buffers["loss"][0].item())
