@@ -495,7 +495,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 template <bool LONG, int OKG>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, ZSTRIDE);
+    constexpr int QS = LONG ? KMAX : 16;        // the host sends graphs with a degree above 16 to the LONG form
+    const Smem s = carve(smem_raw, ZSTRIDE, QS);
     const int opad = OKG ? OKG * 16 : lp.opad;
     const int ostride = OKG ? OKG * 16 + 8 : lp.ostride;
     float* dst = s.extra;                       // ds tile [TILE][ostride]
@@ -528,10 +529,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
             dst[r * ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
         }
     }
-    const int dmine = softmax_phase<false>(p, s, tile0, 0, nullptr, nullptr);
+    const int dmine = softmax_phase<false, QS>(p, s, tile0, 0, nullptr, nullptr);
     // edges 0..15 of every node in sweep 0; a second sweep (block-uniform, rare) for nodes with 17..24 edges.  The
     // per-edge work is independent across edges, so a sweep is the whole computation for its 16 edge slots.
-    const int nsweeps = LONG ? (__syncthreads(), 1) : (__syncthreads_or(dmine > 16) ? 2 : 1);
+    (void)dmine;
+    __syncthreads();
+    constexpr int nsweeps = 1;   // 16 edge slots per sweep: the non-LONG form only sees degrees <= 16, LONG carries 17..24 along
 
     const int nct = KPASS >> 4;   // 18
     const int okg = opad >> 4;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
         for (int nn = 0; nn < NPW; ++nn) {
             const int node = wave * NPW + nn;
             const int e = max(min(ebase + lr, dn[nn] - 1), 0);
-            rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[((size_t)node * KMAX + e) * QLD + 9]) : 0;
+            rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]) : 0;
             dq[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int pass = 0; pass < p.passes; ++pass) {
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                     if (dn[nn] <= 16) continue;            // wave-uniform
                     const int node = wave * NPW + nn;
                     const int e = min(16 + lr, dn[nn] - 1);
-                    const int row = __float_as_int(s.qbuf[((size_t)node * KMAX + e) * QLD + 9]);
+                    const int row = __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]);
                     const unsigned off = __umul24((unsigned)row, rowbytes) + laneoff;
                     const f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                     const f32x4 x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64u, 0, 0));
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
             for (int et = 0; et < ntile; ++et) {
                 const int edge = ebase + 16 * et + lr;
                 const bool ok = edge < d;
-                const float* qr = s.qbuf + ((size_t)node * KMAX + min(edge, d - 1)) * QLD;
+                const float* qr = s.qbuf + ((size_t)node * QS + min(edge, d - 1)) * QLD;
                 f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
                 else if (lq == 2) q[0] = qr[8];
@@ -1259,7 +1262,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         fill_core_params(p, g1, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, cout, io->ag,
                          d->shift, 0, 12, nullptr);
         LogitParams lp{io->ds, cout, opad, ostride, w.Wq, io->dl, io->dag, w.dc_part};
-        const size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
+        size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
         const bool vec4 = conv_vec4_ok(d);
         if (g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX &&
             !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1')) {
@@ -1284,6 +1287,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                    dim3(cdiv(d->n, TILE)), dim3(NTHREADS), smem, p, lp);                                             \
     } while (0)
                 const bool lng = d->max_deg > 16;
+                if (!lng) smem = smem_core_bytes(g1.zstride, 16) + (size_t)(TILE * ostride + 48) * 4;
                 const bool al16 = ((uintptr_t)io->ds % 16) == 0;
                 if (cout == 32 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 2); else FGC_DEEP_LAUNCH(false, 2); }
                 else if (cout == 64 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 4); else FGC_DEEP_LAUNCH(false, 4); }

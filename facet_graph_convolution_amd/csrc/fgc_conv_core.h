@@ -77,19 +77,20 @@ struct Smem {
     float* extra;   // op specific
 };
 
-__device__ __forceinline__ Smem carve(char* base, int zstride) {
+// qslots: edge slots per node the kernel keeps (KMAX, or 16 where the host guarantees max_deg <= 16: 12 KB less LDS)
+__device__ __forceinline__ Smem carve(char* base, int zstride, int qslots = KMAX) {
     Smem s;
     s.ztile = reinterpret_cast<float*>(base);
     size_t off = (size_t)TILE * zstride * 4;
     s.qbuf = reinterpret_cast<float*>(base + off);
-    off += (size_t)TILE * KMAX * QLD * 4;
+    off += (size_t)TILE * qslots * QLD * 4;
     s.deg = reinterpret_cast<int*>(base + off);
     off += (2 * TILE + 4) * 4;
     s.extra = reinterpret_cast<float*>(base + off);
     return s;
 }
-static inline size_t smem_core_bytes(int zstride) {
-    return (size_t)TILE * zstride * 4 + (size_t)TILE * KMAX * QLD * 4 + (2 * TILE + 4) * 4;
+static inline size_t smem_core_bytes(int zstride, int qslots = KMAX) {
+    return (size_t)TILE * zstride * 4 + (size_t)TILE * qslots * QLD * 4 + (2 * TILE + 4) * 4;
 }
 
 // ---- phase S: per-edge soft assignment ------------------------------------------------------
@@ -97,7 +98,7 @@ static inline size_t smem_core_bytes(int zstride) {
 // Edges [kbase, kbase+KMAX) of every node of the tile are processed per call (one call covers
 // every node whose degree is <= KMAX = 24, i.e. every reference K-list; longer in-edge lists of
 // asymmetric graphs take several chunks).  Returns this thread's node degree.
-template <bool WITH_DL>
+template <bool WITH_DL, int QS = KMAX>
 __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s, int tile0, int kbase,
                                              const float* dl, float* dgsum /* [9] += sum of dl over my edges */) {
     const int tid = threadIdx.x;
@@ -122,7 +123,7 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
     const int kend = min(d, kbase + KMAX);
     // all neighbour ids first, then all their logit rows: two memory round trips for the (up to 3) edges of this
     // thread instead of two per edge
-    constexpr int EPT = KMAX / 8;  // edges per thread
+    constexpr int EPT = QS / 8;  // edges per thread (QS < KMAX: the caller guarantees degrees <= QS)
     int jj[EPT];
     f32x4 g0[EPT], g1[EPT];
     float g8[EPT];
@@ -159,7 +160,7 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
             sum += l[m];
         }
         const float inv = 1.0f / sum;
-        float* q = s.qbuf + ((size_t)node * KMAX + k) * QLD;
+        float* q = s.qbuf + ((size_t)node * QS + k) * QLD;
         *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
         *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
         q[8] = l[8] * inv;
