@@ -104,6 +104,13 @@ struct LogitParams {
     float* dl;           // [nnz, 12]
     float* dag;          // [n, 24]  (writes 0..8)
     float* dc_part;      // [grid, 12]
+    // fused s = dy * lrelu'(y) / deg (+ db partials): set when the d-logits kernel computes s itself (dy != NULL)
+    const float* dy;
+    const float* y;
+    int act, bias_mask;
+    float alpha;
+    float* ds_out;       // [n, cout]
+    float* db_part;      // [cdiv(n, TILE), cout]
 };
 
 constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> ceil(18/4)
@@ -509,11 +516,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
         // rows tile0 .. tile0+31 of ds are one contiguous run of 32 * cout floats (cout == opad)
         constexpr int V4 = TILE * OKG * 16 / 4;          // float4s in the tile: 128 * OKG
         constexpr int PER = (V4 + NTHREADS - 1) / NTHREADS;
+        static_assert(V4 % NTHREADS == 0, "whole float4s per thread");
         const f32x4* src = reinterpret_cast<const f32x4*>(lp.ds + (size_t)tile0 * (OKG * 16));
         const int vmax = (min(p.n - tile0, TILE) * OKG * 16) / 4 - 1;     // last valid float4 (n > tile0)
         f32x4 v[PER];
+        if (lp.dy) {
+            // s = dy * lrelu'(y) / deg computed here instead of by a launch of its own: the tile goes to LDS and to ds
+            // (the data kernel gathers it), the bias-gradient partial of the tile's 32 rows to db_part
+            const f32x4* dy4 = reinterpret_cast<const f32x4*>(lp.dy + (size_t)tile0 * (OKG * 16));
+            const f32x4* y4 = reinterpret_cast<const f32x4*>(lp.y + (size_t)tile0 * (OKG * 16));
+            f32x4* out4 = reinterpret_cast<f32x4*>(lp.ds_out + (size_t)tile0 * (OKG * 16));
+            f32x4 gy[PER], yy[PER];
+            int dg[PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) v[k] = src[min(tid + k * NTHREADS, vmax)];
+            for (int k = 0; k < PER; ++k) {
+                const int t = min(tid + k * NTHREADS, vmax);
+                const int i = tile0 + t / (OKG * 4);
+                gy[k] = dy4[t];
+                if (lp.act) yy[k] = y4[t];
+                dg[k] = p.rowptr[i + 1] - p.rowptr[i];
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int t = tid + k * NTHREADS;
+                const bool ok = t <= vmax;
+                f32x4 g = gy[k];
+                if (lp.act) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) g[c] *= slope_from_y(yy[k][c], lp.alpha);
+                }
+                f32x4 sv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sv[c] = (ok && dg[k] > 0) ? g[c] / (float)dg[k] : 0.f;
+                v[k] = sv;
+                if (ok) out4[t] = sv;
+                const bool counts = ok && (!lp.bias_mask || dg[k] > 0);
+                const int r = t / (OKG * 4), o4 = t % (OKG * 4);
+                *reinterpret_cast<f32x4*>(dst + r * ostride + o4 * 4) = counts ? g : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            if (tid < OKG * 16) {
+                float acc = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < TILE; ++r) acc += dst[r * ostride + tid];
+                lp.db_part[(size_t)(tile0 / TILE) * (OKG * 16) + tid] = acc;
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = src[min(tid + k * NTHREADS, vmax)];
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int t = tid + k * NTHREADS;
@@ -1225,8 +1277,20 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const int stages = io->stages ? io->stages : 15;
     FGC_CHECK_ARG(io->data_tile_list == nullptr || (io->n_data_tiles >= 0 && io->n_data_tiles <= cdiv(d->n, TILE)),
                   "fgc_conv_bwd: n_data_tiles=%d outside [0, %d]", io->n_data_tiles, cdiv(d->n, TILE));
+    // The deep d-logits kernel of the 32- and 64-wide layers can compute s (and the db partials) in its prologue: one
+    // launch and one pass over dy / y less, when stages 1 and 2 come in the same call (a facet-sharded caller runs stage
+    // 1 on its own: the halo rows of s travel under the d-logits kernel)
+    const bool narrow_path = io->dx0 == nullptr && w.narrow;
+    const bool deep_ok = !narrow_path && g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX && conv_vec4_ok(d) &&
+                         cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) && (size_t)d->n * 4 * 128 < 0xFFFFFFFFull &&
+                         !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1') &&
+                         !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+    const bool fuse_ds = (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, TILE) &&
+                         ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
+                         (!d->act || ((uintptr_t)io->y % 16) == 0) &&
+                         !(getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1');
     // s = dy*lrelu'(y)/deg, db partials
-    if (stages & 1) {
+    if ((stages & 1) && !fuse_ds) {
         int cp2 = 1;
         while (cp2 < cout) cp2 <<= 1;
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
@@ -1262,6 +1326,15 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         fill_core_params(p, g1, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, cout, io->ag,
                          d->shift, 0, 12, nullptr);
         LogitParams lp{io->ds, cout, opad, ostride, w.Wq, io->dl, io->dag, w.dc_part};
+        if (fuse_ds) {
+            lp.dy = io->dy;
+            lp.y = io->y ? io->y : io->dy;
+            lp.act = d->act;
+            lp.bias_mask = d->bias_mask;
+            lp.alpha = d->alpha;
+            lp.ds_out = io->ds;
+            lp.db_part = w.db_part;
+        }
         size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
         const bool vec4 = conv_vec4_ok(d);
         if (g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX &&
