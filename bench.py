@@ -274,7 +274,10 @@ def main():
             if r[4]:
                 fam[r[1].split("/", 1)[1]] = fam.get(r[1].split("/", 1)[1], 0.0) + r[0]
         top = max(fam, key=fam.get) if fam else None
-        dom = next((r for r in rows if r[4] and r[1].split("/", 1)[1] == top), None)
+        # ... the launch with the most algorithmic work (ties: first by name, so that the choice does not flip between
+        # two equal layers from run to run)
+        cands = sorted((r for r in rows if r[4] and r[1].split("/", 1)[1] == top), key=lambda r: (-r[4], r[1]))
+        dom = cands[0] if cands else None
         if dom:
             ms, key, cnt, avg_us, fl = dom
             ach = fl / (avg_us * 1e-6) / 1e12

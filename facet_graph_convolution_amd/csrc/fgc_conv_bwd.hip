@@ -111,6 +111,8 @@ struct LogitParams {
     float alpha;
     float* ds_out;       // [n, cout]
     float* db_part;      // [cdiv(n, TILE), cout]
+    int a_global;        // LONG form, cout % 16 == 0: the dz GEMM reads its ds operand from global memory (the tile is
+                         // L1-resident) instead of an LDS copy, which keeps two workgroups per CU for wide layers
 };
 
 constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> ceil(18/4)
@@ -507,12 +509,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
     const int opad = OKG ? OKG * 16 : lp.opad;
     const int ostride = OKG ? OKG * 16 + 8 : lp.ostride;
     float* dst = s.extra;                       // ds tile [TILE][ostride]
-    float* red = dst + TILE * ostride;          // [4][12]
+    float* red = dst + ((LONG && lp.a_global) ? 0 : TILE * ostride);          // [4][12]
     const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
 
-    if constexpr (OKG > 0) {
+    const bool a_global = LONG && lp.a_global;      // block-uniform
+    if (a_global) {
+        // no LDS copy of the ds tile
+    } else if constexpr (OKG > 0) {
         // rows tile0 .. tile0+31 of ds are one contiguous run of 32 * cout floats (cout == opad)
         constexpr int V4 = TILE * OKG * 16 / 4;          // float4s in the tile: 128 * OKG
         constexpr int PER = (V4 + NTHREADS - 1) / NTHREADS;
@@ -652,8 +657,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 auto mmw = [&](int g, const f32x4 (&b)[K1_CTW]) {
                     f32x4 a[RT];
 #pragma unroll
-                    for (int r = 0; r < RT; ++r)
-                        a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * ostride + g * 16 + lq * 4);
+                    for (int r = 0; r < RT; ++r) {
+                        if (a_global)
+                            a[r] = *reinterpret_cast<const f32x4*>(lp.ds + (size_t)min(tile0 + r * 16 + lr, p.n - 1) * lp.cout +
+                                                                   g * 16 + lq * 4);
+                        else
+                            a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * ostride + g * 16 + lq * 4);
+                    }
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c)
 #pragma unroll
@@ -1286,6 +1296,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                          !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1') &&
                          !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
     const bool fuse_ds = (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, TILE) &&
+                         !(d->max_deg > 16 && cout > 32) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
                          !(getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1');
@@ -1361,6 +1372,11 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     } while (0)
                 const bool lng = d->max_deg > 16;
                 if (!lng) smem = smem_core_bytes(g1.zstride, 16) + (size_t)(TILE * ostride + 48) * 4;
+                // 24 edge slots + the ds tile of a 64- or 128-wide layer do not fit twice into a CU's LDS
+                if (lng && cout > 32 && cout % 16 == 0 && ((uintptr_t)io->ds % 16) == 0) {
+                    lp.a_global = 1;
+                    smem = smem_core_bytes(g1.zstride) + (size_t)48 * 4;
+                }
                 const bool al16 = ((uintptr_t)io->ds % 16) == 0;
                 if (cout == 32 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 2); else FGC_DEEP_LAUNCH(false, 2); }
                 else if (cout == 64 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 4); else FGC_DEEP_LAUNCH(false, 4); }
