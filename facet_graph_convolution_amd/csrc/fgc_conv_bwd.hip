@@ -1406,7 +1406,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
         if (g2.lpn == 8 && w8_supported(p, io->max_in_deg)) {
-            rc = launch_data_w8(p, ep, smem, st);
+            rc = launch_data_w8(p, ep, smem, io->max_in_deg, st);
             if (rc) return rc;
         } else
             rc = launch_data<8>(p, ep, vec4, smem, st);

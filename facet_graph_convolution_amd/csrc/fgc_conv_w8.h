@@ -28,7 +28,8 @@ struct DataEpilogue {
 };
 
 bool w8_supported(const CoreParams& p, int max_deg);
-int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, hipStream_t st);
-int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, hipStream_t st);
+// max_deg: the largest degree of the gathered graph (<= KMAX); <= 16 selects the 16-slot form of the fast kernel
+int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st);
+int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st);
 
 }  // namespace fgc

@@ -53,10 +53,13 @@ __device__ __forceinline__ void edge_batch(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // the wave's largest degree rounded up to 8, all lanes run the same (scalar) trip count, rows are fetched with
 // buffer loads whose 32-bit offset is one v_mad_u32_u24 from the row id, and the row id travels with q[8] in one
 // ds_read_b64.  The generic form keeps per-lane degree tests (exec masking) and 64-bit addressing.
-template <bool DATA, bool FAST>
+// QS: edge slots per node kept in LDS - 16 when the host knows that no node has more edges (each of the 16 softmax lanes
+// of a node then owns one slot instead of two, and the tile needs 12 KB less LDS), KMAX otherwise
+template <bool DATA, bool FAST, int QS>
 __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, ZSTRIDE);
+    const Smem s = carve(smem_raw, ZSTRIDE, QS);
+    constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
     float* dagt = s.extra;  // DATA: [TILE][24]
     const int tile0 = block_tile0(p);
     const int tid = threadIdx.x;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         for (int m = 0; m < FGC_M; ++m) ctr[m] = 0.f;
         if (i < p.n) {
             e0 = p.rowptr[i];
-            d = min(p.rowptr[i + 1] - e0, KMAX);
+            d = min(p.rowptr[i + 1] - e0, QS);
             const float* ar = p.ag + (size_t)(i >> p.ag_shift) * FGC_AG_LD + p.ctr_off;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
@@ -101,27 +104,27 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             dwave = dmax;
         }
         const int dfill = (dwave + 7) & ~7;
-        int jj[2];
-        f32x4 g0[2], g1[2];
-        float g8[2];
+        int jj[SPL];
+        f32x4 g0[SPL], g1[SPL];
+        float g8[SPL];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
             jj[t] = k < d ? p.col[e0 + k] : 0;
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < SPL; ++t) {
             const float* gr = p.ag + (size_t)(jj[t] >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
             g0[t] = *reinterpret_cast<const f32x4*>(gr);
             g1[t] = *reinterpret_cast<const f32x4*>(gr + 4);
             g8[t] = gr[8];
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
             if (k >= d) {
                 if (FAST && k < dfill) {  // zero-weight slot pointing at a valid row
-                    float* q = s.qbuf + ((size_t)node * KMAX + k) * QLD;
+                    float* q = s.qbuf + ((size_t)node * QS + k) * QLD;
                     *reinterpret_cast<f32x4*>(q) = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(q + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
                     q[8] = 0.f;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 sum += l[m];
             }
             const float inv = 1.0f / sum;
-            float* q = s.qbuf + ((size_t)node * KMAX + k) * QLD;
+            float* q = s.qbuf + ((size_t)node * QS + k) * QLD;
             *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
             *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
             q[8] = l[8] * inv;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 
     const int cl = kl;
     const int d = s.deg[node];
-    const float* qb = s.qbuf + (size_t)node * KMAX * QLD;
+    const float* qb = s.qbuf + (size_t)node * QS * QLD;
     for (int pass = 0; pass < p.passes; ++pass) {
         // ---------------- phase A: z[m][2] = sum_k q[k][m] * x_j(k)[2]; every row is requested before the first FMA
         f32x2 z[FGC_M];
@@ -419,31 +422,36 @@ static bool w8_fast(const CoreParams& p) {
     return p.cg % 32 == 0 && (p.c1 == 0 || p.c0 % 32 == 0) && (size_t)p.n * 4 * 128 < 0xFFFFFFFFull;
 }
 
-template <bool DATA, bool FAST>
+template <bool DATA, bool FAST, int QS>
 static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST, QS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
         attr = true;
     }
-    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST>), dim3(core_grid(p)),
-               dim3(W8_THREADS), smem, p, fe, de);
+    smem -= (size_t)TILE * (KMAX - QS) * QLD * 4;     // the caller sized the tile for KMAX slots
+    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS>),
+               dim3(core_grid(p)), dim3(W8_THREADS), smem, p, fe, de);
     FGC_CHECK_LAUNCH("conv_w8_kernel");
     return FGC_OK;
 }
 
 template <bool DATA>
-static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
-    return w8_fast(p) ? launch_w8f<DATA, true>(p, fe, de, smem, st) : launch_w8f<DATA, false>(p, fe, de, smem, st);
+static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, int max_deg,
+                     hipStream_t st) {
+    if (!w8_fast(p)) return launch_w8f<DATA, false, KMAX>(p, fe, de, smem, st);
+    return max_deg <= 16 ? launch_w8f<DATA, true, 16>(p, fe, de, smem, st)
+                         : launch_w8f<DATA, true, KMAX>(p, fe, de, smem, st);
 }
 
-int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, hipStream_t st) {
+int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st) {
     DataEpilogue de{};
-    return launch_w8<false>(p, ep, de, smem, st);
+    return launch_w8<false>(p, ep, de, smem, max_deg, st);
 }
-int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, hipStream_t st) {
+int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st) {
     FwdEpilogue fe{};
-    return launch_w8<true>(p, fe, ep, smem, st);
+    return launch_w8<true>(p, fe, ep, smem, max_deg, st);
 }
 
 }  // namespace fgc
