@@ -369,6 +369,77 @@ extern "C" int fgc_graph_patch(const int32_t* adj, int32_t n, int32_t K, int32_t
     return FGC_OK;
 }
 
+// utils.py:1298-1410: breadth-first mesh patch (faces, their vertices and the K-list among the patch's faces)
+extern "C" int fgc_mesh_patch(const float* V, int32_t nv, const int32_t* F, int32_t nf, const int32_t* adj, int32_t K,
+                              int32_t face_num, int32_t seed, float* v_out, int32_t v_cap, int32_t* f_out,
+                              int32_t* adj_out, int32_t* v_old, int32_t* f_old, int32_t* n_v, int32_t* n_f) {
+    FGC_CHECK_ARG(V && F && adj && v_out && f_out && adj_out && v_old && f_old && n_v && n_f, "fgc_mesh_patch: null pointer");
+    FGC_CHECK_ARG(nv > 0 && nf > 0 && K > 1 && face_num > 0 && seed >= 0 && seed < nf && v_cap > 0,
+                  "fgc_mesh_patch: nv=%d nf=%d K=%d face_num=%d seed=%d v_cap=%d", nv, nf, K, face_num, seed, v_cap);
+    const int f_cap = face_num + K;
+    for (size_t t = 0; t < (size_t)f_cap * K; ++t) adj_out[t] = 0;   // one-indexed K-list: 0 = empty slot
+    std::vector<int> v_new(nv, -1), f_new(nf, -1);
+    std::vector<int> q;
+    size_t qh = 0;
+    int vc = 0, fc = 0;
+    bool overflow = false;
+    auto add_vertex = [&](int v) {
+        if (v_new[v] != -1) return;
+        if (vc >= v_cap) {
+            overflow = true;
+            return;
+        }
+        v_new[v] = vc;
+        v_old[vc] = v;
+        for (int t = 0; t < 3; ++t) v_out[3 * (size_t)vc + t] = V[3 * (size_t)v + t];
+        ++vc;
+    };
+    auto add_face = [&](int f) {
+        for (int t = 0; t < 3; ++t) add_vertex(F[3 * (size_t)f + t]);
+        if (overflow) return;
+        for (int t = 0; t < 3; ++t) f_out[3 * (size_t)fc + t] = v_new[F[3 * (size_t)f + t]];
+        f_new[f] = fc;
+        f_old[fc] = f;
+        ++fc;
+    };
+    add_face(seed);
+    q.push_back(seed);
+    // a face is only added while fc < face_num at loop entry, then at most K - 1 more: face_num + K rows suffice
+    while (fc < face_num && qh < q.size() && !overflow) {
+        const int cur = q[qh++];
+        const int r = f_new[cur];
+        adj_out[(size_t)r * K] = r + 1;
+        for (int s = 1; s < K; ++s) {
+            const int nb = adj[(size_t)cur * K + s] - 1;
+            if (nb == -1) break;
+            if (f_new[nb] == -1) {
+                add_face(nb);
+                if (overflow) break;
+                q.push_back(nb);
+            }
+            adj_out[(size_t)r * K + s] = f_new[nb] + 1;
+        }
+    }
+    FGC_CHECK_ARG(!overflow, "fgc_mesh_patch: more than %d vertices in a patch of %d faces (the reference raises IndexError)",
+                  v_cap, face_num);
+    // faces still queued when growth stopped: their rows list the neighbours that made it into the patch, compacted
+    while (qh < q.size()) {
+        const int cur = q[qh++];
+        const int r = f_new[cur];
+        adj_out[(size_t)r * K] = r + 1;
+        int c = 1;
+        for (int s = 1; s < K; ++s) {
+            const int nb = adj[(size_t)cur * K + s] - 1;
+            if (nb == -1) break;
+            if (f_new[nb] == -1) continue;
+            adj_out[(size_t)r * K + c++] = f_new[nb] + 1;
+        }
+    }
+    *n_v = vc;
+    *n_f = fc;
+    return FGC_OK;
+}
+
 // utils.py:370-395
 extern "C" int fgc_vertices_faces(const int32_t* F, int32_t nf, int32_t nv, int32_t k_v, int32_t* out) {
     FGC_CHECK_ARG(F && out && nf > 0 && nv > 0 && k_v > 0, "fgc_vertices_faces: bad arguments");

@@ -87,7 +87,7 @@ class PreprocessedData(object):
         V0 = np.asarray(V0, dtype=np.float32)
         faces0 = np.asarray(faces0)
         if faces0.shape[0] > self.maxSize:
-            raise NotImplementedError("the multi-scale pipeline is built for whole meshes (patches: dataClasses.py:270-372)")
+            return self._add_mesh_patches_with_vertices(V0, faces0, GTV, seed)
         first = len(self.in_list)
         self.addMesh_TimeEfficient(V0, faces0, GTV=GTV, seed=seed, parents=parents)
         oldToNew = self.permutations[first]
@@ -108,6 +108,54 @@ class PreprocessedData(object):
         self.fOldInd_list.append([])
         self.vOldInd_list.append([])
         return V0.shape[0], faces0.shape[0]
+
+    def _add_mesh_patches_with_vertices(self, V0, faces0, GTV, seed):
+        """dataClasses.py:270-372: meshes above maxSize are cut into breadth-first MESH patches (getMeshPatch) around
+        seeds drawn with np.random among the faces no patch has covered yet, until every face is covered; components of
+        fewer than 100 faces are dropped, and with a ground-truth point cloud so are patches whose bounding box holds
+        fewer GT points than the patch has vertices.  Every patch brings its own vertices (normalised coordinates),
+        faces, vertex-face table and graph levels; vOldInd_list / fOldInd_list map them back."""
+        f_normals0 = utils.computeFacesNormals(V0, faces0)
+        f_adj0 = utils.getFacesLargeAdj(faces0, K_faces)
+        f_pos0 = utils.getTrianglesBarycenter(V0, faces0, normalize=True)
+        f_normals_pos = np.concatenate((f_normals0, f_pos0), axis=1)
+        addGT = GTV is not None
+        if addGT:
+            GTV = np.asarray(GTV, dtype=np.float32)
+            gtf_normals0 = utils.computeFacesNormals(GTV, faces0)
+            Vn, GTn = utils.normalizePointSets(V0, GTV)
+        else:
+            Vn, _ = utils.normalizePointSets(V0, V0)
+        facesNum = faces0.shape[0]
+        faceCheck = np.zeros(facesNum)
+        faceRange = np.arange(facesNum)
+        while np.any(faceCheck == 0):
+            toBeProcessed = faceRange[faceCheck == 0]
+            faceSeed = toBeProcessed[np.random.randint(toBeProcessed.shape[0])]
+            pV, pF, pAdj, vOldInd, fOldInd = utils.getMeshPatch(Vn, faces0, f_adj0, self.patchSize, faceSeed)
+            faceCheck[fOldInd] += 1
+            if fOldInd.shape[0] < 100:          # small disjoint components are not added
+                continue
+            if addGT:
+                patchGTV = utils.takePointSetSlice(GTn, utils.getBoundingBox(pV))
+                if patchGTV.shape[0] < pV.shape[0]:     # no ground truth in the window: a fake surface
+                    continue
+            first = len(self.in_list)
+            self._add_graph(pAdj, f_normals_pos[fOldInd], gtf_normals0[fOldInd] if addGT else None, fOldInd, seed, None)
+            oldToNew = self.permutations[first]
+            new_N = len(oldToNew)
+            newToOld = np.empty(new_N, dtype=np.int64)
+            newToOld[oldToNew] = np.arange(new_N)
+            faces_p = np.concatenate((pF.astype(np.int64), -np.ones((new_N - pF.shape[0], 3), dtype=np.int64)),
+                                     axis=0)[newToOld]
+            self.v_list.append(pV[np.newaxis])
+            self.faces_list.append(faces_p[np.newaxis])
+            self.v_faces_list.append(utils.getVerticesFaces(faces_p, 25, pV.shape[0])[np.newaxis])
+            self.vOldInd_list.append(vOldInd)
+            self.fOldInd_list.append(fOldInd)
+            if addGT:
+                self.__dict__.setdefault("gtv_list", []).append(patchGTV[np.newaxis])
+        return V0.shape[0], facesNum
 
     def _add_graph(self, f_adj, f_normals_pos, GTf_normals, patch_index, seed, parents):
         """One mesh or one patch: coarsen, pad with fake nodes, reorder, append (dataClasses.py:106-171,172-233)."""

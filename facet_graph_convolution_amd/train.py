@@ -160,9 +160,10 @@ def update_position_MS(x, face_normals_list, faces, v_faces0, coarsening_steps, 
 
 
 def inferNet(inputMesh, net_or_checkpoint, device="cuda"):
-    """train.py:147-376, whole-mesh case: the multi-scale network (three heads), its three normal fields normalised,
-    update_position_MS with [80, 20, 20] iterations.  inputMesh: InferenceMesh filled by addMeshWithVertices; the
-    network must have been built with multi_scale=True.  Returns the reference's 9-tuple
+    """train.py:147-376: the multi-scale network (three heads), its three normal fields normalised, update_position_MS
+    with [80, 20, 20] iterations - on the whole mesh, or patch by patch when addMeshWithVertices cut it (maxSize).
+    inputMesh: InferenceMesh filled by addMeshWithVertices; the network must have been built with multi_scale=True.
+    Returns the reference's 9-tuple
     (points, points_mid, points_coarse, fine / mid / coarse normals [F,3] in face order, fine / mid / coarse positions
     [F,3]; as in the reference the three position arrays are the input barycentre channels)."""
     from . import ops, tfckpt
@@ -173,33 +174,58 @@ def inferNet(inputMesh, net_or_checkpoint, device="cuda"):
         load_checkpoint(net_or_checkpoint, net)
     if not net.multi_scale:
         raise ValueError("inferNet needs a network with the multi-scale heads (multi_scale=True)")
-    if len(inputMesh.in_list) != 1 or not inputMesh.v_list:
-        raise NotImplementedError("whole meshes prepared by addMeshWithVertices")
-    x, adjs = inputMesh.in_list[0], inputMesh.adj_list[0]
-    net.bind_mesh(x, adjs)
-    net.forward(rotate=False)
-    B = net.buffers
+    if not inputMesh.v_list or len(inputMesh.v_list) != len(inputMesh.in_list):
+        raise ValueError("inferNet needs a mesh prepared by addMeshWithVertices")
     dev = net.device
-    n0 = B["nconv"]                                              # normalizeTensor(y0), done by forward()
-    n1 = _normalize_rows_like_reference(B["y1"])                 # train.py:192-193
-    n2 = _normalize_rows_like_reference(B["y2"])
-    xp = torch.as_tensor(inputMesh.v_list[0][0], dtype=torch.float32, device=dev)
-    faces = torch.as_tensor(np.asarray(inputMesh.faces_list[0][0]).astype(np.int32), device=dev)
-    vf = torch.as_tensor(np.asarray(inputMesh.v_faces_list[0][0]).astype(np.int32), device=dev)
-    pts, dx = ops.vertex_update_ms(xp, [n0, n1, n2], faces, vf, (80, 20, 20))
-    pts_mid = pts - dx[2]                                        # train.py:249-250
-    pts_coarse = pts_mid - dx[1]
-    perm = torch.as_tensor(np.asarray(inputMesh.permutations[0]).astype(np.int64), device=dev)
-    nf = inputMesh.num_faces[0]
-    up1 = n1.repeat_interleave(4, dim=0)                         # custom_upsampling, train.py:222-223
-    up2 = n2.repeat_interleave(16, dim=0)
-    fine = n0[perm][:nf]
-    mid = _normalize_rows_like_reference(up1)[perm][:nf]
-    coarse = _normalize_rows_like_reference(up2)[perm][:nf]
-    pos = torch.as_tensor(np.asarray(x)[0, :, 3:].astype(np.float32), device=dev)[perm][:nf]   # train.py:288,296-297
-    torch.cuda.synchronize()
     c = lambda t: t.cpu().numpy()
-    return c(pts), c(pts_mid), c(pts_coarse), c(fine), c(mid), c(coarse), c(pos), c(pos), c(pos)
+    n_patches = len(inputMesh.in_list)
+    if n_patches > 1:
+        # train.py:255-330: the vertex positions of the patches are averaged over the patches that hold a vertex, the
+        # normals of a face are those of the last patch that holds it, and (as in the reference) the three position
+        # arrays are the last patch's input barycentre channels, padded and in node order
+        vnum, fnum = inputMesh.vNum, inputMesh.fNum
+        acc = [torch.zeros(vnum, 3, dtype=torch.float32, device=dev) for _ in range(3)]
+        weights = torch.zeros(vnum, 3, dtype=torch.float32, device=dev)
+        normals = [torch.zeros(fnum, 3, dtype=torch.float32, device=dev) for _ in range(3)]
+        pos = None
+    for i in range(n_patches):
+        x, adjs = inputMesh.in_list[i], inputMesh.adj_list[i]
+        net.bind_mesh(x, adjs)
+        net.forward(rotate=False)
+        B = net.buffers
+        n0 = B["nconv"]                                              # normalizeTensor(y0), done by forward()
+        n1 = _normalize_rows_like_reference(B["y1"])                 # train.py:192-193
+        n2 = _normalize_rows_like_reference(B["y2"])
+        xp = torch.as_tensor(inputMesh.v_list[i][0], dtype=torch.float32, device=dev)
+        faces = torch.as_tensor(np.asarray(inputMesh.faces_list[i][0]).astype(np.int32), device=dev)
+        vf = torch.as_tensor(np.asarray(inputMesh.v_faces_list[i][0]).astype(np.int32), device=dev)
+        pts, dx = ops.vertex_update_ms(xp, [n0, n1, n2], faces, vf, (80, 20, 20))
+        pts_mid = pts - dx[2]                                        # train.py:249-250
+        pts_coarse = pts_mid - dx[1]
+        perm = torch.as_tensor(np.asarray(inputMesh.permutations[i]).astype(np.int64), device=dev)
+        nf = inputMesh.num_faces[i]
+        up1 = n1.repeat_interleave(4, dim=0)                         # custom_upsampling, train.py:222-223
+        up2 = n2.repeat_interleave(16, dim=0)
+        fine = n0[perm][:nf]
+        mid = _normalize_rows_like_reference(up1)[perm][:nf]
+        coarse = _normalize_rows_like_reference(up2)[perm][:nf]
+        pos_nodes = torch.as_tensor(np.asarray(x)[0, :, 3:].astype(np.float32), device=dev)
+        if n_patches == 1:
+            pos = pos_nodes[perm][:nf]                               # train.py:288,296-297
+            torch.cuda.synchronize()
+            return c(pts), c(pts_mid), c(pts_coarse), c(fine), c(mid), c(coarse), c(pos), c(pos), c(pos)
+        vold = torch.as_tensor(np.asarray(inputMesh.vOldInd_list[i]).astype(np.int64), device=dev)
+        fold = torch.as_tensor(np.asarray(inputMesh.fOldInd_list[i]).astype(np.int64), device=dev)
+        for a, p_ in zip(acc, (pts, pts_mid, pts_coarse)):
+            a.index_add_(0, vold, p_)
+        weights.index_add_(0, vold, torch.ones_like(pts))
+        for nrm, v in zip(normals, (fine, mid, coarse)):
+            nrm[fold] = v
+        pos = pos_nodes
+    w = torch.clamp(weights, min=1.0)
+    torch.cuda.synchronize()
+    return (c(acc[0] / w), c(acc[1] / w), c(acc[2] / w), c(normals[0]), c(normals[1]), c(normals[2]), c(pos), c(pos),
+            c(pos))
 
 
 def _normalize_rows_like_reference(t):

@@ -142,6 +142,47 @@ def getGraphPatch_wMask(fAdjIn, nodesNum, seed, mask, minPatchSize):
     return out[:cnt.value].copy(), old[:cnt.value].copy(), int(nxt.value)
 
 
+def getMeshPatch(vIn, fIn, fAdjIn, faceNum, seed):
+    """utils.py:1298-1410: (vOut [nv',3] float32, fOut [nf',3] in patch vertex ids, fAdjOut [nf',K] one-indexed, vOldInd,
+    fOldInd), natively and bit-exact (same breadth-first queue discipline; the reference's vertex buffer of
+    int(0.6 * faceNum) + K rows is kept, overflowing it raises like the reference's IndexError)."""
+    from . import _lib
+    import ctypes as C
+    V = np.ascontiguousarray(np.asarray(vIn), dtype=np.float32)
+    F = np.ascontiguousarray(np.asarray(fIn), dtype=np.int32)
+    adj = np.ascontiguousarray(np.asarray(fAdjIn), dtype=np.int32)
+    K = adj.shape[1]
+    faceNum = int(faceNum)
+    v_cap = int(faceNum * 0.6) + K
+    v_out = np.empty((v_cap, 3), dtype=np.float32)
+    f_out = np.empty((faceNum + K, 3), dtype=np.int32)
+    adj_out = np.empty((faceNum + K, K), dtype=np.int32)
+    v_old = np.empty(v_cap, dtype=np.int32)
+    f_old = np.empty(faceNum + K, dtype=np.int32)
+    n_v, n_f = C.c_int32(0), C.c_int32(0)
+    rc = _lib.lib().fgc_mesh_patch(V.ctypes.data, V.shape[0], F.ctypes.data, F.shape[0], adj.ctypes.data, K, faceNum,
+                                   int(seed), v_out.ctypes.data, v_cap, f_out.ctypes.data, adj_out.ctypes.data,
+                                   v_old.ctypes.data, f_old.ctypes.data, C.byref(n_v), C.byref(n_f))
+    if rc:
+        raise IndexError(_lib.lib().fgc_last_error().decode())
+    nv, nf = n_v.value, n_f.value
+    return (v_out[:nv].copy(), f_out[:nf].astype(np.int64), adj_out[:nf].astype(np.int64), v_old[:nv].astype(np.int64),
+            f_old[:nf].astype(np.int64))
+
+
+def getBoundingBox(points):
+    """utils.py:2130-2137: [[xmin, xmax], [ymin, ymax], [zmin, zmax]]."""
+    points = np.asarray(points)
+    return np.stack([points.min(axis=0), points.max(axis=0)], axis=1)
+
+
+def takePointSetSlice(points, boundBox):
+    """utils.py:2109-2125: the points inside the (closed) box."""
+    points = np.asarray(points)
+    boundBox = np.asarray(boundBox)
+    return points[np.all((points >= boundBox[:, 0]) & (points <= boundBox[:, 1]), axis=1)]
+
+
 def coarsen_klists(adj, pos, normals, levels=4, K=23, seed=0, parents=None, keep=(0, 2, 4)):
     """listToSparseWNormals + coarsen + sparseToList (utils.py:1753-1827, lib/coarsening.py:5-31).
 

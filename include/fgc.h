@@ -115,6 +115,18 @@ int fgc_graph_patch(const int32_t* adj_h, int32_t n, int32_t K, int32_t nodes_nu
                     int32_t min_patch_size, int32_t* patch_adj_h, int32_t* old_index_h, int32_t* patch_n,
                     int32_t* next_seed);
 
+/* Breadth-first patch of a MESH = getMeshPatch (utils.py:1298-1410), host: what the multi-scale pipeline cuts meshes
+ * above maxSize into (dataClasses.py:270-372).  V_h [nv,3], F_h [nf,3] int32, adj_h [nf,K] one-indexed K-list of the
+ * faces.  Grows from face `seed` until face_num faces are in (plus the at most K-1 discovered by the last expanded
+ * face).  Outputs, all in discovery order: v_out_h [v_cap,3] vertices of the patch (v_cap = int(0.6 * face_num) + K in
+ * the reference; -EINVAL where the reference raises IndexError), f_out_h [face_num+K,3] faces in patch vertex ids,
+ * adj_out_h [face_num+K,K] their one-indexed K-list (rows of faces still queued when growth stopped are compacted),
+ * v_old_h / f_old_h the mesh index of every patch vertex / face, *n_v / *n_f the counts.  Same queue discipline as the
+ * reference: bit-identical outputs. */
+int fgc_mesh_patch(const float* V_h, int32_t nv, const int32_t* F_h, int32_t nf, const int32_t* adj_h, int32_t K,
+                   int32_t face_num, int32_t seed, float* v_out_h, int32_t v_cap, int32_t* f_out_h, int32_t* adj_out_h,
+                   int32_t* v_old_h, int32_t* f_old_h, int32_t* n_v, int32_t* n_f);
+
 /* Faces incident to every vertex = getVerticesFaces (utils.py:370-395), host.  faces_h [nf,3] int32 with -1 rows for
  * fake faces (skipped); v_faces_h [nv, k_v] receives the face (row) indices in face order, -1 padded.  -EINVAL if a
  * vertex is in more than k_v faces (the reference raises IndexError). */

@@ -305,3 +305,59 @@ def normalize_point_sets(vl1, vl2):
     hi = np.maximum(vl1.max(0), vl2.max(0))
     diag = math.sqrt(float(((hi - lo) ** 2).sum()))
     return vl1 / diag, vl2 / diag
+
+
+
+def mesh_patch(vIn, fIn, fAdjIn, faceNum, seed):
+    """getMeshPatch (utils.py:1298-1410) restated: breadth-first growth from face `seed`; returns
+    (vOut, fOut, fAdjOut one-indexed, vOldInd, fOldInd)."""
+    import collections
+    vIn, fIn, fAdjIn = np.asarray(vIn), np.asarray(fIn), np.asarray(fAdjIn)
+    K = fAdjIn.shape[1]
+    v_new, f_new = {}, {}
+    v_old, f_old, f_out = [], [], []
+    adj_out = {}
+
+    def add_face(f):
+        for v in fIn[f]:
+            v = int(v)
+            if v not in v_new:
+                v_new[v] = len(v_old)
+                v_old.append(v)
+        f_new[f] = len(f_old)
+        f_old.append(f)
+        f_out.append([v_new[int(v)] for v in fIn[f]])
+
+    q = collections.deque([int(seed)])
+    add_face(int(seed))
+    while len(f_old) < faceNum and q:                      # utils.py:1349-1376
+        cur = q.popleft()
+        row = [0] * K
+        row[0] = f_new[cur] + 1
+        for s in range(1, K):
+            nb = int(fAdjIn[cur, s]) - 1
+            if nb == -1:
+                break
+            if nb not in f_new:
+                add_face(nb)
+                q.append(nb)
+            row[s] = f_new[nb] + 1
+        adj_out[f_new[cur]] = row
+    while q:                                               # utils.py:1381-1402: compacted rows of the faces still queued
+        cur = q.popleft()
+        row = [0] * K
+        row[0] = f_new[cur] + 1
+        c = 1
+        for s in range(1, K):
+            nb = int(fAdjIn[cur, s]) - 1
+            if nb == -1:
+                break
+            if nb not in f_new:
+                continue
+            row[c] = f_new[nb] + 1
+            c += 1
+        adj_out[f_new[cur]] = row
+    nf = len(f_old)
+    return (vIn[v_old].astype(np.float32), np.asarray(f_out, dtype=np.int64),
+            np.asarray([adj_out.get(r, [0] * K) for r in range(nf)], dtype=np.int64), np.asarray(v_old, dtype=np.int64),
+            np.asarray(f_old, dtype=np.int64))

@@ -338,6 +338,22 @@ def patch_case(tag, F, patch_size, min_patch_size, seed):
     save("patch_%s.npz" % tag, **out)
 
 
+def mesh_patch_case(tag, V, F, cases):
+    """getMeshPatch (utils.py:1298-1410) for a few (faceNum, seed) pairs, plus the bounding-box slice helpers
+    (utils.py:2109-2137) on the patch's vertices."""
+    adj = ref_utils.getFacesLargeAdj(F, 23)
+    out = {"verts": V.astype(np.float32), "faces": F.astype(np.int32), "adj": adj.astype(np.int32),
+           "cases": np.asarray(cases, dtype=np.int32)}
+    for k, (face_num, seed) in enumerate(cases):
+        vO, fO, aO, vOld, fOld = ref_utils.getMeshPatch(V.astype(np.float32), F, adj, face_num, seed)
+        bb = ref_utils.getBoundingBox(vO)
+        inside = ref_utils.takePointSetSlice(V.astype(np.float32), bb)
+        out.update({"v%d" % k: vO.astype(np.float32), "f%d" % k: fO.astype(np.int32), "a%d" % k: aO.astype(np.int32),
+                    "vold%d" % k: vOld.astype(np.int32), "fold%d" % k: fOld.astype(np.int32),
+                    "bb%d" % k: bb.astype(np.float32), "slice%d" % k: inside.astype(np.float32)})
+    save("meshpatch_%s.npz" % tag, **out)
+
+
 def random_klist(n, K, seed, zero_rows=(3,), dup=True):
     """Random one-indexed K-list with self slot, ragged degrees, duplicates and an isolated (all-zero) row."""
     rs = np.random.RandomState(seed)
@@ -404,6 +420,16 @@ def main():
         # two disjoint components (a fresh random seed is needed when a component is exhausted)
         V2, F2 = icosphere(2)
         patch_case("two_spheres", np.concatenate([F2, F2 + V2.shape[0]]), 150, 60, seed=12)
+    if want("meshpatch") and not F64:
+        Vp, Fp = torus(24, 20)
+        mesh_patch_case("torus960", Vp, Fp, [(300, 0), (300, 517), (100, 959), (2000, 3)])
+        # open mesh with a ragged border + a second component
+        Vt2, Ft2 = torus(20, 16)
+        used, Fo = np.unique(Ft2[:450], return_inverse=True)
+        V2, F2 = icosphere(1)
+        Fo2 = np.concatenate([Fo.reshape(-1, 3), F2 + used.shape[0]]).astype(Ft2.dtype)
+        Vo2 = np.concatenate([Vt2[used], V2 + 5.0])
+        mesh_patch_case("open_plus_sphere", Vo2, Fo2, [(200, 10), (60, 455), (450, 449)])
     if want("vertex"):
         # closed mesh: noisy icosphere, target normals = normals of the clean sphere
         Vn = add_noise(V, F)

@@ -211,3 +211,53 @@ def test_multiscale_inference_driver_matches_oracle():
     np.testing.assert_allclose(out[4], up1, atol=2e-5)
     np.testing.assert_allclose(out[5], up2, atol=2e-5)
     np.testing.assert_allclose(out[6], im.in_list[0][0][:, 3:][perm][:nf], atol=1e-6)
+
+
+def test_multiscale_inference_in_patches_matches_oracle():
+    """inferNet on a mesh that addMeshWithVertices cut into breadth-first mesh patches (dataClasses.py:270-372,
+    train.py:255-330): per patch the three-head network and update_position_MS, vertex positions averaged over the
+    patches that hold a vertex, face normals from the last patch that holds the face - against the oracle run patch by
+    patch on the same patches and weights."""
+    from facet_graph_convolution_amd.dataClasses import InferenceMesh
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.train import inferNet
+    from oracle import model_ref as R
+    V, F = icosphere(3)
+    np.random.seed(3)
+    im = InferenceMesh(maxSize=500)
+    vnum, fnum = im.addMeshWithVertices(add_noise(V, F), F, seed=0)
+    n = len(im.in_list)
+    assert n >= 3 and len(im.v_list) == n == len(im.vOldInd_list) == len(im.fOldInd_list)
+    covered = np.zeros(fnum, dtype=int)
+    for i in range(n):
+        covered[im.fOldInd_list[i]] += 1
+        # a patch carries its own vertices and faces: faces in patch vertex ids map back to the mesh's faces
+        nf = im.num_faces[i]
+        real = im.faces_list[i][0][im.permutations[i]][:nf]
+        assert np.array_equal(np.asarray(im.vOldInd_list[i])[real], F[im.fOldInd_list[i]])
+    assert covered.min() >= 1
+    net = FacetDenoiser("cuda:0", multi_scale=True, seed=7)
+    out = inferNet(im, net)
+    assert out[0].shape == (vnum, 3) and out[3].shape == (fnum, 3)
+    params = [p.detach().cpu() for p in net.params.values]
+    acc = [np.zeros((vnum, 3), np.float64) for _ in range(3)]
+    w = np.zeros((vnum, 3))
+    fine = np.zeros((fnum, 3), np.float32)
+    for i in range(n):
+        x = torch.tensor(im.in_list[i].astype(np.float32))
+        adjs = [torch.tensor(a.astype(np.int32)) for a in im.adj_list[i]]
+        y0, y1, y2 = R.get_model_reg_multi_scale(x, adjs, params, multiScale=True)
+        n0, n1, n2 = (R.normalizeTensor(y) for y in (y0, y1, y2))
+        xr, dxl = R.update_position_MS(torch.tensor(im.v_list[i][0].astype(np.float32)), [n0[0], n1[0], n2[0]],
+                                       im.faces_list[i][0], im.v_faces_list[i][0], 2, (80, 20, 20))
+        pts = xr.numpy()
+        mid = pts - dxl[2].numpy()
+        for a, p_ in zip(acc, (pts, mid, mid - dxl[1].numpy())):
+            np.add.at(a, im.vOldInd_list[i], p_)
+        np.add.at(w, im.vOldInd_list[i], 1.0)
+        fine[im.fOldInd_list[i]] = n0[0].numpy()[im.permutations[i]][:im.num_faces[i]]
+    w = np.maximum(w, 1)
+    for k in range(3):
+        np.testing.assert_allclose(out[k], acc[k] / w, atol=3e-5)
+    np.testing.assert_allclose(out[3], fine, atol=2e-5)

@@ -248,3 +248,59 @@ def test_native_vertices_faces_is_bit_exact(golden_dir):
         utils.getVerticesFaces(z["faces_perm"], 3, z["verts"].shape[0])
     a, b = utils.normalizePointSets(z["verts"], z["verts"] * 2)
     assert abs(np.linalg.norm(np.maximum(a.max(0), b.max(0)) - np.minimum(a.min(0), b.min(0))) - 1) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["torus960", "open_plus_sphere"])
+def test_native_mesh_patch_is_bit_exact(golden_dir, tag):
+    """getMeshPatch (utils.py:1298-1410) and the bounding-box helpers (utils.py:2109-2137): the native breadth-first
+    growth and the oracle restatement against the reference's own outputs."""
+    from oracle import prep_ref as R
+    z = np.load(os.path.join(golden_dir, "meshpatch_%s.npz" % tag))
+    for k, (face_num, seed) in enumerate(z["cases"]):
+        want = [z["%s%d" % (n, k)] for n in ("v", "f", "a", "vold", "fold")]
+        for impl in (utils.getMeshPatch, R.mesh_patch):
+            got = impl(z["verts"], z["faces"], z["adj"], int(face_num), int(seed))
+            for g, w in zip(got, want):
+                assert g.shape == w.shape and np.array_equal(g, w), (tag, k, impl.__name__)
+        bb = utils.getBoundingBox(want[0])
+        assert np.array_equal(bb.astype(np.float32), z["bb%d" % k])
+        assert np.array_equal(utils.takePointSetSlice(z["verts"], bb), z["slice%d" % k])
+
+
+def test_mesh_patch_vertex_buffer_overflow_raises_like_the_reference():
+    # a fan of triangles that share nothing: 3 new vertices per face > the reference's 0.6 * faceNum + K buffer
+    nf = 200
+    V = np.random.RandomState(0).normal(size=(3 * nf, 3)).astype(np.float32)
+    F = np.arange(3 * nf).reshape(nf, 3)
+    adj = np.zeros((nf, 23), dtype=np.int32)
+    adj[:, 0] = np.arange(nf) + 1
+    adj[:-1, 1] = np.arange(1, nf) + 1                      # a chain, so that the growth keeps going
+    with pytest.raises(IndexError):
+        utils.getMeshPatch(V, F, adj, 150, 0)
+
+
+def test_multiscale_patch_branch_covers_the_mesh():
+    """dataClasses.py:270-372 through addMeshWithVertices(maxSize=...): every face ends up in a patch, patches carry
+    consistent vertex / face tables, components below 100 faces are dropped, GT patches keep their bounding-box slice."""
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import torus, icosphere, add_noise
+    V, F = torus(24, 20)
+    V2, F2 = icosphere(1)                                   # an 80-face component: never added
+    Vall = np.concatenate([V, V2 + 10.0]).astype(np.float32)
+    Fall = np.concatenate([F, F2 + V.shape[0]])
+    np.random.seed(5)
+    ts = TrainingSet(maxSize=300)
+    ts.addMeshWithVertices(add_noise(Vall, Fall), Fall, GTV=Vall, seed=0)
+    n = len(ts.in_list)
+    assert n >= 3 and n == len(ts.v_list) == len(ts.faces_list) == len(ts.v_faces_list) == len(ts.gtv_list) == len(ts.gt_list)
+    covered = np.zeros(Fall.shape[0], dtype=int)
+    for i in range(n):
+        fold, vold = np.asarray(ts.fOldInd_list[i]), np.asarray(ts.vOldInd_list[i])
+        covered[fold] += 1
+        nf = ts.num_faces[i]
+        assert nf == len(fold) >= 100 and ts.v_list[i].shape[1] == len(vold)
+        real = ts.faces_list[i][0][ts.permutations[i]][:nf]
+        assert np.array_equal(vold[real], Fall[fold])
+        assert ts.gtv_list[i].shape[1] >= len(vold)
+        assert ts.gt_list[i].shape[1] == ts.in_list[i].shape[1]
+    assert covered[:F.shape[0]].min() >= 1 and covered[F.shape[0]:].max() == 0
