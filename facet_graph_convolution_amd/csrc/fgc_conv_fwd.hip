@@ -166,7 +166,10 @@ using namespace fgc;
 extern "C" size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d) {
     if (!d) return 0;
     const ConvGeom g = conv_geom(d->c0 + d->c1, d->cout);
-    return align_up(packed_floats(g) * sizeof(float), 256);
+    size_t b = align_up(packed_floats(g) * sizeof(float), 256);
+    if ((d->flags & FGC_CONV_SAVE_Z) && narrow_supported(d))
+        b = std::max(b, align_up((size_t)d->n * narrow_zld(d->c0) * sizeof(float), 256));
+    return b;
 }
 
 namespace fgc {
@@ -289,7 +292,7 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
         FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
     }
     if (d->tile_list && d->n_tiles == 0) return FGC_OK;
-    if (narrow) return launch_narrow_fwd(d, ag, y, y_pool, st);
+    if (narrow) return launch_narrow_fwd(d, ag, y, y_pool, (d->flags & FGC_CONV_SAVE_Z) ? (float*)workspace : nullptr, st);
 
     CoreParams p;
     fill_core_params(p, g, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, d->cout, ag,

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
             }
         }
     }
-    if (ZONLY) {
+    if (ZONLY || p.z != nullptr) {      // the aggregates themselves: operand of the backward pass' weight-gradient GEMM
         if (active) {
             float* zr = p.z + (size_t)i * p.zld;
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
                 for (int c = 0; c < CIN; ++c) zr[m * CIN + c] = z[m][c];
             for (int k = FGC_M * CIN; k < p.zld; ++k) zr[k] = 0.f;
         }
-        return;
+        if (ZONLY) return;
     }
     // y_i = (1/d) W~ z_i + b [d > 0]; the weight address depends on loop counters only (scalar loads)
     const int d = e1 - e0;
@@ -374,9 +374,9 @@ static int launch_narrow_fwd_z(const NarrowFwd& p, hipStream_t st) {
     }
 }
 
-int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, hipStream_t st) {
+int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, float* zsave, hipStream_t st) {
     NarrowFwd p{d->n,    d->rowptr,    d->col, d->x0,   ag, d->W0, d->b, d->c0, d->cout, d->bias_mask, d->act,
-                d->alpha, y, y_pool, nullptr, 0, d->tile_list, d->n_tiles};
+                d->alpha, y, y_pool, zsave, narrow_zld(d->c0), d->tile_list, d->n_tiles};
     return launch_narrow_fwd_z<false>(p, st);
 }
 
@@ -404,7 +404,7 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     float* part = zbuf + (size_t)d->n * zld + 64;
     NarrowFwd pz{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, d->b, cin, d->cout, d->bias_mask, d->act, d->alpha,
                  nullptr, nullptr, zbuf, zld, nullptr, 0};
-    int rc = launch_narrow_fwd_z<true>(pz, st);
+    int rc = io->z_saved ? FGC_OK : launch_narrow_fwd_z<true>(pz, st);   // forward left them (FGC_CONV_SAVE_Z)
     if (rc) return rc;
     NarrowBwd pb{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, io->ds, cin, d->cout, part};
     const dim3 grid(cdiv(d->n, NB));
@@ -436,7 +436,8 @@ int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     const int ns = cdiv(d->n, rps);
     int rc = 0;
     if (parts & 1) {
-        rc = launch_gemm_tn_stream("gemm_tn_kernel:dW", zbuf, zld, zld, io->ds, cout, d->n, rps, ns, slab, st);
+        rc = launch_gemm_tn_stream("gemm_tn_kernel:dW", io->z_saved ? io->z_saved : zbuf, zld, zld, io->ds, cout, d->n, rps,
+                                   ns, slab, st);
         if (rc) return rc;
     }
     const RedJob jobs[3] = {

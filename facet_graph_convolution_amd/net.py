@@ -135,6 +135,7 @@ class FacetDenoiser:
         # one launch packs the weight operands of all layers, one pair sums all parameter gradients (each small launch
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
+        self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
         # parameter slots
         k = 0
         self.slot = {}
@@ -240,6 +241,7 @@ class FacetDenoiser:
         # descriptors + workspace
         vals, grads = self.params.values, self.params.grads
         descs, ios, ws_f, ws_b = {}, {}, 0, 0
+        layer_flags = {}
         wsf, wsb = {}, {}    # a workspace of its own per layer: packed operands and partial sums stay put for the step
         for lay in self.layers:
             g = graphs[lay.level]
@@ -257,6 +259,9 @@ class FacetDenoiser:
             d.bias_mask, d.act, d.alpha = 1, lay.act, LRELU_ALPHA
             d.src_rows = B[lay.x0].shape[0]
             d.max_deg = g.max_deg
+            # a narrow first layer leaves its aggregates in the forward workspace for the backward pass (training only)
+            d.flags = _lib.CONV_SAVE_Z if (gt is not None and lay.name == "conv1" and self.save_z) else 0
+            layer_flags[lay.name] = d.flags
             descs[lay.name] = d
             wsf[lay.name] = torch.empty(self.L.fgc_conv_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
             if gt is not None:
@@ -282,6 +287,10 @@ class FacetDenoiser:
             io.accumulate0, io.accumulate1 = 0, 0
         ios["conv1"].dx0 = None
         ios["conv1"].dx1 = None
+        if layer_flags["conv1"] and not self.L.fgc_conv_bwd_needs_exchange(C.byref(descs["conv1"]), C.byref(ios["conv1"])):
+            ios["conv1"].z_saved = wsf["conv1"].data_ptr()      # (the library took the narrow path: see FGC_CONV_SAVE_Z)
+        else:
+            layer_flags["conv1"] = descs["conv1"].flags = 0
         ws_f = max(ws_f, self.L.fgc_mlp_workspace_bytes(128, HIDDEN, 3))
         ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n0, 32, HIDDEN, 3))
         B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)     # the MLP heads
@@ -297,7 +306,7 @@ class FacetDenoiser:
             wsf=(C.c_void_p * nl)(*[wsf[k].data_ptr() for k in names]),
             wsb=(C.c_void_p * nl)(*[wsb[k].data_ptr() for k in names]) if wsb else None, count=nl)
         self._mesh = dict(graphs=graphs, B=B, descs=descs, ios=ios, ns=ns, nh=nh, has_gt=gt is not None,
-                          plan=plan, n_total=n_total, own_lo=own_lo, arrays=arrays)
+                          plan=plan, n_total=n_total, own_lo=own_lo, arrays=arrays, layer_flags=layer_flags)
         self.comm = comm
         self._graph_fb = None
         return self
@@ -369,7 +378,8 @@ class FacetDenoiser:
         for lay in self.layers:
             d = M["descs"][lay.name]
             lws = B["wsf_" + lay.name]
-            d.flags = packed
+            lflags = M["layer_flags"][lay.name]
+            d.flags = packed | lflags
             args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(lws),
                     lws.numel(), st)
             reqs = halo_before.get(lay.name, []) if self.sharded else []
@@ -389,9 +399,9 @@ class FacetDenoiser:
                     yield ("wait", wait_before[lay.name])
                 d.tile_list, d.n_tiles = g.tiles["tiles_bnd"][0].data_ptr(), g.tiles["tiles_bnd"][1]
                 d.proj_row0, d.proj_rows = own_src, (d.src_rows - own_src) or -1
-                d.flags = _lib.CONV_PACKED
+                d.flags = _lib.CONV_PACKED | lflags
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
-                d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, packed
+                d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, packed | lflags
             else:
                 for name, level, parent in reqs:
                     yield ("rows", level, B[name], parent)

@@ -189,6 +189,10 @@ typedef struct fgc_conv_desc {
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
 #define FGC_CONV_PACKED 1
 #define FGC_CONV_DEFER_REDUCE 2   /* fgc_conv_bwd_io.flags: stage 8 leaves its partial sums for fgc_conv_bwd_reduce */
+#define FGC_CONV_SAVE_Z 4         /* fgc_conv_desc.flags, first layer over a narrow input (cin <= 8): the forward pass
+                                  * leaves the aggregates z [n, roundup4(9*cin)] in its workspace (sized for it by
+                                  * fgc_conv_workspace_bytes when the flag is set) so that the backward pass, given
+                                  * fgc_conv_bwd_io.z_saved, does not recompute them for the weight gradient */
 
 /* bytes of scratch the conv entry points need for this descriptor (packed weights) */
 size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d);
@@ -236,6 +240,7 @@ typedef struct fgc_conv_bwd_io {
     int32_t n_data_tiles;
     int32_t flags;                 /* FGC_CONV_PACKED: the operands are already packed (an earlier stage call, or
                                     * fgc_conv_pack); FGC_CONV_DEFER_REDUCE: see fgc_conv_bwd_reduce */
+    const float* z_saved;          /* optional: the workspace of the forward call made with FGC_CONV_SAVE_Z */
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
