@@ -156,7 +156,7 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
         float sum = 0.f;
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) {
-            l[m] = expf(l[m] - mx);
+            l[m] = __expf(l[m] - mx);   // v_exp_f32 (2 ulp; arguments <= 0): the accurate expf is 5x the instructions
             sum += l[m];
         }
         const float inv = 1.0f / sum;

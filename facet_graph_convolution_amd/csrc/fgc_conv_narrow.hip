@@ -68,7 +68,7 @@ __device__ __forceinline__ void softmax9(const float (&a)[FGC_M], const float (&
     float sum = 0.f;
 #pragma unroll
     for (int m = 0; m < FGC_M; ++m) {
-        q[m] = expf(q[m] - mx);
+        q[m] = __expf(q[m] - mx);
         sum += q[m];
     }
     const float inv = 1.0f / sum;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             float sum = 0.f;
 #pragma unroll
             for (int m = 0; m < FGC_M; ++m) {
-                l[m] = expf(l[m] - mx);
+                l[m] = __expf(l[m] - mx);
                 sum += l[m];
             }
             const float inv = 1.0f / sum;
