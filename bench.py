@@ -214,6 +214,29 @@ def main():
         dt = t.item()
     loss = net.buffers["loss"][0].item()
 
+    # the same steps as hipGraph replays (one graph per step holds the whole forward+backward enqueue), untimed extra:
+    # a second network from the same seed walks the same inputs, so its final loss must equal the eager one bit for bit
+    hipgraph = None
+    if world == 1 and not shard and not args.graph:
+        net_g = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+
+        def step_g(k):
+            net_g.set_step_inputs_device(S_all[k % nsteps_total], R_all[k % nsteps_total])
+            net_g.forward_backward(rotate=True, capture=True)
+            net_g.adam_step()
+
+        for k in range(args.warmup):
+            step_g(k)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for k in range(args.warmup, nsteps_total):
+            step_g(k)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg
+        loss_g = net_g.buffers["loss"][0].item()
+        hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": loss_g, "matches_eager": loss_g == loss}
+        del net_g
+
     # forward-only rate (BASELINE config 2 wording), untimed extra
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -324,6 +347,7 @@ def main():
                                         (F_total, world, ", ".join("%.3f" % h for h in halo_frac))) if shard else
                                        "1 mesh per GPU, flat-gradient all-reduce")},
             "loss_deg": loss,
+            "hipgraph_replay": hipgraph,
             "forward_only_ms": fwd_ms,
             "forward_only_facets_per_s": F_total / (fwd_ms * 1e-3),
             "hbm_roofline_frac_whole_step": fb_b / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),
