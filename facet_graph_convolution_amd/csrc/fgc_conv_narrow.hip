@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
             }
         }
     }
-    if (ZONLY || p.z != nullptr) {      // the aggregates themselves: operand of the backward pass' weight-gradient GEMM
+    auto store_z = [&]() {     // the aggregates themselves: operand of the backward pass' weight-gradient GEMM
         if (active) {
             float* zr = p.z + (size_t)i * p.zld;
 #pragma unroll
@@ -159,7 +159,10 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
                 for (int c = 0; c < CIN; ++c) zr[m * CIN + c] = z[m][c];
             for (int k = FGC_M * CIN; k < p.zld; ++k) zr[k] = 0.f;
         }
-        if (ZONLY) return;
+    };
+    if (ZONLY) {
+        store_z();
+        return;
     }
     // y_i = (1/d) W~ z_i + b [d > 0]; the weight address depends on loop counters only (scalar loads)
     const int d = e1 - e0;
@@ -178,6 +181,9 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
         if (p.act) val = fmaxf(val, 0.f) - p.alpha * fmaxf(-val, 0.f);
         yt[threadIdx.x * ys + o] = val;
     }
+    // (stored only now: a global store ahead of the loop above would make the compiler treat W0 as possibly clobbered
+    // and load the wave-uniform weights through the vector memory path instead of scalar loads)
+    if (p.z != nullptr) store_z();
     __syncthreads();
     // coalesced row writes, one 32-row tile (= 32 * cout contiguous floats) at a time; 4:1 max-pool from the tile
     for (int tl = 0; tl < NB / TILE; ++tl) {
@@ -203,6 +209,131 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
                 }
                 if (any) p.y_pool[(size_t)((row0 >> 2) + pr) * p.cout + o] = mx;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same forward pass with the per-node product y_i = W~ z_i on the matrix cores (cout a multiple of 16): every lane
+// parks the aggregates of its node in LDS ([node][k], k = m * CIN + c, zero padded to a multiple of 16), from where
+// (a) they are copied to global memory as whole rows for the backward pass (FGC_CONV_SAVE_Z; the per-lane stores of the
+// vector form write 4 bytes per lane with a 224-byte stride), (b) they are the A operand of [64 nodes x K] x [K x cout]
+// per wave, B = the weights re-laid as [k][o] in LDS once per workgroup.  The C layout puts four consecutive nodes of one
+// output channel in one lane: bias, activation, the row stores (64-byte segments) and the 4:1 max-pool need no second
+// trip through LDS.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int OT>
+__global__ __launch_bounds__(NB) void conv_narrow_fwd_mma_kernel(NarrowFwd p) {
+    constexpr int K9 = FGC_M * CIN;
+    constexpr int KZ = (K9 + 15) / 16 * 16;     // padded k extent
+    constexpr int ZS = KZ + 4;                  // LDS row stride of the aggregates (== 4 mod 8)
+    constexpr int COUT = OT * 16;
+    constexpr int WS = COUT + 4;                // row stride of the weights (== 4 mod 8)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* zt = reinterpret_cast<float*>(smem_raw);            // [NB][ZS]
+    float* Wk = zt + NB * ZS;                                   // [KZ][WS]
+    int* nodes = reinterpret_cast<int*>(Wk + KZ * WS);          // [NB] node of every row, -1 = none
+    int* degs = nodes + NB;                                     // [NB]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    int active;
+    const int i = narrow_node(p.tile_list, p.n_tiles, p.n, active);
+    // weights as [k][o] (zero rows past 9 * CIN)
+    for (int t = tid; t < KZ * COUT; t += NB) {
+        const int k = t / COUT, o = t % COUT;
+        Wk[k * WS + o] = k < K9 ? p.W0[((size_t)(k / CIN) * COUT + o) * CIN + k % CIN] : 0.f;
+    }
+    int e0 = 0, e1 = 0;
+    float a[FGC_M];
+#pragma unroll
+    for (int m = 0; m < FGC_M; ++m) a[m] = 0.f;
+    if (active) {
+        e0 = p.rowptr[i];
+        e1 = p.rowptr[i + 1];
+        const float* ar = p.ag + (size_t)i * FGC_AG_LD;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+        a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+        a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+        a[8] = ar[8];
+    }
+    float z[KZ];      // flat [m * CIN + c], zero tail
+#pragma unroll
+    for (int k = 0; k < KZ; ++k) z[k] = 0.f;
+    for (int e = e0; e < e1; e += EB_FWD) {
+        float g[EB_FWD][FGC_M], xj[EB_FWD][CIN];
+        fetch_edges<CIN, EB_FWD>(p.col, p.ag, p.x, p.cin, e, e1, g, xj);
+#pragma unroll
+        for (int t = 0; t < EB_FWD; ++t) {
+            float q[FGC_M];
+            softmax9(a, g[t], q);
+            const float w = e + t < e1 ? 1.f : 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                const float qm = q[m] * w;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) z[m * CIN + c] = fmaf(qm, xj[t][c], z[m * CIN + c]);
+            }
+        }
+    }
+    {
+        float* zr = zt + tid * ZS;
+#pragma unroll
+        for (int k = 0; k < KZ; k += 4) *reinterpret_cast<f32x4*>(zr + k) = f32x4{z[k], z[k + 1], z[k + 2], z[k + 3]};
+        nodes[tid] = active ? i : -1;
+        degs[tid] = e1 - e0;
+    }
+    __syncthreads();       // Wk is shared by the waves; everything else below is private to a wave (its 64 rows)
+    const int w0 = wave * 64;
+    if (p.z != nullptr) {
+        // rows of the aggregates to global memory, 16 bytes per lane, consecutive lanes consecutive addresses
+        const int q4 = p.zld >> 2;                        // float4s per row (zld = roundup4(9 * CIN) <= KZ)
+        for (int f = lane; f < 64 * q4; f += 64) {
+            const int r = f / q4, c4 = f % q4;
+            const int node = nodes[w0 + r];
+            if (node >= 0)
+                *reinterpret_cast<f32x4*>(p.z + (size_t)node * p.zld + c4 * 4) =
+                    *reinterpret_cast<const f32x4*>(zt + (w0 + r) * ZS + c4 * 4);
+        }
+    }
+    float bias_o[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) bias_o[ot] = p.bias[ot * 16 + lr];
+#pragma unroll 1
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x4 acc[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < KZ / 16; ++g) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(zt + (w0 + nt * 16 + lr) * ZS + g * 16 + lq * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot)
+                    acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], Wk[(g * 16 + lq * 4 + t) * WS + ot * 16 + lr],
+                                                                   acc[ot], 0, 0, 0);
+        }
+        // C layout: column = lr (output channel within the tile), rows = nt*16 + lq*4 + t: one 4:1 pooling group per lane
+        int nd[4], dd[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            nd[t] = nodes[w0 + nt * 16 + lq * 4 + t];
+            dd[t] = degs[w0 + nt * 16 + lq * 4 + t];
+        }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            const int o = ot * 16 + lr;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (nd[t] < 0) continue;
+                float val = acc[ot][t] * (dd[t] > 0 ? 1.0f / (float)dd[t] : 0.f);
+                if (!p.bias_mask || dd[t] > 0) val += bias_o[ot];
+                if (p.act) val = fmaxf(val, 0.f) - p.alpha * fmaxf(-val, 0.f);
+                p.y[(size_t)nd[t] * COUT + o] = val;
+                mx = fmaxf(mx, val);
+            }
+            if (p.y_pool && nd[0] >= 0) p.y_pool[(size_t)(nd[0] >> 2) * COUT + o] = mx;
         }
     }
 }
@@ -374,9 +505,28 @@ static int launch_narrow_fwd_z(const NarrowFwd& p, hipStream_t st) {
     }
 }
 
+template <int CIN, int OT>
+static int launch_narrow_fwd_mma_t(const NarrowFwd& p, hipStream_t st) {
+    const int tiles = p.tile_list ? p.n_tiles : cdiv(p.n, TILE);
+    if (tiles == 0) return FGC_OK;
+    constexpr int KZ = (FGC_M * CIN + 15) / 16 * 16;
+    const size_t smem = ((size_t)NB * (KZ + 4) + (size_t)KZ * (OT * 16 + 4)) * 4 + (size_t)2 * NB * 4;
+    hipFuncSetAttribute((const void*)conv_narrow_fwd_mma_kernel<CIN, OT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)smem);
+    FGC_LAUNCH("conv_narrow_kernel<fwd>", st, (conv_narrow_fwd_mma_kernel<CIN, OT>), dim3(cdiv(tiles, NB / TILE)), dim3(NB),
+               smem, p);
+    FGC_CHECK_LAUNCH("conv_narrow_fwd_mma_kernel");
+    return FGC_OK;
+}
+
 int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, float* zsave, hipStream_t st) {
     NarrowFwd p{d->n,    d->rowptr,    d->col, d->x0,   ag, d->W0, d->b, d->c0, d->cout, d->bias_mask, d->act,
                 d->alpha, y, y_pool, zsave, narrow_zld(d->c0), d->tile_list, d->n_tiles};
+    // the network's first layer (6 -> 32) and its 3-channel sibling: per-node products on the matrix cores
+    const bool mma = !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
+                     ((uintptr_t)zsave % 16) == 0;
+    if (mma && d->c0 == 6) return launch_narrow_fwd_mma_t<6, 2>(p, st);
+    if (mma && d->c0 == 3) return launch_narrow_fwd_mma_t<3, 2>(p, st);
     return launch_narrow_fwd_z<false>(p, st);
 }
 
