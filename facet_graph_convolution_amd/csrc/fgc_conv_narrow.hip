@@ -354,9 +354,12 @@ struct NarrowBwd {
 };
 constexpr int NARROW_PART = 160;   // >= 2 * 9 * 8 + 9
 
-template <int CIN>
+// MMA (cout == 32): dz = W^T s of the workgroup's 256 nodes as [64 x 32] x [32 x K] per wave on the matrix cores, handed
+// to the node-per-lane part through LDS (the vector form spends 1 728 FMAs per lane and 32 strided 4-byte loads of s)
+template <int CIN, bool MMA>
 __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
     __shared__ float red[NB / 64][NARROW_PART];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int i = blockIdx.x * NB + threadIdx.x;
     const bool active = i < p.n;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -381,13 +384,57 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
 #pragma unroll
         for (int c = 0; c < CIN; ++c) xi[c] = p.x[(size_t)i * CIN + c];
     }
-    for (int o = 0; o < p.cout; ++o) {
-        const float so = active ? p.ds[(size_t)i * p.cout + o] : 0.f;
+    if constexpr (MMA) {
+        constexpr int K9 = FGC_M * CIN, KZ = (K9 + 15) / 16 * 16, ZS = KZ + 4;
+        float* dzt = reinterpret_cast<float*>(smem_raw);      // [NB][ZS]
+        float* Wt = dzt + NB * ZS;                             // [32][ZS]: Wt[o][m * CIN + c] = W0[m][o][c]
+        const int lr = lane & 15, lq = lane >> 4;
+        for (int t = threadIdx.x; t < 32 * KZ; t += NB) {
+            const int o = t / KZ, k = t % KZ;
+            Wt[o * ZS + k] = k < K9 ? p.W0[((size_t)(k / CIN) * 32 + o) * CIN + k % CIN] : 0.f;
+        }
+        __syncthreads();
+        const int w0 = wave * 64;
+        const int node0 = blockIdx.x * NB + w0;
+#pragma unroll 1
+        for (int nt = 0; nt < 4; ++nt) {
+            const int row = min(node0 + nt * 16 + lr, p.n - 1);      // rows past n: never used (no edges there)
+            f32x4 av[2];
 #pragma unroll
-        for (int m = 0; m < FGC_M; ++m) {
-            const float* w = p.W0 + ((size_t)m * p.cout + o) * CIN;
+            for (int g = 0; g < 2; ++g) av[g] = *reinterpret_cast<const f32x4*>(p.ds + (size_t)row * 32 + g * 16 + lq * 4);
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) dz[m][c] = fmaf(w[c], so, dz[m][c]);
+            for (int kt = 0; kt < KZ / 16; ++kt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][t], Wt[(g * 16 + lq * 4 + t) * ZS + kt * 16 + lr], acc,
+                                                                   0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dzt[(w0 + nt * 16 + lq * 4 + t) * ZS + kt * 16 + lr] = acc[t];
+            }
+        }
+        // the wave wrote the rows of its own 64 nodes: each lane takes its node's row back
+        float dzf[KZ];
+#pragma unroll
+        for (int k = 0; k < KZ; k += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dzt + threadIdx.x * ZS + k);
+            dzf[k] = v[0]; dzf[k + 1] = v[1]; dzf[k + 2] = v[2]; dzf[k + 3] = v[3];
+        }
+#pragma unroll
+        for (int m = 0; m < FGC_M; ++m)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) dz[m][c] = active ? dzf[m * CIN + c] : 0.f;
+    } else {
+        for (int o = 0; o < p.cout; ++o) {
+            const float so = active ? p.ds[(size_t)i * p.cout + o] : 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                const float* w = p.W0 + ((size_t)m * p.cout + o) * CIN;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) dz[m][c] = fmaf(w[c], so, dz[m][c]);
+            }
         }
     }
     float da[FGC_M], wv[FGC_M][CIN];
@@ -559,11 +606,26 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     NarrowBwd pb{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, io->ds, cin, d->cout, part};
     const dim3 grid(cdiv(d->n, NB));
 #define FGC_NARROW_BWD(C_) \
-    case C_: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, conv_narrow_bwd_kernel<C_>, grid, dim3(NB), 0, pb); break;
+    case C_: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<C_, false>), grid, dim3(NB), 0, pb); break;
+    const bool mma = !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
+                     ((uintptr_t)io->ds % 16) == 0 && (cin == 6 || cin == 3);
+    if (mma) {
+        const int KZ = (FGC_M * cin + 15) / 16 * 16;
+        const size_t smem = (size_t)(NB + 32) * (KZ + 4) * 4;
+        if (cin == 6) {
+            hipFuncSetAttribute((const void*)conv_narrow_bwd_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+            FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<6, true>), grid, dim3(NB), smem, pb);
+        } else {
+            hipFuncSetAttribute((const void*)conv_narrow_bwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+            FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<3, true>), grid, dim3(NB), smem, pb);
+        }
+    } else
     switch (cin) {
         FGC_NARROW_BWD(1) FGC_NARROW_BWD(2) FGC_NARROW_BWD(3) FGC_NARROW_BWD(4)
         FGC_NARROW_BWD(5) FGC_NARROW_BWD(6) FGC_NARROW_BWD(7)
-        default: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, conv_narrow_bwd_kernel<8>, grid, dim3(NB), 0, pb); break;
+        default: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<8, false>), grid, dim3(NB), 0, pb); break;
     }
 #undef FGC_NARROW_BWD
     FGC_CHECK_LAUNCH("conv_narrow_bwd_kernel");
