@@ -672,11 +672,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                             for (int r = 0; r < RT; ++r)
                                 acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
                 };
+                if constexpr (OKG >= 4) {
+                    // two weight buffers with fixed roles: the fragments of group g + 1 are in flight under the MFMAs of g
+                    f32x4 wA[K1_CTW], wB[K1_CTW];
+                    loadw(0, wA);
+#pragma unroll 1
+                    for (int g = 0; g < OKG; g += 2) {
+                        loadw(g + 1, wB);
+                        mmw(g, wA);
+                        loadw(g + 2, wA);       // (clamped to the last group at the end)
+                        mmw(g + 1, wB);
+                    }
+                } else {
 #pragma unroll OKG == 2 ? 2 : 1
-                for (int g = 0; g < okg; ++g) {
-                    f32x4 w0[K1_CTW];
-                    loadw(g, w0);
-                    mmw(g, w0);
+                    for (int g = 0; g < okg; ++g) {
+                        f32x4 w0[K1_CTW];
+                        loadw(g, w0);
+                        mmw(g, w0);
+                    }
                 }
                 if (!LONG) gather(H, bxb);
                 if (pass > 0 || sweep > 0) __syncthreads();  // the previous readers of ztile are done
