@@ -64,6 +64,21 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobsT<MAXJ> J) {
         if (t < J.njobs && (int)blockIdx.x >= J.block0[t]) q = t;
     const RedJob& job = J.job[q];
     const int b = blockIdx.x - J.block0[q];
+    if (J.group[q] < 0) {
+        // a few long slabs (the MLP's four dx slabs): four elements per thread, 1024 per workgroup, the same summation
+        // order as the general form below (slab s belongs to lane s % 4; (l0 + l1) + (l2 + l3))
+        const size_t j4 = ((size_t)b * 256 + threadIdx.x) * 4;
+        if (j4 < (size_t)job.count) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (l < job.nslabs) acc[l] += *reinterpret_cast<const f32x4*>(job.slab + (size_t)l * job.stride + j4);
+            }
+            *reinterpret_cast<f32x4*>(job.out + j4) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        return;
+    }
     const int bx = b % J.xblocks[q], by = b / J.xblocks[q];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int j = bx * 64 + col;
@@ -120,6 +135,17 @@ static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, flo
             return FGC_EINVAL;
         }
         A.job[q] = j;
+        const bool wide = j.nslabs <= 4 && j.count >= (1 << 16) && j.count % 4 == 0 && j.in_ld == j.out_ld &&
+                          j.stride % 4 == 0 && ((uintptr_t)j.slab % 16) == 0 && ((uintptr_t)j.out % 16) == 0;
+        if (wide) {
+            A.xblocks[q] = (j.count / 4 + 255) / 256;
+            A.block0[q] = nb;
+            nb += A.xblocks[q];
+            A.group[q] = -1;
+            A.fin[q] = 1;
+            A.stage_out[q] = j.out;
+            continue;
+        }
         A.xblocks[q] = (j.count + 63) / 64;
         A.block0[q] = nb;
         nb += A.xblocks[q] * groups;
