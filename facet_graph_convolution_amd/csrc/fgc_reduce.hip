@@ -50,6 +50,7 @@ struct RedJobsT {
     int block0[MAXJ + 1];     // first workgroup of each job
     int xblocks[MAXJ];        // workgroups along the element axis
     int group[MAXJ];          // slabs per workgroup (RED_GROUP unless the job has more than RED_GROUP^2 slabs)
+    int vec[MAXJ];            // 1: the workgroup covers 64 float4 columns instead of 64 floats (same order per element)
     int njobs;
 };
 constexpr int RED_FEW_JOBS = 6;
@@ -81,11 +82,40 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobsT<MAXJ> J) {
     }
     const int bx = b % J.xblocks[q], by = b / J.xblocks[q];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int j = bx * 64 + col;
     const int s0 = by * J.group[q];
     const int s1 = min(job.nslabs, s0 + J.group[q]);
     const float* slab = job.slab;
     const size_t stride = job.stride;
+    if (J.vec[q]) {
+        __shared__ __attribute__((aligned(16))) float part4[4][64][4];
+        const int j = (bx * 64 + col) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (j < job.count) {
+            int s = s0 + sl;
+            for (; s + 12 < s1; s += 16) {  // 4 independent loads in flight
+                const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (size_t)s * stride + j),
+                            bb = *reinterpret_cast<const f32x4*>(slab + (size_t)(s + 4) * stride + j),
+                            c = *reinterpret_cast<const f32x4*>(slab + (size_t)(s + 8) * stride + j),
+                            d = *reinterpret_cast<const f32x4*>(slab + (size_t)(s + 12) * stride + j);
+                acc += a;
+                acc += bb;
+                acc += c;
+                acc += d;
+            }
+            for (; s < s1; s += 4) acc += *reinterpret_cast<const f32x4*>(slab + (size_t)s * stride + j);
+        }
+        *reinterpret_cast<f32x4*>(part4[sl][col]) = acc;
+        __syncthreads();
+        if (sl == 0 && j < job.count) {
+            const f32x4 v = (*reinterpret_cast<const f32x4*>(part4[0][col]) + *reinterpret_cast<const f32x4*>(part4[1][col])) +
+                            (*reinterpret_cast<const f32x4*>(part4[2][col]) + *reinterpret_cast<const f32x4*>(part4[3][col]));
+            float* out = J.stage_out[q];
+            // in_ld == out_ld for vectorised jobs: element j of the slab is element j of the result in both stages
+            *reinterpret_cast<f32x4*>(out + (J.fin[q] ? (size_t)j : (size_t)by * job.count + j)) = v;
+        }
+        return;
+    }
+    const int j = bx * 64 + col;
     float acc = 0.f;
     if (j < job.count) {
         int s = s0 + sl;
@@ -142,11 +172,17 @@ static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, flo
             A.block0[q] = nb;
             nb += A.xblocks[q];
             A.group[q] = -1;
+            A.vec[q] = 0;
             A.fin[q] = 1;
             A.stage_out[q] = j.out;
             continue;
         }
-        A.xblocks[q] = (j.count + 63) / 64;
+        // four columns per thread where the layout allows it: a quarter of the workgroups, 16-byte accesses
+        const bool vec = j.count >= 4096 && j.count % 4 == 0 && j.in_ld == j.out_ld && j.stride % 4 == 0 &&
+                         ((uintptr_t)j.slab % 16) == 0 && ((uintptr_t)j.out % 16) == 0 &&
+                         (groups == 1 || ((uintptr_t)t % 16) == 0);
+        A.vec[q] = vec ? 1 : 0;
+        A.xblocks[q] = vec ? (j.count / 4 + 63) / 64 : (j.count + 63) / 64;
         A.block0[q] = nb;
         nb += A.xblocks[q] * groups;
         A.group[q] = group;
@@ -159,6 +195,7 @@ static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, flo
             B.job[k].stride = (size_t)j.count;
             B.job[k].nslabs = groups;
             B.xblocks[k] = A.xblocks[q];
+            B.vec[k] = A.vec[q];
             B.block0[k] = nb2;
             nb2 += B.xblocks[k];
             B.group[k] = RED_GROUP;
