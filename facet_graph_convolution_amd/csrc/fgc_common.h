@@ -54,6 +54,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2c __attribute__((ext_vector_type(2)));
 
 #ifdef __HIPCC__
 // Sum over each row of 16 lanes, result in every lane, on the VALU's DPP crossbar (4 adds) instead of 4 LDS-pipe

@@ -1061,6 +1061,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 //   * four operand register sets with fixed roles (loop unrolled by 4): each load has three MFMA groups = 48
 //     matrix instructions to land;
 //   * the 4-wave sum goes through 2 x 16 KB of LDS instead of 4, so four workgroups are resident per CU.
+// NJ = 4: 64 x 64 output tile (lane lr owns columns 4*lr .. 4*lr+3); NJ = 2: 64 x 32 for operands only 32 wide (columns
+// 2*lr, 2*lr+1: half the MFMAs instead of multiplying clamped duplicates)
+template <int NJ>
 __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __restrict__ A, int lda, int P,
                                                                 const float* __restrict__ x0,
                                                                 const float* __restrict__ x1, int c0, int c1, int shift,
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     const int Q = c0 + c1;
     const int npt = (P + 63) >> 6;
     const int pt = blockIdx.x % npt, qt = blockIdx.x / npt;
-    const int p0 = pt * 64, q0 = qt * 64;
+    const int p0 = pt * 64, q0 = qt * (16 * NJ);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r_begin = blockIdx.y * rows_per_split;
@@ -1077,14 +1080,14 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     const int nsteps = (r_end - r_begin + 3) >> 2;
     // column quads of this lane, clamped into the operands (results of clamped columns are never stored)
     const int pc = min(p0 + 4 * lr, P - 4);
-    const int qc = min(q0 + 4 * lr, Q - 4);
+    const int qc = min(q0 + NJ * lr, Q - NJ);
     const float* bsrc = qc < c0 ? x0 + qc : x1 + (qc - c0);
     const int bld = qc < c0 ? c0 : c1;
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // A load only requests memory; the zeroing of out-of-range rows happens where the fragment is consumed (a select
     // right behind the load would make the compiler wait for it on the spot)
@@ -1092,14 +1095,19 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
         row = r_begin + 4 * step + lq;
         const int rc = min(row, r_end - 1);
         a = *reinterpret_cast<const f32x4*>(A + (size_t)rc * lda + pc);
-        b = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(rc >> shift) * bld);
+        if constexpr (NJ == 4) {
+            b = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(rc >> shift) * bld);
+        } else {
+            const f32x2c b2 = *reinterpret_cast<const f32x2c*>(bsrc + (size_t)(rc >> shift) * bld);
+            b = f32x4{b2[0], b2[1], 0.f, 0.f};
+        }
     };
     auto mm = [&](f32x4 a, const f32x4& b, int row) {
         if (row >= r_end) a = f32x4{0.f, 0.f, 0.f, 0.f};   // a select, not a branch
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     };
     f32x4 a0, b0, a1, b1, a2, b2, a3, b3;
     int r0, r1, r2, r3;
@@ -1127,17 +1135,17 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) red[slot][4 * (lq * 4 + t) + i][4 * lr + j] = acc[i][j][t];
+                for (int t = 0; t < 4; ++t) red[slot][4 * (lq * 4 + t) + i][NJ * lr + j] = acc[i][j][t];
     };
     auto add = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[i][j][t] += red[slot][4 * (lq * 4 + t) + i][4 * lr + j];
+                for (int t = 0; t < 4; ++t) acc[i][j][t] += red[slot][4 * (lq * 4 + t) + i][NJ * lr + j];
     };
     if (wave == 1) put(0);
     if (wave == 3) put(1);
@@ -1149,17 +1157,23 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     if (wave == 2) put(1);
     __syncthreads();
     float* out = slab + (size_t)blockIdx.y * P * Q;
-    for (int t = tid; t < 64 * 64; t += 256) {
-        const int pp = t >> 6, qq = t & 63;
+    for (int t = tid; t < 64 * 16 * NJ; t += 256) {
+        const int pp = t / (16 * NJ), qq = t % (16 * NJ);
         if (p0 + pp < P && q0 + qq < Q) out[(size_t)(p0 + pp) * Q + q0 + qq] = red[0][pp][qq] + red[1][pp][qq];
     }
 }
 
 int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,
                           int rows_per_split, int nsplits, float* slab, hipStream_t st) {
-    const dim3 grid(cdiv(P, 64) * cdiv(c0, 64), nsplits);
-    FGC_LAUNCH(tag, st, gemm_tn_stream_kernel, grid, dim3(256), 0, A, lda, P, x0, (const float*)nullptr, c0, 0, 0, rows,
-               rows_per_split, slab);
+    if (c0 <= 32 && c0 % 2 == 0) {
+        const dim3 grid(cdiv(P, 64), nsplits);
+        FGC_LAUNCH(tag, st, gemm_tn_stream_kernel<2>, grid, dim3(256), 0, A, lda, P, x0, (const float*)nullptr, c0, 0, 0, rows,
+                   rows_per_split, slab);
+    } else {
+        const dim3 grid(cdiv(P, 64) * cdiv(c0, 64), nsplits);
+        FGC_LAUNCH(tag, st, gemm_tn_stream_kernel<4>, grid, dim3(256), 0, A, lda, P, x0, (const float*)nullptr, c0, 0, 0, rows,
+                   rows_per_split, slab);
+    }
     FGC_CHECK_LAUNCH("gemm_tn_stream_kernel");
     return FGC_OK;
 }
@@ -1435,7 +1449,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const int ns = cdiv(d->n, rps);
         const dim3 g1(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
-        if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel, g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
+        if (stream_ok && cin <= 32 && d->c1 == 0)
+            FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, dim3(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
+                       d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        else if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<4>, g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                                   d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                            d->c0, d->c1, d->shift, d->n, rps, w.slab);
