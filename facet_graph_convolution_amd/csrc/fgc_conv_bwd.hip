@@ -665,12 +665,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                             a[r] = *reinterpret_cast<const f32x4*>(dst + (r * 16 + lr) * ostride + g * 16 + lq * 4);
                     }
 #pragma unroll
-                    for (int c = 0; c < K1_CTW; ++c)
+                    for (int c = 0; c < K1_CTW; ++c) {
+                        // 18 column tiles over 4 waves = 5, 5, 4, 4: waves 2 and 3 skip their (duplicate) fifth tile.  Only
+                        // where it was measured to pay (64-wide layers: -5 %); the branch costs the other forms 10 - 90 %
+                        if (OKG == 4 && wave + c * 4 >= nct) continue;
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
                             for (int r = 0; r < RT; ++r)
                                 acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+                    }
                 };
                 if constexpr (OKG >= 4) {
                     // two weight buffers with fixed roles: the fragments of group g + 1 are in flight under the MFMAs of g
