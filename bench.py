@@ -1,30 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the facet-graph-convolution hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (plain shell: N > 1 starts its own torchrun child)
 
 One "step" = one full training iteration of the reference's loop body (train.py:558-575,619) on one
 synthetic mesh: random rotation of inputs and ground truth, full 3-level graph U-Net + MLP forward,
-normalisation, angular loss on 4000 sampled rows, full backward, TF1-Adam update.  fp32 throughout.
+normalisation, angular loss on 4000 sampled rows, full backward, TF1-Adam update.  fp32 by default
+(--dtype bf16: activations stored as bf16, matrix products on the bf16 MFMA, fp32 accumulation and fp32
+master weights - BASELINE config 3, never the headline).
 
-Workload (BASELINE.json configs[1]): torus 250 x 200 quads = 100 000 facets,
-preprocessed natively (adjacency + 4 pairing levels + binary-tree order) before the timed region;
-everything is resident in HBM when the clock starts.
+Workloads (--config):
+  c2 (default)  torus 250 x 200 quads = 100 000 facets per GPU, train step          [headline metric]
+  c3            torus 250 x 100 = 50 000 facets, train step (meant for --dtype bf16)
+  c4            torus 1000 x 500 = 1 000 000 facets, ONE mesh facet-sharded over the N GPUs (strong scaling)
+  c5            torus 500 x 500 = 500 000 facets, multi-scale network (three heads), ONE mesh over the N GPUs;
+                step = the reference's multi-scale denoising forward (inferNet, train.py:188-193: three normal
+                fields, each through normalizeTensor); its training objective is a point-set loss (out of scope)
+--nu/--nv override the torus, --multi-scale the network, --scaling weak|strong the decomposition.
 
-N > 1: one process per GPU (torchrun).  Default (--mode shard): ONE mesh of N x 100 000 facets (torus
-250N x 200) is facet-sharded over the N GPUs (shard.py): each rank owns a contiguous range of the coarsest
-graph level and everything under it, halo rows are exchanged by RCCL all-to-all before every conv (and
-s = dy/deg rows plus cross-edge d-logits in backward), the flat fp32 gradient is all-reduced once per
-step.  Per-GPU work is fixed as N grows ("weak" scaling); --scaling strong shards the 100k mesh instead.
---mode replicas: each rank trains on its own 100k-facet mesh, gradient all-reduce only.
+N > 1: one process per GPU.  Default (--mode shard): ONE mesh is facet-sharded over the N GPUs (shard.py): each
+rank owns a contiguous range of the coarsest graph level and everything under it, halo rows are exchanged by
+RCCL all-to-all before every conv (and s = dy/deg rows plus cross-edge d-logits in backward), the flat fp32
+gradient is all-reduced once per step.  With c2 the mesh has N x 100 000 facets: per-GPU work is fixed as N
+grows ("weak" scaling).  --mode replicas: each rank trains on its own mesh, gradient all-reduce only.
+FGC_BENCH_BACKEND=gloo rehearses N > 1 with N processes on ONE GPU (host-staged exchange).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel's achieved TFLOP/s from hipEvent timings taken live in this process
+  roofline      the dominant kernel FAMILY (summed time per step) through its launch with the most algorithmic work:
+                achieved TFLOP/s from hipEvent timings taken live in this process; `families` has the top three
   cpu_baseline  the oracle (reference-shaped torch CPU restatement) timed on this host on a bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,10 +45,86 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 
+CONFIGS = {
+    # name: (nu, nv, multi_scale, default scaling, what one step is)
+    "c2": (250, 200, False, "weak", "train"),
+    "c3": (250, 100, False, "weak", "train"),
+    "c4": (1000, 500, False, "strong", "train"),
+    "c5": (500, 500, True, "strong", "denoise"),
+}
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--nu", type=int, default=0, help="torus quads around the large circle (default: from --config)")
+    ap.add_argument("--nv", type=int, default=0)
+    ap.add_argument("--multi-scale", action="store_true", help="three-head network, step = multi-scale denoising forward")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="replay the forward+backward enqueue as one hipGraph (1 %% faster than eager here: the step is "
+                         "GPU-bound).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
+                         "the runtime's pre-built graph packets a replay after a stream synchronise computes garbage on "
+                         "this ROCm stack (DESIGN.md section 6), so the timed default stays on eager launches")
+    ap.add_argument("--repeats", type=int, default=5, help="untimed-extra repeats of the K-step block (min / median)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernels", type=str, default="", help="write the full per-kernel table to this file")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="multi-GPU decomposition")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
+    args = ap.parse_args(argv)
+    nu, nv, ms, scaling, what = CONFIGS[args.config]
+    args.nu = args.nu or nu
+    args.nv = args.nv or nv
+    args.multi_scale = args.multi_scale or ms
+    args.scaling = args.scaling or scaling
+    args.what = "denoise" if args.multi_scale else what
+    return args
+
+
+# ---------------------------------------------------------------------------------------------------
+# N > 1 from a plain shell: a fresh torchrun child, started before this process touches the GPU
+# ---------------------------------------------------------------------------------------------------
+def launcher_command(gpus, argv, port):
+    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without torchrun's environment: run the N ranks as a CHILD process group (never an
+    exec of a process that may have touched the GPU) and relay rank 0's JSON line and the exit code."""
+    cmd = launcher_command(args.gpus, argv, _free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in proc.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line:
+        print(line)
+    return proc.returncode if (proc.returncode or line) else 1
+
+
+# ---------------------------------------------------------------------------------------------------
 def build_mesh(nu, nv, seed):
     from facet_graph_convolution_amd.meshgen import torus, add_noise
     from facet_graph_convolution_amd.dataClasses import TrainingSet
@@ -49,7 +135,7 @@ def build_mesh(nu, nv, seed):
 
 
 def kernel_flops(kind, n, nnz, cin, cout, M=9):
-    """Algorithmic FLOPs of one launch (DESIGN.md §5): the dense contraction 2*n*M*cin*cout plus the per-edge
+    """Algorithmic FLOPs of one launch (DESIGN.md section 5): the dense contraction 2*n*M*cin*cout plus the per-edge
     aggregation 2*nnz*M*C (C = gathered width)."""
     gemm = 2.0 * n * M * cin * cout
     if kind == "fwd":          # gathers cin-wide rows
@@ -63,70 +149,125 @@ def kernel_flops(kind, n, nnz, cin, cout, M=9):
     raise ValueError(kind)
 
 
-def algorithmic_bytes_fwd_bwd(net):
-    """SURVEY.md §8d convention: each tensor crossing a layer boundary written once, read once per consumer;
+def algorithmic_bytes_fwd_bwd(net, elem=4):
+    """SURVEY.md section 8d convention: each tensor crossing a layer boundary written once, read once per consumer;
     CSR read once per conv; weights and fused ops free.  Backward moves the same tensors as gradients plus
-    the saved activations again (x2.45 of forward in the survey's accounting: 3879/1584)."""
+    the saved activations again (x2.45 of forward in the survey's accounting: 3879/1584).  elem: bytes per stored
+    activation element (2 with --dtype bf16; the 6-channel input, the 3-channel output and the CSR stay 4 bytes)."""
     dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net.layer_dims()}
     n0, n1, n2 = dims["conv1"][0], dims["conv2"][0], dims["conv3"][0]
     d0, d1, d2 = (dims[k][1] / dims[k][0] for k in ("conv1", "conv2", "conv3"))
-    fwd = 4 * (n0 * (6 + 32 + 1 + d0) + n1 * (32 + 64 + 1 + d1) + n2 * (64 + 128 + 1 + d2) +
-               n2 * (128 + 128 + 1 + d2) + n1 * (32 + 64 + 1 + d1) + n1 * (128 + 64 + 1 + d1) +
-               n0 * (16 + 32 + 1 + d0) + n0 * (64 + 32 + 1 + d0) + n0 * (32 + 3) + n1 * 32 + n2 * 64)
+    e = elem
+    fwd = (n0 * (4 * 6 + e * 32 + 4 * (1 + d0)) + n1 * (e * (32 + 64) + 4 * (1 + d1)) + n2 * (e * (64 + 128) + 4 * (1 + d2)) +
+           n2 * (e * (128 + 128) + 4 * (1 + d2)) + n1 * (e * (32 + 64) + 4 * (1 + d1)) + n1 * (e * (128 + 64) + 4 * (1 + d1)) +
+           n0 * (e * (16 + 32) + 4 * (1 + d0)) + n0 * (e * (64 + 32) + 4 * (1 + d0)) + n0 * (e * 32 + 4 * 3) + n1 * e * 32 +
+           n2 * e * 64)
     return fwd, fwd * 3879.0 / 1584.0
 
 
-def cpu_baseline(sample_faces=(140, 140)):
-    """The oracle timed on this host: one forward+backward of the reference-shaped torch-CPU restatement on a
-    39 200-facet torus (bounded: about 10 s of CPU work, so that the default bench run stays within minutes), up to 32
-    host threads."""
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    """Distinct (physical id, core id) pairs; falls back to the logical count."""
+    seen, phys, core = set(), None, None
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("physical id"):
+                phys = l.split(":")[1].strip()
+            elif l.startswith("core id"):
+                core = l.split(":")[1].strip()
+            elif not l.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return len(seen) or (os.cpu_count() or 1)
+
+
+def cpu_baseline(sample_faces=(140, 140), full=(250, 200)):
+    """The oracle timed on this host (bounded: about 30 s of CPU work, so that the default bench run stays within
+    minutes): (1) one forward+backward of the reference-shaped torch-CPU restatement on a 39 200-facet torus - the
+    backward of the full 100k mesh keeps the materialised [N0,23,288] tensors of every layer alive and does not fit
+    in 62 GB; (2) one forward on the full 100 000-facet mesh of the headline."""
     import torch
     from oracle import model_ref as R
-    ds, F = build_mesh(sample_faces[0], sample_faces[1], seed=7)
-    x = torch.tensor(ds.in_list[0].astype(np.float32))
-    gt = torch.tensor(ds.gt_list[0].astype(np.float32))
-    adjs = [torch.tensor(a.astype(np.int32)) for a in ds.adj_list[0]]
-    threads = min(os.cpu_count() or 1, 32)   # more threads than this only add contention on these op sizes
+    logical = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    threads = min(affinity, 32)   # more threads than this only add contention on these op sizes
     torch.set_num_threads(threads)
+
+    def tensors(nu, nv):
+        ds, F = build_mesh(nu, nv, seed=7)
+        x = torch.tensor(ds.in_list[0].astype(np.float32))
+        gt = torch.tensor(ds.gt_list[0].astype(np.float32))
+        adjs = [torch.tensor(a.astype(np.int32)) for a in ds.adj_list[0]]
+        return x, gt, adjs, F
+
+    x, gt, adjs, F = tensors(*sample_faces)
     params = [p.requires_grad_(True) for p in R.init_params(0)]
     samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
-    Rm = torch.eye(3)
     t0 = time.time()
-    loss, _ = R.train_loss(x, adjs, gt, params, samp, Rm)
+    loss, _ = R.train_loss(x, adjs, gt, params, samp, torch.eye(3))
     loss.backward()
     dt = time.time() - t0
-    return {"value": F / dt, "unit": "facets/s", "cores": threads, "kind": "port",
-            "sample": "oracle/model_ref.py (reference-shaped K-padded torch CPU fp32), 1 forward+backward of the "
-                      "full net on a torus %dx%d = %d facets (N0=%d), %.1f s" % (sample_faces[0], sample_faces[1], F, x.shape[1], dt)}
+    out = {"value": F / dt, "unit": "facets/s", "cores": threads, "kind": "port",
+           "cpu_model": cpu_model(), "logical_cpus": logical, "physical_cores": physical_cores(),
+           "cpus_in_affinity_mask": affinity,
+           "sample": "oracle/model_ref.py (reference-shaped K-padded torch CPU fp32), 1 forward+backward of the "
+                     "full net on a torus %dx%d = %d facets (N0=%d), %.1f s" % (sample_faces[0], sample_faces[1], F,
+                                                                                 x.shape[1], dt)}
+    del loss, x, gt, adjs
+    if full:
+        x, gt, adjs, F = tensors(*full)
+        with torch.no_grad():
+            plain = [p.detach() for p in params]
+            t0 = time.time()
+            y = R.normalizeTensor(R.get_model_reg_multi_scale(x, adjs, plain))
+            dtf = time.time() - t0
+        out["forward_only_full_mesh"] = {"value": F / dtf, "unit": "facets/s",
+                                         "sample": "1 forward of the full net on the torus %dx%d = %d facets (N0=%d), %.1f s" %
+                                                   (full[0], full[1], F, x.shape[1], dtf)}
+        del y
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nu", type=int, default=250)
-    ap.add_argument("--nv", type=int, default=200)
-    ap.add_argument("--graph", type=int, default=0,
-                    help="replay the forward+backward enqueue as one hipGraph (1 %% faster than eager here: the step is "
-                         "GPU-bound).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
-                         "the runtime's pre-built graph packets a replay after a stream synchronise computes garbage on "
-                         "this ROCm stack (DESIGN.md section 6), so the timed default stays on eager launches")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dump-kernels", type=str, default="", help="write the full per-kernel table to this file")
-    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard", help="multi-GPU decomposition")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    args = ap.parse_args()
+# kernel name -> family (the kernel FUNCTION, all template instances and both directions of the shared core together)
+def family_of(kern):
+    if "conv_w8_kernel" in kern or "conv_fwd_kernel" in kern or "conv_bwd_data_kernel" in kern:
+        return "conv_w8"
+    if "conv_bwd_logits" in kern:
+        return "conv_bwd_logits"
+    if "mlp_bwd_kernel" in kern or "mlp_fwd_kernel" in kern:
+        return "mlp"
+    if "gemm_tn" in kern:
+        return "gemm_tn"
+    if "conv_narrow" in kern or "narrow_" in kern:
+        return "conv_narrow"
+    return kern.split("<")[0]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
-                         (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # FGC_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (host-staged exchange)
     backend = os.environ.get("FGC_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
@@ -143,45 +284,49 @@ def main():
     from facet_graph_convolution_amd.net import FacetDenoiser
     from facet_graph_convolution_amd.utils import rand_rotation_matrix
 
+    train = args.what == "train"
     shard = world > 1 and args.mode == "shard"
+    mk = dict(seed=0, multi_scale=args.multi_scale, dtype=args.dtype)
     if shard:
         from facet_graph_convolution_amd.shard import ShardPlan, DistComm, graphs_to_host_csr
         nu = args.nu * world if args.scaling == "weak" else args.nu
         ds, F_total = build_mesh(nu, args.nv, seed=0)          # every rank builds the same mesh (seeded)
         plan = ShardPlan(graphs_to_host_csr(ds.adj_list[0]), rank, world)
-        net = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0], plan=plan,
-                                                   comm=DistComm())
+        net = FacetDenoiser(dev, **mk).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0] if train else None,
+                                                 plan=plan, comm=DistComm())
         n0 = ds.in_list[0].shape[1]            # samples are drawn over the WHOLE mesh, same stream on every rank
         rs = np.random.RandomState(100)
         F = F_total / world                    # facets per GPU (for the per-GPU accounting below)
         halo_frac = [net._mesh["nh"][l] / max(net._mesh["ns"][l], 1) for l in range(3)]
     else:
+        nu = args.nu
         ds, F = build_mesh(args.nu, args.nv, seed=rank)
         F_total = F * world
-        net = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+        net = FacetDenoiser(dev, **mk).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0] if train else None)
         n0 = ds.in_list[0].shape[1]
         rs = np.random.RandomState(100 + rank)
         halo_frac = None
 
-    # per-step random inputs (train.py:561-565) for the whole run, uploaded once: inside the loop they are refreshed by
-    # device-to-device copies (stream-ordered with the hipGraph replay)
+    # per-step random inputs (train.py:561-565) for the whole run, uploaded ONCE: inside the loop they are refreshed by
+    # device-to-device copies (stream-ordered with the hipGraph replay); a sharded rank keeps, per step, the samples
+    # that fall into its own rows
+    nrep = max(args.repeats, 1)
     nsteps_total = args.warmup + args.steps
     samp_host = [rs.randint(n0, size=4000) for _ in range(nsteps_total)]
     rot_host = [rand_rotation_matrix(randnums=rs.uniform(size=3)) for _ in range(nsteps_total)]
-    if not shard:
-        S_all = torch.from_numpy(np.stack(samp_host).astype(np.int32)).to(dev)
-        R_all = torch.from_numpy(np.stack(rot_host).astype(np.float32).reshape(nsteps_total, 9)).to(dev)
+    S_all = torch.from_numpy(np.stack(samp_host).astype(np.int32)).to(dev)
+    R_all = torch.from_numpy(np.stack(rot_host).astype(np.float32).reshape(nsteps_total, 9)).to(dev)
+    S_loc = [net.local_samples_device(s) for s in samp_host] if (shard and train) else None
     torch.cuda.synchronize()
     counter = [0]
 
     def step():
         k = counter[0] % nsteps_total
         counter[0] += 1
-        if shard:
-            net.set_samples(samp_host[k])
-            net.set_rotation(rot_host[k])
-        else:
-            net.set_step_inputs_device(S_all[k], R_all[k])
+        if not train:
+            net.forward_multi_scale() if args.multi_scale else net.forward(rotate=False)
+            return
+        net.set_step_inputs_device(S_all[k], R_all[k], S_loc[k] if S_loc else None)
         net.forward_backward(rotate=True, capture=bool(args.graph) and not shard)
         if world > 1 and not shard:
             if backend == "nccl":
@@ -200,56 +345,75 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_block():
+        sync_barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
     for _ in range(args.warmup):
         step()
-    sync_barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    loss = net.buffers["loss"][0].item()
+    dt = timed_block()                       # THE timed region: exactly K steps, max over ranks
+    loss = net.buffers["loss"][0].item() if train else None
+    # the same K-step block again (extras: spread of the measurement)
+    rep_ms = [dt / args.steps * 1e3] + [timed_block() / args.steps * 1e3 for _ in range(nrep - 1)]
 
     # the same steps as hipGraph replays (one graph per step holds the whole forward+backward enqueue), untimed extra:
     # a second network from the same seed walks the same inputs, so its final loss must equal the eager one bit for bit
     hipgraph = None
-    if world == 1 and not shard and not args.graph:
-        net_g = FacetDenoiser(dev, seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+    if world == 1 and train and not args.graph:
+        net_g = FacetDenoiser(dev, **mk).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+        net_e = FacetDenoiser(dev, **mk).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
 
-        def step_g(k):
-            net_g.set_step_inputs_device(S_all[k % nsteps_total], R_all[k % nsteps_total])
-            net_g.forward_backward(rotate=True, capture=True)
-            net_g.adam_step()
+        def walk(nn, capture):
+            for k in range(args.warmup):
+                nn.set_step_inputs_device(S_all[k], R_all[k])
+                nn.forward_backward(rotate=True, capture=capture)
+                nn.adam_step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(args.warmup, nsteps_total):
+                nn.set_step_inputs_device(S_all[k], R_all[k])
+                nn.forward_backward(rotate=True, capture=capture)
+                nn.adam_step()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t, nn.buffers["loss"][0].item()
 
-        for k in range(args.warmup):
-            step_g(k)
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        for k in range(args.warmup, nsteps_total):
-            step_g(k)
-        torch.cuda.synchronize()
-        tg = time.perf_counter() - tg
-        loss_g = net_g.buffers["loss"][0].item()
-        hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": loss_g, "matches_eager": loss_g == loss}
-        del net_g
+        te, loss_e = walk(net_e, False)
+        tg, loss_g = walk(net_g, True)
+        hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": loss_g, "matches_eager": loss_g == loss_e}
+        del net_g, net_e
 
     # forward-only rate (BASELINE config 2 wording), untimed extra
     torch.cuda.synchronize()
+    nf = max(3, args.steps // 2)
     t1 = time.perf_counter()
-    for _ in range(max(3, args.steps // 2)):
+    for _ in range(nf):
         net.forward(rotate=False)
     torch.cuda.synchronize()
-    fwd_ms = (time.perf_counter() - t1) / max(3, args.steps // 2) * 1e3
+    fwd_ms = (time.perf_counter() - t1) / nf * 1e3
     if world > 1:
         dist.barrier()
 
+    # sharded runs: what the exchanges cost when nothing overlaps them (blocking, timed on the host around device
+    # synchronises), and how many collectives a step issues
+    exchange = None
+    if shard:
+        exchange = net.measure_exchanges(lambda: step(), steps=max(2, min(5, args.steps)))
+        dist.barrier()
+
     roofline = None
+    families = None
     kernels = {}
-    if not args.no_roofline and not shard:
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    if not args.no_roofline and not shard and train:
         # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
         # `steps` eager steps of the same work as the timed region
         net.profile_start()
@@ -272,13 +436,13 @@ def main():
                     kind = "bwd_logits"
                 elif "conv_bwd_data_kernel" in kern or "conv_w8_kernel<data>" in kern:
                     kind = "bwd_data"
-                elif "gemm_tn_kernel" in kern and cnt == args.steps:
+                elif "gemm_tn" in kern and cnt == args.steps:
                     kind = "bwd_weight"
             avg_us = ms / cnt * 1e3
             fl = kernel_flops(kind, *dims[layer]) if kind else None
-            if layer == "mlp" and kern in ("mlp_fwd_kernel", "mlp_bwd_kernel"):
+            if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern):
                 # 32 -> 1024 -> 3 per padded node; the backward recomputes the hidden layer and adds dW and dx
-                fl = 2.0 * dims["conv1"][0] * 1024 * (32 + 3) * (3 if kern == "mlp_bwd_kernel" else 1)
+                fl = 2.0 * dims["conv1"][0] * 1024 * (32 + 3) * (3 if "mlp_bwd_kernel" in kern else 1)
             rows.append((ms, key, cnt, avg_us, fl))
         rows.sort(reverse=True)
         if args.dump_kernels and rank == 0:
@@ -290,42 +454,57 @@ def main():
         for ms, key, cnt, avg_us, fl in rows[:12]:
             kernels[key] = {"launches": cnt, "avg_us": round(avg_us, 2), "share": round(ms / total_ms, 4),
                             "tflops": round(fl / (avg_us * 1e-6) / 1e12, 2) if fl else None}
-        # the dominant kernel = the kernel function with the largest summed time per step (the d-logits kernel: seven
-        # launches), reported through its longest launch
+        # families = kernel FUNCTIONS (conv_w8 forward and data-gradient are the same kernel over the graph and its
+        # transpose); HBM bytes per launch of each family's reported launch from the PMC passes kept under profiles/
+        # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md); null when no pass is recorded
+        traffic_db = {}
+        tpath = os.path.join(REPO, "profiles", "r2_traffic_families.json")
+        if os.path.exists(tpath) and args.nu == 250 and args.nv == 200 and args.dtype == "f32":
+            traffic_db = json.load(open(tpath))
         fam = {}
-        for r in rows:
-            if r[4]:
-                fam[r[1].split("/", 1)[1]] = fam.get(r[1].split("/", 1)[1], 0.0) + r[0]
-        top = max(fam, key=fam.get) if fam else None
-        # ... the launch with the most algorithmic work (ties: first by name, so that the choice does not flip between
-        # two equal layers from run to run)
-        cands = sorted((r for r in rows if r[4] and r[1].split("/", 1)[1] == top), key=lambda r: (-r[4], r[1]))
-        dom = cands[0] if cands else None
-        if dom:
-            ms, key, cnt, avg_us, fl = dom
-            ach = fl / (avg_us * 1e-6) / 1e12
-            # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
-            # gfx950 correction of MI355X_MICROARCH.md); null when the dominant kernel has no recorded pass
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", "r1_traffic_dominant_kernel.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("kernel") == key and args.nu == 250 and args.nv == 200:
-                    traffic = tj["hbm_bytes_per_launch"]
-            roofline = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "avg_kernel_us": round(avg_us, 2), "launch_flops": fl,
-                        "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3)}
+        for ms, key, cnt, avg_us, fl in rows:
+            f = fam.setdefault(family_of(key.split("/", 1)[1]), {"ms": 0.0, "flop": 0.0, "rows": []})
+            f["ms"] += ms
+            f["flop"] += (fl or 0.0) * cnt
+            f["rows"].append((ms, key, cnt, avg_us, fl))
+        ranked = sorted((k for k in fam if fam[k]["flop"] > 0), key=lambda k: -fam[k]["ms"])
+        families = []
+        for name in ranked[:3]:
+            f = fam[name]
+            # the launch with the most algorithmic work (ties: first by name, so the choice does not flip from run to run)
+            top = sorted((r for r in f["rows"] if r[4]), key=lambda r: (-r[4], r[1]))[0]
+            ach = top[4] / (top[3] * 1e-6) / 1e12
+            tr = traffic_db.get(top[1])
+            families.append({"family": name, "share_of_step": round(f["ms"] / total_ms, 4),
+                             "us_per_step": round(f["ms"] / args.steps * 1e3, 1),
+                             "family_tflops": round(f["flop"] / (f["ms"] * 1e-3) / 1e12, 2),
+                             "family_frac": round(f["flop"] / (f["ms"] * 1e-3) / 1e12 / peak, 4),
+                             "kernel": top[1], "avg_kernel_us": round(top[3], 2), "launch_flops": top[4],
+                             "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+                             "traffic": tr["hbm_bytes_per_launch"] if tr else None})
+        if families:
+            d = families[0]
+            roofline = {"bound": "mfma", "kernel": d["kernel"], "family": d["family"], "achieved": d["achieved"],
+                        "peak": peak, "unit": "TFLOP/s", "frac": d["frac"], "traffic": d["traffic"],
+                        "avg_kernel_us": d["avg_kernel_us"], "launch_flops": d["launch_flops"],
+                        "family_share_of_step": d["share_of_step"], "family_frac": d["family_frac"],
+                        "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
+                        "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step")}
 
-    fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net)
+    fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net, elem=2 if args.dtype == "bf16" else 4)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
+        step_bytes = fb_b if train else fwd_b
+        mesh_txt = "torus %dx%d quads = %d facets%s (N0=%d padded nodes%s)" % (
+            nu, args.nv, int(F_total if shard else F), "" if shard else " per GPU", n0, " in the whole mesh" if shard else "")
+        what_txt = ("rotate + forward + angular loss + backward + Adam" if train else
+                    "multi-scale denoising forward (three heads, each normalised)")
         out = {
-            "metric": "facets/sec (fwd+bwd) on 100k-facet mesh",
+            "metric": ("facets/sec (fwd+bwd) on 100k-facet mesh" if train else "facets/sec (multi-scale denoising forward)"),
             "value": F_total * args.steps / dt,
             "unit": "facets/s",
             "n_gpus": world,
@@ -333,26 +512,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "strong" if (shard and args.scaling == "strong") else "weak",
+            "scaling": args.scaling if shard else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "torus %dx%d quads = %d facets per GPU (N0=%d padded nodes%s), full graph U-Net + MLP: "
-                                   "rotate + forward + angular loss + backward + Adam, fp32%s" %
-                                   (args.nu, args.nv, int(F), n0, " in the whole mesh" if shard else "",
-                                    ", hipGraph replay" if (args.graph and not shard) else ""),
+            "config": {"workload": "%s: %s, full graph U-Net + MLP%s: %s, %s%s" % (
+                           args.config, mesh_txt, " with the multi-scale heads" if args.multi_scale else "", what_txt,
+                           "fp32" if args.dtype == "f32" else "bf16 storage / fp32 accumulate, fp32 master weights",
+                           ", hipGraph replay" if (args.graph and not shard) else ""),
                        "parallelism": ("single GPU" if world == 1 else
-                                       ("one %d-facet mesh facet-sharded over %d GPUs, halo all-to-all per conv + flat-gradient "
-                                        "all-reduce (halo/owned rows per level on rank 0: %s)" %
-                                        (F_total, world, ", ".join("%.3f" % h for h in halo_frac))) if shard else
-                                       "1 mesh per GPU, flat-gradient all-reduce")},
+                                       ("one %d-facet mesh facet-sharded over %d GPUs (%s world size %d), halo all-to-all per "
+                                        "conv + flat-gradient all-reduce; halo/owned rows per level on rank 0: %s; %d "
+                                        "collectives per step, %.3f ms per step when exchanged blocking" %
+                                        (F_total, world, "RCCL" if backend == "nccl" else backend, dist.get_world_size(),
+                                         ", ".join("%.3f" % h for h in halo_frac), exchange["collectives_per_step"],
+                                         exchange["blocking_ms_per_step"])) if shard else
+                                       "1 mesh per GPU, flat-gradient all-reduce (%s world size %d)" % (
+                                           "RCCL" if backend == "nccl" else backend, dist.get_world_size()))},
             "loss_deg": loss,
+            "repeats_ms_per_step": [round(v, 4) for v in rep_ms],
+            "ms_per_step_min": min(rep_ms),
+            "ms_per_step_median": float(np.median(rep_ms)),
             "hipgraph_replay": hipgraph,
             "forward_only_ms": fwd_ms,
             "forward_only_facets_per_s": F_total / (fwd_ms * 1e-3),
-            "hbm_roofline_frac_whole_step": fb_b / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),
-            "algorithmic_bytes_fwd_bwd": fb_b,
+            "hbm_roofline_frac_whole_step": step_bytes / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),
+            "algorithmic_bytes_per_step": step_bytes,
+            "exchange": exchange,
             "roofline": roofline,
+            "families": families,
             "kernels": kernels,
             "cpu_baseline": cpu,
         }

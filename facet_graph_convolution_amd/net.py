@@ -116,9 +116,12 @@ class _ConvLayer:
 
 
 class FacetDenoiser:
-    def __init__(self, device="cuda", multi_scale=False, in_channels=6, seed=0):
+    def __init__(self, device="cuda", multi_scale=False, in_channels=6, seed=0, dtype="f32"):
         if not torch.cuda.is_available():
             raise RuntimeError("FacetDenoiser needs an MI355X (no CPU fallback)")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16' (storage of the activations; weights stay fp32)")
+        self.dtype = dtype
         self.L = _lib.lib()
         self.device = torch.device(device)
         self.multi_scale = multi_scale
@@ -177,6 +180,8 @@ class FacetDenoiser:
         plan / comm (facet sharding, shard.py): x, adjs, gt are still the WHOLE mesh; this rank keeps only its
         shard ([owned rows | halo rows] per level) and exchanges halos through `comm` between the layers."""
         dev = self.device
+        if self.dtype != "f32":
+            raise NotImplementedError("dtype %r: only the fp32 network is built" % self.dtype)
         xt = torch.as_tensor(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32))
         xt = xt.reshape(-1, xt.shape[-1]).contiguous()
         if xt.shape[1] != self.in_channels:
@@ -220,8 +225,11 @@ class FacetDenoiser:
         for lay in self.layers:
             B["ag_" + lay.name] = torch.empty(B[lay.x0].shape[0], AG_LD, **f)
         if self.multi_scale:
-            B["y1"] = torch.empty(n1, 3, **f)
-            B["y2"] = torch.empty(n2, 3, **f)
+            for k, nk in (("1", n1), ("2", n2)):
+                B["y" + k] = torch.empty(nk, 3, **f)
+                B["nconv" + k] = torch.empty(nk, 3, **f)
+                B["abs_part" + k] = torch.empty(self.L.fgc_mlp_num_partials(nk), **f)
+                B["norm_scratch" + k] = torch.zeros(2 + self.L.fgc_norm_num_partials(nk), **f)
         # shared backward scratch, sized for the largest user
         max_ds = max((ns[l.level] + nh[l.level]) * self._cout(l) for l in self.layers)
         max_r = max(ns[l.level] * (FGC_M * self._cout(l) + 24) for l in self.layers)
@@ -418,7 +426,8 @@ class FacetDenoiser:
                 xin = B[lay.y]
                 nrows = M["ns"][lay.level]
                 _lib.check(L.fgc_mlp_fwd(_p(xin), nrows, xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
-                                         _p(b2), LRELU_ALPHA, _p(B[out]), None, _p(ws), ws.numel(), st), head)
+                                         _p(b2), LRELU_ALPHA, _p(B[out]), _p(B["abs_part" + out[1]]), _p(ws),
+                                         ws.numel(), st), head)
         self._tag("fwd:mlp")
         W1, b1, W2, b2 = vals[self.slot["head0"]:self.slot["head0"] + 4]
         _lib.check(L.fgc_mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
@@ -615,24 +624,103 @@ class FacetDenoiser:
                 self._upload(buf, loc.astype(np.int32))
             B["sample_ind_local"] = buf
 
-    def set_step_inputs_device(self, sample_ind_dev, R_dev):
+    def set_step_inputs_device(self, sample_ind_dev, R_dev, sample_local_dev=None):
         """Per-step inputs that are ALREADY on the device (e.g. a window of steps uploaded in one go): device-to-device
         copies are kernels on the compute queue, ordered with hipGraph replays; host -> device DMAs between replays of a
-        captured graph were observed to race on this stack when many steps are queued."""
+        captured graph were observed to race on this stack when many steps are queued.  sample_local_dev: a facet-sharded
+        rank's own part of the samples (local_samples_device), used in place as this step's list."""
         B = self._mesh["B"]
         B["sample_ind"].copy_(sample_ind_dev)
         B["R"].copy_(R_dev.reshape(9))
+        if self.sharded:
+            if sample_local_dev is None:
+                raise ValueError("a sharded network needs the rank's local sample list (local_samples_device)")
+            B["sample_ind_local"] = sample_local_dev
+
+    def local_samples_device(self, sample_ind):
+        """The samples (row ids of the WHOLE mesh, train.py:561) that fall into this rank's owned rows, as local row
+        ids on the device; the unsharded network keeps them all."""
+        t = np.asarray(sample_ind).astype(np.int32)
+        if self.sharded:
+            lo = self._mesh["own_lo"]
+            t = t[(t >= lo) & (t < lo + self._mesh["ns"][0])] - lo
+        return torch.from_numpy(np.ascontiguousarray(t.astype(np.int32))).to(self.device)
 
     def forward(self, rotate=False):
         """Normalised normals of the bound mesh: [N0,3] (padded, permuted order). Un-normalised output in buffers['y0']."""
         self._enqueue_forward(rotate)
         return self._mesh["B"]["nconv"]
 
+    def forward_multi_scale(self, rotate=False):
+        """The multi-scale denoising forward of inferNet (train.py:188-193): the three heads, each through
+        normalizeTensor.  Returns (n_conv0 [N0,3], n_conv1 [N0/4,3], n_conv2 [N0/16,3]) in node order."""
+        if not self.multi_scale:
+            raise RuntimeError("the network was built without the multi-scale heads (multi_scale=True)")
+        self._enqueue_forward(rotate)
+        M, L, st = self._mesh, self.L, self._st()
+        B = M["B"]
+        for k, level in (("1", 1), ("2", 2)):
+            nk = M["ns"][level]
+            y, out, part, sc = B["y" + k], B["nconv" + k], B["abs_part" + k], B["norm_scratch" + k]
+            if not self.sharded:
+                _lib.check(L.fgc_normalize_fwd(_p(y), nk, _p(part), part.numel(), _p(out), _p(sc), st), "normalize")
+            else:
+                tot = part.sum().reshape(1)
+                self.comm.all_reduce_sum(tot)
+                sc[0:1] = tot / (3.0 * M["n_total"][level]) + 1e-5
+                _lib.check(L.fgc_normalize_apply(_p(y), nk, _p(sc), _p(out), st), "normalize")
+        return B["nconv"], B["nconv1"], B["nconv2"]
+
+    def measure_exchanges(self, step_fn, steps=3):
+        """Facet-sharded runs: what a step's exchanges cost when nothing overlaps them.  Runs `steps` steps with
+        every collective made blocking and bracketed by device synchronises (host clock); returns the collectives per
+        step, their summed time and bytes sent by this rank.  Diagnostic only: never inside a timed region."""
+        import time
+        comm = self.comm
+        stats = {"n": 0, "s": 0.0, "bytes": 0}
+
+        class Timed:
+            world, rank, host_staged = comm.world, comm.rank, comm.host_staged
+
+            def _t(self, fn, nbytes):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                stats["s"] += time.perf_counter() - t0
+                stats["n"] += 1
+                stats["bytes"] += nbytes
+
+            def all_to_all_rows(self, send, sc, recv, rc):
+                self._t(lambda: comm.all_to_all_rows(send, sc, recv, rc), send.numel() * send.element_size())
+
+            def all_to_all_rows_begin(self, send, sc, recv, rc):
+                self.all_to_all_rows(send, sc, recv, rc)
+                return None
+
+            def finish(self, h):
+                pass
+
+            def all_reduce_sum(self, t):
+                self._t(lambda: comm.all_reduce_sum(t), t.numel() * t.element_size())
+
+        self.comm = Timed()
+        try:
+            for _ in range(steps):
+                step_fn()
+            torch.cuda.synchronize()
+        finally:
+            self.comm = comm
+        return {"collectives_per_step": stats["n"] // steps, "blocking_ms_per_step": stats["s"] / steps * 1e3,
+                "bytes_sent_per_step": stats["bytes"] // steps}
+
     def forward_backward(self, rotate=True, capture=False):
         """One forward + backward (train.py:492-520 without the optimiser); loss in buffers['loss'][0]."""
         if not self._mesh["has_gt"]:
             raise RuntimeError("bind_mesh(..., gt=...) is required for training")
         if capture:
+            from . import require_graph_replay_safe
+            require_graph_replay_safe()
             if self._graph_fb is None:
                 # warm up on a side stream, then capture the whole enqueue sequence into one hipGraph
                 s = torch.cuda.Stream()
@@ -651,6 +739,23 @@ class FacetDenoiser:
             self._enqueue_forward(rotate)
             self._enqueue_loss_backward(rotate)
         return self._mesh["B"]["loss"]
+
+    def eval_loss(self, rotate=True):
+        """Forward + sampled angular loss, no gradients: the validation pass of trainNet (train.py:588-617 runs
+        customLoss alone on the validation feed).  Uses the bound rotation and samples; loss in buffers['loss'][0]."""
+        if not self._mesh["has_gt"]:
+            raise RuntimeError("bind_mesh(..., gt=...) is required for a loss")
+        if self.sharded:
+            raise NotImplementedError("validation runs on an unsharded network")
+        self._enqueue_forward(rotate)
+        B, L, st = self._mesh["B"], self.L, self._st()
+        gt = B["gt"]
+        if rotate:
+            _lib.check(L.fgc_rotate_rows(_p(B["gt"]), _p(B["gtr"]), self._mesh["ns"][0], 1, _p(B["R"]), st), "rotate gt")
+            gt = B["gtr"]
+        samp = B["sample_ind"]
+        _lib.check(L.fgc_angular_loss_fwd(_p(B["nconv"]), _p(gt), _p(samp), samp.numel(), _p(B["loss"]), st), "loss")
+        return B["loss"]
 
     def adam_step(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
         P = self.params

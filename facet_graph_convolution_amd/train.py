@@ -95,6 +95,9 @@ def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device
     lossArray = np.zeros([max(num_iterations // evalStepNum, 1), 2])
     bound = -1
     train_loss, train_samp, hasNan = 0.0, 0, False
+    valid, last_loss = [], 0.0
+    if validSet is not None:
+        valid = [(validSet.in_list[i], validSet.adj_list[i], validSet.gt_list[i]) for i in range(len(validSet.in_list))]
     for it in range(num_iterations):
         if ckpt and it % SAVEITER == 0 and it > 0:
             save_checkpoint(ckpt, net, start + it)
@@ -104,8 +107,27 @@ def trainNet(trainSet, num_iterations, network_path=None, net_name="net", device
             net.bind_cached(b, x, adjs, gt=gt)
             bound = b
         n0 = meshes[b][0].shape[1]
-        loss = net.train_step(sample_ind=rs.randint(n0, size=COST_SAMPLES),
-                              R=rand_rotation_matrix(randnums=rs.uniform(size=3)), capture=capture)
+        samp_it = rs.randint(n0, size=COST_SAMPLES)
+        R_it = rand_rotation_matrix(randnums=rs.uniform(size=3))
+        if valid and it % (evalStepNum * 2) == 0:
+            # train.py:588-617: every 100 iterations the loss alone on every validation mesh, with this iteration's
+            # rotation and fresh random rows, BEFORE the training step; the previous row of the CSV gets the mean of
+            # this and the last value
+            valid_loss = 0.0
+            for vbm, (vx, vadj, vgt) in enumerate(valid):
+                net.bind_cached(("valid", vbm), vx, vadj, gt=vgt)
+                net.set_samples(rs.randint(vx.shape[1], size=COST_SAMPLES))
+                net.set_rotation(R_it)
+                valid_loss += net.eval_loss(rotate=True)[0].item()
+            valid_loss /= len(valid)
+            log("Iteration %d, validation loss %g" % (it, valid_loss))
+            row = min(it // evalStepNum, len(lossArray) - 1)
+            lossArray[row, 1] = valid_loss
+            if it > 0:
+                lossArray[row - 1, 1] = (valid_loss + last_loss) / 2
+                last_loss = valid_loss
+            net.bind_cached(b, *meshes[b][:2], gt=meshes[b][2])
+        loss = net.train_step(sample_ind=samp_it, R=R_it, capture=capture)
         if it % evalStepNum == 0 or it == num_iterations - 1:
             lv = loss[0].item()      # the only host sync of the loop
             if not np.isfinite(lv):  # NaN watchdog (train.py:620-623)

@@ -1,0 +1,55 @@
+"""bench.py on the GPU box: the contract line at N = 1, the N = 2 sharded path started from a plain shell (two ranks
+on this one GPU over gloo: the same DistComm code a multi-GPU RCCL run uses, host-staged), the multi-scale mode."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+SMALL = ["--steps", "2", "--warmup", "1", "--nu", "48", "--nv", "40", "--no-cpu-baseline", "--repeats", "2"]
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ, **(env or {}))
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=e, capture_output=True, text=True,
+                       timeout=timeout, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields_and_family_rooflines():
+    j = _bench(SMALL)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert abs(j["value"] - 48 * 40 * 2 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    assert j["hipgraph_replay"]["matches_eager"] is True
+    fams = [f["family"] for f in j["families"]]
+    assert len(fams) == 3 and "conv_w8" in fams and j["roofline"]["family"] == fams[0]
+    assert 0 < j["roofline"]["frac"] < 1 and len(j["repeats_ms_per_step"]) == 2
+
+
+def test_two_ranks_from_a_plain_shell_over_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts the ranks itself."""
+    j = _bench(["--gpus", "2"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert "facet-sharded over 2 GPUs" in j["config"]["parallelism"] and "world size 2" in j["config"]["parallelism"]
+    assert j["exchange"]["collectives_per_step"] > 0 and j["exchange"]["bytes_sent_per_step"] > 0
+    assert 0 < j["loss_deg"] < 180
+    # weak scaling: the mesh has twice the facets of the single-GPU run
+    assert "%d facets" % (2 * 48 * 40 * 2) in j["config"]["workload"]
+
+
+def test_multi_scale_denoising_mode_sharded_and_single():
+    a = _bench(["--multi-scale"] + SMALL)
+    assert a["metric"].startswith("facets/sec (multi-scale") and a["loss_deg"] is None
+    b = _bench(["--gpus", "2", "--multi-scale", "--scaling", "strong"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["exchange"]["collectives_per_step"] > 0

@@ -261,3 +261,66 @@ def test_multiscale_inference_in_patches_matches_oracle():
     for k in range(3):
         np.testing.assert_allclose(out[k], acc[k] / w, atol=3e-5)
     np.testing.assert_allclose(out[3], fine, atol=2e-5)
+
+
+def test_trainnet_evaluates_the_validation_set():
+    """train.py:588-617: every 100 iterations the loss alone on every validation mesh; the CSV's second column gets the
+    value at that row and the mean of this and the previous value one row up.  The training trajectory is the one of
+    a run without a validation set (the extra draws come from the same stream, so the losses differ - only finite,
+    falling training losses and the row pattern are checked)."""
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, torus, add_noise
+    from facet_graph_convolution_amd.train import trainNet
+    V, F = icosphere(3)
+    ts = TrainingSet()
+    ts.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    Vt, Ft = torus(20, 16)
+    vs = TrainingSet()
+    vs.addMeshWithGT(add_noise(Vt, Ft), Ft, Vt, seed=1)
+    vs.addMeshWithGT(add_noise(V, F, seed=5), F, V, seed=2)
+    logs = []
+    net, losses = trainNet(ts, 250, validSet=vs, log=lambda s: logs.append(s))
+    assert losses.shape == (5, 2) and np.isfinite(losses).all()
+    vlog = [float(l.rsplit(" ", 1)[1]) for l in logs if "validation loss" in l]
+    assert len(vlog) == 3                                   # iterations 0, 100, 200
+    assert losses[4, 1] == pytest.approx(vlog[2]) and losses[3, 1] == pytest.approx((vlog[2] + vlog[1]) / 2)
+    # row 1 was written at iteration 100 as (v100 + last_loss) / 2 with last_loss still 0: the reference sets
+    # last_loss only inside `if iter > 0` (train.py:615-617)
+    assert losses[1, 1] == pytest.approx(vlog[1] / 2)
+    assert vlog[2] < vlog[0] and losses[4, 0] < losses[0, 0]
+
+
+def test_graph_capture_refuses_when_the_runtime_switch_was_not_in_effect():
+    """forward_backward(capture=True) must raise - not compute garbage - when DEBUG_CLR_GRAPH_PACKET_CAPTURE was not 0
+    at HIP initialisation: the caller exported another value, or touched torch.cuda before importing the package."""
+    import subprocess, sys, textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = textwrap.dedent("""
+        import numpy as np
+        from facet_graph_convolution_amd.net import FacetDenoiser
+        from facet_graph_convolution_amd.dataClasses import TrainingSet
+        from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+        V, F = icosphere(2)
+        ds = TrainingSet(); ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+        net = FacetDenoiser("cuda:0").bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
+        net.forward_backward(rotate=True)            # eager is always fine
+        try:
+            net.forward_backward(rotate=True, capture=True)
+            print("captured")
+        except RuntimeError as e:
+            print("refused:", str(e)[:60])
+    """)
+    env = dict(os.environ)
+    env.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+    ok = subprocess.run([sys.executable, "-c", body], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert "captured" in ok.stdout, ok.stdout + ok.stderr[-2000:]
+    late = subprocess.run([sys.executable, "-c", "import torch; torch.cuda.init()\n" + body], cwd=repo, env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert "refused" in late.stdout and "captured" not in late.stdout, late.stdout + late.stderr[-2000:]
+    wrong = subprocess.run([sys.executable, "-c", body], cwd=repo, env=dict(env, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"),
+                           capture_output=True, text=True, timeout=600)
+    assert "refused" in wrong.stdout and "captured" not in wrong.stdout, wrong.stdout + wrong.stderr[-2000:]
+    exported = subprocess.run([sys.executable, "-c", "import torch; torch.cuda.init()\n" + body], cwd=repo,
+                              env=dict(env, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0"), capture_output=True, text=True,
+                              timeout=600)
+    assert "captured" in exported.stdout, exported.stdout + exported.stderr[-2000:]

@@ -1,0 +1,91 @@
+"""Oracle parity at benchmark scale (the fixtures stop at 1 280 facets = 51 level-0 tiles): thousands of tiles, more
+workgroups than CUs, the XCD tile remap, the 16-slot fast forms, and the LONG d-logits form on an irregular mesh.
+Same tolerances as test_gpu_net.py: unit normals 2e-5 abs, loss 1e-4 rel, gradients 2e-3 of each tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh(nu, nv, flips=0, seed=7):
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import torus, add_noise, flip_edges
+    V, F = torus(nu, nv)
+    if flips:
+        F = flip_edges(F, flips, seed=1)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F, 0.2, seed=1 + seed), F, V, seed=seed)
+    return ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+
+
+def _oracle_inputs(x, adjs, gt):
+    return (torch.tensor(x.astype(np.float32)), [torch.tensor(a.astype(np.int32)) for a in adjs],
+            torch.tensor(gt.astype(np.float32)))
+
+
+def _train_step_vs_oracle(x, adjs, gt):
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    from oracle import model_ref as R
+    torch.set_num_threads(min(len(__import__("os").sched_getaffinity(0)), 32))
+    net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    net.set_samples(samp)
+    net.set_rotation(Rm)
+    loss = net.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    params = [p.requires_grad_(True) for p in R.init_params(0)]
+    xt, adjt, gtt = _oracle_inputs(x, adjs, gt)
+    ref_loss, n_conv = R.train_loss(xt, adjt, gtt, params, samp, torch.tensor(Rm.astype(np.float32)))
+    ref_loss.backward()
+    err_n = (net.buffers["nconv"].cpu() - n_conv[0].detach()).abs().max().item()
+    assert err_n < 2e-5, err_n
+    assert abs(loss[0].item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    worst = 0.0
+    for i, (g, p) in enumerate(zip(net.params.grads, params)):
+        scale = max(p.grad.abs().max().item(), 1e-3)
+        err = (g.cpu() - p.grad).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
+    print("N0 = %d: |normals - oracle| %.2e, worst rel grad err %.2e" % (x.shape[1], err_n, worst))
+    return net
+
+
+def test_39k_facet_train_step_matches_oracle():
+    """torus 140 x 140 = 39 200 facets (about 1 500 level-0 tiles, six per CU): full forward + backward."""
+    x, adjs, gt = _mesh(140, 140)
+    assert x.shape[1] > 40000
+    _train_step_vs_oracle(x, adjs, gt)
+
+
+def test_100k_facet_forward_matches_oracle():
+    """BASELINE config 2 at full size: torus 250 x 200 = 100 000 facets, forward of the whole network (the oracle's
+    backward does not fit in host memory at this size)."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from oracle import model_ref as R
+    x, adjs, gt = _mesh(250, 200, seed=0)
+    net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs)
+    n_conv = net.forward(rotate=False)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(len(__import__("os").sched_getaffinity(0)), 32))
+    xt, adjt, _ = _oracle_inputs(x, adjs, gt)
+    with torch.no_grad():
+        y = R.get_model_reg_multi_scale(xt, adjt, R.init_params(0))
+        ref = R.normalizeTensor(y)
+    y0 = net.buffers["y0"].cpu()
+    scale = max(1.0, y[0].abs().max().item())
+    assert (y0 - y[0]).abs().max().item() < 3e-6 * scale
+    err = (n_conv.cpu() - ref[0]).abs().max().item()
+    print("100k facets (N0 = %d): |normals - oracle| %.2e" % (x.shape[1], err))
+    assert err < 2e-5
+
+
+def test_irregular_24k_facet_train_step_matches_oracle():
+    """torus 120 x 100 = 24 000 facets after 7 000 random edge flips: facet degrees up to K = 23 on ~900 level-0 tiles
+    (more than the 256 CUs), so the LONG d-logits form and the 24-slot conv kernels run at occupancy."""
+    x, adjs, gt = _mesh(120, 100, flips=7000)
+    degs = [int((a[0] > 0).sum(1).max()) for a in adjs]
+    assert degs[0] > 16 and x.shape[1] >= 24000, degs
+    _train_step_vs_oracle(x, adjs, gt)
