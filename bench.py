@@ -93,9 +93,17 @@ def parse_args(argv=None):
 # N > 1 from a plain shell: a fresh torchrun child, started before this process touches the GPU
 # ---------------------------------------------------------------------------------------------------
 def launcher_command(gpus, argv, port):
-    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL)."""
+    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL).  Only the contract's own flags travel
+    on the command line; everything else goes through FGC_BENCH_ARGV (torchrun's argparse claims abbreviations of its
+    own options in the script's arguments: `--nu` reads as `--numa-binding`)."""
+    keep = []
+    it = iter(range(len(argv)))
+    for i in it:
+        if argv[i] in ("--gpus", "--steps", "--warmup") and i + 1 < len(argv):
+            keep += [argv[i], argv[i + 1]]
+            next(it, None)
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + keep
 
 
 def _free_port():
@@ -110,7 +118,7 @@ def self_launch(args, argv):
     """`python bench.py --gpus N` without torchrun's environment: run the N ranks as a CHILD process group (never an
     exec of a process that may have touched the GPU) and relay rank 0's JSON line and the exit code."""
     cmd = launcher_command(args.gpus, argv, _free_port())
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FGC_BENCH_ARGV=json.dumps(list(argv)))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
@@ -257,6 +265,8 @@ def family_of(kern):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    if os.environ.get("FGC_BENCH_ARGV") and "WORLD_SIZE" in os.environ:
+        argv = json.loads(os.environ["FGC_BENCH_ARGV"])      # a rank of our own self-launch: the parent's full argv
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, argv))

@@ -24,7 +24,7 @@ def test_config_presets_follow_the_survey():
 
 def test_launcher_command_is_the_drivers_torchrun_line():
     import bench
-    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "7"], 29999)
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--nu", "48", "--steps", "7", "--multi-scale"], 29999)
     assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
     assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
