@@ -57,6 +57,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2c __attribute__((ext_vector_type(2)));
 
 #ifdef __HIPCC__
+// ---- bf16 storage (FGC_CONV_BF16: activations live in HBM as bf16, all sums stay fp32) ----------------------
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two bf16 in one dword (low half = the element at the lower address) -> two floats
+__device__ __forceinline__ f32x2c bf2_to_f2(unsigned w) {
+    return f32x2c{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+}
+// round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned f2_to_bf2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2c{a, b}, bf16x2));
+}
+__device__ __forceinline__ f32x4 bf4_to_f4(u32x2 w) {
+    return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16),
+                 __uint_as_float(w[1] & 0xFFFF0000u)};
+}
+__device__ __forceinline__ u32x2 f4_to_bf4(f32x4 v) { return u32x2{f2_to_bf2(v[0], v[1]), f2_to_bf2(v[2], v[3])}; }
+__device__ __forceinline__ float bf_to_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f_to_bf(float v) {
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+// element idx of an activation tensor that is fp32 or bf16 behind the same pointer
+__device__ __forceinline__ float ld_act(const float* base, size_t idx, int bf16) {
+    return bf16 ? bf_to_f(reinterpret_cast<const unsigned short*>(base)[idx]) : base[idx];
+}
+__device__ __forceinline__ void st_act(float* base, size_t idx, float v, int bf16) {
+    if (bf16) reinterpret_cast<unsigned short*>(base)[idx] = f_to_bf(v);
+    else base[idx] = v;
+}
+
 // Sum over each row of 16 lanes, result in every lane, on the VALU's DPP crossbar (4 adds) instead of 4 LDS-pipe
 // ds_bpermute round trips: quad xor 1, quad xor 2, then mirror within 8 and within 16 (the partial sums are already
 // uniform inside each quad, so the mirrors act as xor 4 / xor 8).  Lane 0 adds in the same order as an xor butterfly.
@@ -80,6 +112,9 @@ __device__ __forceinline__ float fgc_dpp_c(float v) {
 constexpr int KC = 32;        // channels per pass
 constexpr int KPASS = 288;    // FGC_M * KC, a multiple of 16
 constexpr int ZSTRIDE = 296;  // LDS row stride of the aggregate tile: == 8 mod 16, >= KPASS
+// bf16 form of the aggregate tile: 288 bf16 = 576 B per row, padded to 608 B (== 32 mod 64: the same ds_read_b128
+// A-fragment pattern - lane l reads row l&15 at byte offset 16*(l>>4) - stays conflict free); in bf16 elements
+constexpr int ZSTRIDE_BF = 304;
 
 struct ConvGeom {
     int cin, cout;

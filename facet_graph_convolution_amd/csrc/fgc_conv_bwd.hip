@@ -37,10 +37,12 @@ __device__ __forceinline__ float slope_from_y(float y, float alpha) { return y >
 // s = dy * lrelu'(y) / deg ; db partial column sums of dy * lrelu'(y) over rows that got the bias
 // ---------------------------------------------------------------------------------------------
 // workgroup = (256 / cp2) row lanes x cp2 columns (cp2 = cout rounded up to a power of two); coalesced over columns
+// in_bf16: dy and y are bf16 tensors; out_bf16: so is ds (FGC_CONV_BF16; a narrow first layer keeps its ds in fp32)
 __global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                     const int* __restrict__ rowptr, int n, int cout, int cp2, int act,
                                                     float alpha, int bias_mask, int rows_per_block,
-                                                    float* __restrict__ ds, float* __restrict__ db_part) {
+                                                    float* __restrict__ ds, float* __restrict__ db_part, int in_bf16,
+                                                    int out_bf16) {
     __shared__ float part[256];
     const int col = threadIdx.x % cp2, rl = threadIdx.x / cp2, nrl = 256 / cp2;
     const int r0 = blockIdx.x * rows_per_block;
@@ -49,10 +51,10 @@ __global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy
     if (col < cout) {
         for (int r = r0 + rl; r < r1; r += nrl) {
             const int d = rowptr[r + 1] - rowptr[r];
-            float g = dy[(size_t)r * cout + col];
-            if (act) g *= slope_from_y(y[(size_t)r * cout + col], alpha);
+            float g = ld_act(dy, (size_t)r * cout + col, in_bf16);
+            if (act) g *= slope_from_y(ld_act(y, (size_t)r * cout + col, in_bf16), alpha);
             if (!bias_mask || d > 0) acc += g;
-            ds[(size_t)r * cout + col] = d > 0 ? g / (float)d : 0.f;
+            st_act(ds, (size_t)r * cout + col, d > 0 ? g / (float)d : 0.f, out_bf16);
         }
     }
     part[threadIdx.x] = acc;
@@ -72,19 +74,6 @@ __global__ void pack_logit_weight_kernel(const float* __restrict__ W0, float* __
     pack_logit_weight_body(W0, Wq, cin, cout, opad, kc, kpass, passes, blockIdx.x, gridDim.x);
 }
 
-// every packed operand of several layers in one launch (fgc_conv_pack)
-struct PackJob {
-    const float* W0;
-    float* dst;
-    int kind;   // 0: forward operand, 1: data-gradient operand (transposed), 2: d-logits operand
-    int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
-    int block0;
-};
-constexpr int PACK_MAX_JOBS = 24;
-struct PackJobs {
-    PackJob job[PACK_MAX_JOBS];
-    int njobs, nblocks;
-};
 __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
     int q = 0;
 #pragma unroll
@@ -93,7 +82,10 @@ __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
     const PackJob& j = J.job[q];
     const int bid = blockIdx.x - j.block0;
     const int nb = (q + 1 < J.njobs ? J.job[q + 1].block0 : J.nblocks) - j.block0;
-    if (j.kind == 2) pack_logit_weight_body(j.W0, j.dst, j.cin, j.cout, j.opad, j.kc, j.kpass, j.passes, bid, nb);
+    if (j.kind == 6) pack_logit_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);
+    else if (j.kind >= 4) pack_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.kdim, j.ncols, j.npad, j.passes,
+                                                j.kind - 4, bid, nb);
+    else if (j.kind == 2) pack_logit_weight_body(j.W0, j.dst, j.cin, j.cout, j.opad, j.kc, j.kpass, j.passes, bid, nb);
     else pack_weight_body(j.W0, j.dst, j.cin, j.cout, j.kdim, j.ncols, j.npad, j.kc, j.kpass, j.passes, j.kind, bid, nb);
 }
 
@@ -818,6 +810,184 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1, bf16 storage (FGC_CONV_BF16).  Same decomposition and summation structure as conv_bwd_logits_deep_kernel; the two
+// matrix products run on v_mfma_f32_16x16x32_bf16:
+//   dz tile [32 x 288] = s tile [32 x cout] (bf16, LDS) x Wq (bf16, packed fragments)     K = cout, 32 per k-step
+//   dq_i [9 x 16 edges] = dz_i [9 x 32] (bf16, LDS) x X_i [32 x 16 edges]                 K = the pass' 32 channels:
+//       one MFMA per node and pass; its B fragment is ONE 16-byte load per lane from the neighbour's bf16 row
+// s = dy * lrelu'(y) / deg comes from ds_db_kernel (bf16), the soft assignment and its backward stay fp32.
+// ---------------------------------------------------------------------------------------------
+template <bool LONG>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreParams p, LogitParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int QS = LONG ? KMAX : 16;
+    const Smem s = carve(smem_raw, ZSTRIDE_BF / 2, QS);
+    const int cout = lp.cout;                       // a multiple of 32
+    const int obytes = cout * 2 + 32;               // LDS row stride of the s tile (== 32 mod 64)
+    char* dst = reinterpret_cast<char*>(s.extra);   // s tile [TILE][obytes]
+    float* red = reinterpret_cast<float*>(dst + TILE * obytes);   // [4][12]
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    {
+        // rows tile0 .. tile0+31 of s are one contiguous run of 32 * cout bf16
+        const int cpr = cout >> 3;                   // 16-byte chunks per row
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(lp.ds) + (size_t)tile0 * cout);
+        const int vmax = min(p.n - tile0, TILE) * cpr - 1;
+        for (int t = tid; t < TILE * cpr; t += NTHREADS) {
+            const int r = t / cpr, c8 = t % cpr;
+            const u32x4 v = src[min(t, vmax)];
+            *reinterpret_cast<u32x4*>(dst + r * obytes + c8 * 16) = t <= vmax ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    softmax_phase<false, QS>(p, s, tile0, 0, nullptr, nullptr);
+    __syncthreads();
+
+    constexpr int nct = KPASS >> 4;   // 18
+    const int kso = cout >> 5;
+    const u32x4* Wq16 = reinterpret_cast<const u32x4*>(lp.Wq);
+    unsigned short* zt16 = reinterpret_cast<unsigned short*>(s.ztile);
+    const char* ztb = reinterpret_cast<const char*>(s.ztile);
+    int dn[NPW], rowid[NPW];
+    f32x4 dq[NPW];
+    f32x4 dq_hi[LONG ? NPW : 1];
+#pragma unroll
+    for (int nn = 0; nn < (LONG ? NPW : 1); ++nn) dq_hi[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nn = 0; nn < NPW; ++nn) {
+        const int node = wave * NPW + nn;
+        dn[nn] = __builtin_amdgcn_readfirstlane(min(s.deg[node], KMAX));
+        const int e = max(min(lr, dn[nn] - 1), 0);
+        rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]) : 0;
+        dq[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int mrow = lr < FGC_M ? lr : FGC_M - 1;  // rows 9..15 of the product are never read
+    f32x4 dcacc = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int pass = 0; pass < p.passes; ++pass) {
+        const int cpass = pass * KC;
+        const bool first = cpass < p.c0;                                            // block-uniform
+        const float* base = first ? p.src0 : p.src1;
+        const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * 2u;
+        const unsigned laneoff = (unsigned)((first ? cpass : cpass - p.c0) + 8 * lq) * 2u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+        // B fragments of the per-node products: the neighbour rows of all 8 nodes of the wave, requested up front
+        u32x4 bx[NPW];
+#pragma unroll
+        for (int nn = 0; nn < NPW; ++nn)
+            bx[nn] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rsrc, __umul24((unsigned)rowid[nn], rowbytes) + laneoff, 0, 0));
+        // ---- dz tile = s tile x Wq[pass] -> LDS (bf16)
+        {
+            f32x4 acc[RT][K1_CTW];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < kso; ++ks) {
+                u32x4 b[K1_CTW];
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c)
+                    b[c] = Wq16[((size_t)(pass * kso + ks) * nct + min(wave + c * 4, nct - 1)) * 64 + lane];
+                u32x4 a[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const u32x4*>(dst + (r * 16 + lr) * obytes + ks * 64 + lq * 16);
+#pragma unroll
+                for (int c = 0; c < K1_CTW; ++c)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[r]),
+                                                                           __builtin_bit_cast(bf16x8, b[c]), acc[r][c], 0, 0, 0);
+            }
+            if (pass > 0) __syncthreads();  // the previous pass' readers of the dz tile are done
+#pragma unroll
+            for (int c = 0; c < K1_CTW; ++c) {
+                const int ct = wave + c * 4;
+                if (ct >= nct) continue;
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        zt16[(size_t)(r * 16 + lq * 4 + t) * ZSTRIDE_BF + ct * 16 + lr] = f_to_bf(acc[r][c][t]);
+            }
+        }
+        __syncthreads();
+        // ---- per node: dq += dz_i (9 x 32) . X_i (32 x 16 edge slots), one MFMA
+#pragma unroll
+        for (int nn = 0; nn < NPW; ++nn) {
+            const int node = wave * NPW + nn;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(ztb + (size_t)node * (ZSTRIDE_BF * 2) + (mrow * 32 + 8 * lq) * 2);
+            dq[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bx[nn]),
+                                                            dq[nn], 0, 0, 0);
+            if constexpr (LONG) {
+                if (dn[nn] > 16) {                      // wave-uniform: edge slots 16..23
+                    const int e = min(16 + lr, dn[nn] - 1);
+                    const int row = __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]);
+                    const u32x4 x1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                   rsrc, __umul24((unsigned)row, rowbytes) + laneoff, 0, 0));
+                    dq_hi[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                       __builtin_bit_cast(bf16x8, x1), dq_hi[nn], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- softmax backward: lane (edge = lr, m0 = 4*lq) holds dq[m0..m0+3][edge]  (as conv_bwd_logits_deep_kernel)
+#pragma unroll
+    for (int nn = 0; nn < NPW; ++nn) {
+        const int node = wave * NPW + nn;
+        const int i = tile0 + node;
+        const int d = dn[nn];
+        if (i >= p.n) continue;                    // wave-uniform
+        if (d <= 0) {                              // an isolated node still owns a dag row
+            if (lr == 0 && lq < 3)
+                *reinterpret_cast<f32x4*>(lp.dag + (size_t)i * FGC_AG_LD + 4 * lq) = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const int e0 = s.deg[TILE + 4 + node];     // first edge id, left in LDS by the softmax phase
+        f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ntile = (LONG && d > 16) ? 2 : 1;
+        for (int et = 0; et < ntile; ++et) {
+            const int edge = 16 * et + lr;
+            const bool ok = edge < d;
+            const float* qr = s.qbuf + ((size_t)node * QS + min(edge, d - 1)) * QLD;
+            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
+            else if (lq == 2) q[0] = qr[8];
+            f32x4 g = (LONG && et == 1) ? dq_hi[LONG ? nn : 0] : dq[nn];
+            if (lq == 2) { g[1] = 0.f; g[2] = 0.f; g[3] = 0.f; }
+            if (lq == 3) g = f32x4{0.f, 0.f, 0.f, 0.f};
+            float dot = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+            f32x4 dl;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dl[t] = ok ? q[t] * (g[t] - dot) : 0.f;
+            if (ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = dl;
+            da += dl;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = da[t];
+            FGC_ROW16_SUM(v);
+            da[t] = v;
+        }
+        dcacc += da;
+        if (lr == 0 && lq < 3) *reinterpret_cast<f32x4*>(lp.dag + (size_t)i * FGC_AG_LD + 4 * lq) = da;
+    }
+    __syncthreads();
+    if (lr == 0 && lq < 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[wave * 12 + 4 * lq + t] = dcacc[t];
+    }
+    __syncthreads();
+    if (tid < 12) {
+        const float v = tid < FGC_M ? (red[tid] + red[12 + tid]) + (red[24 + tid] + red[36 + tid]) : 0.f;
+        lp.dc_part[(size_t)blockIdx.x * 12 + tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2: data gradient = forward core over the transposed graph
 // ---------------------------------------------------------------------------------------------
 template <int LPN, bool VEC4>
@@ -1067,7 +1237,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 //   * the 4-wave sum goes through 2 x 16 KB of LDS instead of 4, so four workgroups are resident per CU.
 // NJ = 4: 64 x 64 output tile (lane lr owns columns 4*lr .. 4*lr+3); NJ = 2: 64 x 32 for operands only 32 wide (columns
 // 2*lr, 2*lr+1: half the MFMAs instead of multiplying clamped duplicates)
-template <int NJ>
+// BF: both operands are bf16 tensors (FGC_CONV_BF16); they are widened on load and multiplied on the fp32 MFMA: the
+// products are exact and the sum over the nodes stays an fp32 chain, as in the fp32 network
+template <int NJ, bool BF = false>
 __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __restrict__ A, int lda, int P,
                                                                 const float* __restrict__ x0,
                                                                 const float* __restrict__ x1, int c0, int c1, int shift,
@@ -1085,7 +1257,9 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     // column quads of this lane, clamped into the operands (results of clamped columns are never stored)
     const int pc = min(p0 + 4 * lr, P - 4);
     const int qc = min(q0 + NJ * lr, Q - NJ);
-    const float* bsrc = qc < c0 ? x0 + qc : x1 + (qc - c0);
+    const float* bsrc = BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(qc < c0 ? x0 : x1) +
+                                                            (qc < c0 ? qc : qc - c0))
+                           : (qc < c0 ? x0 + qc : x1 + (qc - c0));
     const int bld = qc < c0 ? c0 : c1;
     f32x4 acc[4][NJ];
 #pragma unroll
@@ -1098,6 +1272,18 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     auto ld = [&](int step, f32x4& a, f32x4& b, int& row) {
         row = r_begin + 4 * step + lq;
         const int rc = min(row, r_end - 1);
+        if constexpr (BF) {
+            const unsigned short* A16 = reinterpret_cast<const unsigned short*>(A);
+            const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bsrc);
+            a = bf4_to_f4(*reinterpret_cast<const u32x2*>(A16 + (size_t)rc * lda + pc));
+            if constexpr (NJ == 4) {
+                b = bf4_to_f4(*reinterpret_cast<const u32x2*>(b16 + (size_t)(rc >> shift) * bld));
+            } else {
+                const f32x2c b2 = bf2_to_f2(*reinterpret_cast<const unsigned*>(b16 + (size_t)(rc >> shift) * bld));
+                b = f32x4{b2[0], b2[1], 0.f, 0.f};
+            }
+            return;
+        }
         a = *reinterpret_cast<const f32x4*>(A + (size_t)rc * lda + pc);
         if constexpr (NJ == 4) {
             b = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(rc >> shift) * bld);
@@ -1316,6 +1502,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const int ostride = opad + 8;
 
     const int stages = io->stages ? io->stages : 15;
+    const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
     FGC_CHECK_ARG(io->data_tile_list == nullptr || (io->n_data_tiles >= 0 && io->n_data_tiles <= cdiv(d->n, TILE)),
                   "fgc_conv_bwd: n_data_tiles=%d outside [0, %d]", io->n_data_tiles, cdiv(d->n, TILE));
     // The deep d-logits kernel of the 32- and 64-wide layers can compute s (and the db partials) in its prologue: one
@@ -1326,7 +1513,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                          cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) && (size_t)d->n * 4 * 128 < 0xFFFFFFFFull &&
                          !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1') &&
                          !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
-    const bool fuse_ds = (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, TILE) &&
+    FGC_CHECK_ARG(!bf16 || narrow_path || (deep_ok && cout % 32 == 0),
+                  "fgc_conv_bwd: FGC_CONV_BF16 needs widths that are multiples of 32, 16-byte aligned tensors and degrees <= %d "
+                  "(cin=%d cout=%d max_deg=%d)", KMAX, cin, cout, d->max_deg);
+    const bool fuse_ds = !bf16 && (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, TILE) &&
                          !(d->max_deg > 16 && cout > 32) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
@@ -1336,7 +1526,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         int cp2 = 1;
         while (cp2 < cout) cp2 <<= 1;
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
-                   d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part);
+                   d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part, bf16 ? 1 : 0,
+                   (bf16 && !narrow_path) ? 1 : 0);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");   // db partials are summed with the other parameter gradients (stage 8)
     }
     // first layer over a narrow input (no input gradient wanted): vector-ALU path, no transposed graph, no r buffer
@@ -1353,7 +1544,16 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         return FGC_OK;
     }
     // operand packing
-    if ((stages & 6) && !(io->flags & FGC_CONV_PACKED)) {
+    if ((stages & 6) && !(io->flags & FGC_CONV_PACKED) && bf16) {
+        PackJobs J;
+        J.njobs = 2;
+        const size_t t1 = (size_t)g1.passes * (cout >> 5) * 18 * 512, t2 = (size_t)g2.passes * 9 * (g2.npad >> 4) * 512;
+        J.job[0] = PackJob{d->W0, w.Wq, 6, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0};
+        J.job[1] = PackJob{d->W0, w.Wpt, 5, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, cdiv((int)t1, 1024)};
+        J.nblocks = cdiv((int)t1, 1024) + cdiv((int)t2, 1024);
+        FGC_LAUNCH("pack_many_kernel", st, pack_many_kernel, dim3(J.nblocks), dim3(256), 0, J);
+        FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
+    } else if ((stages & 6) && !(io->flags & FGC_CONV_PACKED)) {
         const size_t tot = (size_t)g1.passes * opad * g1.kpass;
         FGC_LAUNCH("pack_logit_weight_kernel", st, pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, d->W0, w.Wq, cin, cout,
                            opad, g1.kc, g1.kpass, g1.passes);
@@ -1379,7 +1579,23 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         }
         size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
         const bool vec4 = conv_vec4_ok(d);
-        if (g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX &&
+        if (bf16) {
+            const bool lng = d->max_deg > 16;
+            smem = smem_core_bytes(ZSTRIDE_BF / 2, lng ? KMAX : 16) + (size_t)TILE * (cout * 2 + 32) + 48 * 4;
+            if (lng) {
+                hipFuncSetAttribute((const void*)conv_bwd_logits_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem);
+                FGC_LAUNCH("conv_bwd_logits_bf16_kernel", st, (conv_bwd_logits_bf16_kernel<true>), dim3(cdiv(d->n, TILE)),
+                           dim3(NTHREADS), smem, p, lp);
+            } else {
+                hipFuncSetAttribute((const void*)conv_bwd_logits_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem);
+                FGC_LAUNCH("conv_bwd_logits_bf16_kernel", st, (conv_bwd_logits_bf16_kernel<false>), dim3(cdiv(d->n, TILE)),
+                           dim3(NTHREADS), smem, p, lp);
+            }
+            FGC_CHECK_LAUNCH("fgc_conv_bwd/logits_bf16");
+            rc = 0;
+        } else if (g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX &&
             !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1')) {
             static bool attr = false;
             if (!attr) {
@@ -1436,7 +1652,12 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
-        if (g2.lpn == 8 && w8_supported(p, io->max_in_deg)) {
+        if (bf16) {
+            FGC_CHECK_ARG(w8_bf16_supported(p, io->max_in_deg), "fgc_conv_bwd: FGC_CONV_BF16: unsupported shape for the data "
+                          "gradient (cin=%d cout=%d max_in_deg=%d)", cin, cout, io->max_in_deg);
+            rc = launch_data_w8(p, ep, smem, io->max_in_deg, st, true);
+            if (rc) return rc;
+        } else if (g2.lpn == 8 && w8_supported(p, io->max_in_deg)) {
             rc = launch_data_w8(p, ep, smem, io->max_in_deg, st);
             if (rc) return rc;
         } else
@@ -1453,7 +1674,13 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const int ns = cdiv(d->n, rps);
         const dim3 g1(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
-        if (stream_ok && cin <= 32 && d->c1 == 0)
+        if (bf16 && cin <= 32 && d->c1 == 0)
+            FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<2, true>), dim3(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL,
+                       PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        else if (bf16)
+            FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<4, true>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
+                       d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        else if (stream_ok && cin <= 32 && d->c1 == 0)
             FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, dim3(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
                        d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<4>, g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
@@ -1506,10 +1733,11 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
         if (rc) return rc;
         const int cin = d->c0 + d->c1, cout = d->cout;
         const bool narrow = narrow_supported(d);
+        const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
         if (fwd_ws && fwd_ws[i] && !narrow) {
             const ConvGeom g = conv_geom(cin, cout);
             FGC_CHECK_ARG((uintptr_t)fwd_ws[i] % 16 == 0, "fgc_conv_pack: workspace %d misaligned", i);
-            add(PackJob{d->W0, (float*)fwd_ws[i], 0, cin, cout, cin, cout, g.npad, g.kc, g.kpass, g.passes, 0, 0},
+            add(PackJob{d->W0, (float*)fwd_ws[i], bf16 ? 4 : 0, cin, cout, cin, cout, g.npad, g.kc, g.kpass, g.passes, 0, 0},
                 (size_t)g.passes * g.kpass * g.npad);
         }
         const bool narrow_bwd = narrow && ios && ios[i] && ios[i]->dx0 == nullptr;   // vector-ALU path: nothing to pack
@@ -1518,10 +1746,17 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
             const BwdWorkspace w = plan_bwd(d, (char*)bwd_ws[i]);
             const ConvGeom g1 = conv_geom(cin, cout), g2 = conv_geom(cout, cin);
             const int opad = (cout + 15) / 16 * 16;
+            if (bf16) {
+                add(PackJob{d->W0, w.Wq, 6, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
+                    (size_t)g1.passes * (cout >> 5) * 18 * 512);
+                add(PackJob{d->W0, w.Wpt, 5, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},
+                    (size_t)g2.passes * 9 * (g2.npad >> 4) * 512);
+            } else {
             add(PackJob{d->W0, w.Wq, 2, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
                 (size_t)g1.passes * opad * g1.kpass);
             add(PackJob{d->W0, w.Wpt, 1, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},
                 (size_t)g2.passes * g2.kpass * g2.npad);
+            }
         }
     }
     flush();

@@ -25,7 +25,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ W0, float* __restri
 // fragments straight from global memory (one dwordx4 per lane per 16 channels), B = [u|v] staged once per workgroup
 // in LDS (column tile 0 = the 9 a-logits, tile 1 = the 9 g-logits).  Streams x exactly once: HBM-bound.
 // ---------------------------------------------------------------------------------------------
-template <bool VEC4>
+// BF: x0 / x1 are bf16 tensors (FGC_CONV_BF16), widened on load; the table stays fp32
+template <bool VEC4, bool BF = false>
 __global__ __launch_bounds__(256) void proj_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                         int c0, int c1, int rows, const float* __restrict__ u,
                                                         const float* __restrict__ c, const float* __restrict__ v,
@@ -52,7 +53,12 @@ __global__ __launch_bounds__(256) void proj_mfma_kernel(const float* __restrict_
         for (int kb = 0; kb < kpad; kb += 16) {
             const int cb = kb + 4 * lq;
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            if (VEC4) {
+            if (BF) {
+                const unsigned short* h0 = reinterpret_cast<const unsigned short*>(x0);
+                const unsigned short* h1 = reinterpret_cast<const unsigned short*>(x1);
+                if (cb < c0) a = bf4_to_f4(*reinterpret_cast<const u32x2*>(h0 + (size_t)row * c0 + cb));
+                else if (cb < cin) a = bf4_to_f4(*reinterpret_cast<const u32x2*>(h1 + (size_t)row * c1 + (cb - c0)));
+            } else if (VEC4) {
                 if (cb < c0) a = *reinterpret_cast<const f32x4*>(x0 + (size_t)row * c0 + cb);
                 else if (cb < cin) a = *reinterpret_cast<const f32x4*>(x1 + (size_t)row * c1 + (cb - c0));
             } else {
@@ -272,7 +278,19 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
                   "fgc_conv_fwd: n_tiles=%d outside [0, %d]", d->n_tiles, cdiv(d->n, TILE));
 
     const bool narrow = narrow_supported(d);   // cin <= 8: vector-ALU kernel, no packed operand (fgc_conv_narrow.hip)
-    if (!narrow && !(d->flags & FGC_CONV_PACKED)) {
+    const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
+    FGC_CHECK_ARG(!bf16 || narrow || (conv_vec4_ok(d) && cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) && d->cout % 32 == 0),
+                  "fgc_conv_fwd: FGC_CONV_BF16 needs widths that are multiples of 32 and 16-byte aligned tensors (c0=%d c1=%d "
+                  "cout=%d)", d->c0, d->c1, d->cout);
+    if (!narrow && !(d->flags & FGC_CONV_PACKED) && bf16) {
+        PackJobs J;
+        J.njobs = 1;
+        const size_t tot = (size_t)g.passes * 9 * (g.npad >> 4) * 512;
+        J.job[0] = PackJob{d->W0, Wp, 4, cin, d->cout, cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0, 0};
+        J.nblocks = cdiv((int)tot, 1024);
+        FGC_LAUNCH("pack_many_kernel", st, pack_many_kernel, dim3(J.nblocks), dim3(256), 0, J);
+        FGC_CHECK_LAUNCH("fgc_conv_fwd/pack");
+    } else if (!narrow && !(d->flags & FGC_CONV_PACKED)) {
         const size_t tot = packed_floats(g);
         FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot, 256 * 4)), dim3(256), 0, d->W0, Wp, cin,
                    d->cout, cin, d->cout, g.npad, g.kc, g.kpass, g.passes, 0);
@@ -280,10 +298,16 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     }
     if (prows > 0) {
         const int pg = std::min(cdiv(cdiv(prows, 16), 4), 1024);
-        const float* px0 = d->x0 + (size_t)prow0 * d->c0;
-        const float* px1 = d->x1 ? d->x1 + (size_t)prow0 * d->c1 : nullptr;
+        const bool xbf = bf16 && !narrow;        // (a narrow first layer reads its fp32 input)
+        const size_t esz = xbf ? 2 : 4;
+        const float* px0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->x0) + (size_t)prow0 * d->c0 * esz);
+        const float* px1 = d->x1 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->x1) + (size_t)prow0 * d->c1 * esz)
+                                 : nullptr;
         float* pag = ag + (size_t)prow0 * FGC_AG_LD;
-        if (conv_vec4_ok(d))
+        if (xbf)
+            FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true, true>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
+                       prows, d->u, d->c, d->v, pag);
+        else if (conv_vec4_ok(d))
             FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
                        prows, d->u, d->c, d->v, pag);
         else
@@ -292,7 +316,8 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
         FGC_CHECK_LAUNCH("fgc_conv_fwd/proj");
     }
     if (d->tile_list && d->n_tiles == 0) return FGC_OK;
-    if (narrow) return launch_narrow_fwd(d, ag, y, y_pool, (d->flags & FGC_CONV_SAVE_Z) ? (float*)workspace : nullptr, st);
+    if (narrow)
+        return launch_narrow_fwd(d, ag, y, y_pool, (d->flags & FGC_CONV_SAVE_Z) ? (float*)workspace : nullptr, st, bf16);
 
     CoreParams p;
     fill_core_params(p, g, d->n, d->rowptr, d->col, nullptr, d->x0, d->x1, d->c0, d->c1, d->shift, d->cout, ag,
@@ -302,6 +327,11 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FwdEpilogue ep{d->b, d->bias_mask, d->act, d->alpha, y, y_pool};
     const size_t smem = conv_smem_bytes(g, 0);
     const bool vec4 = conv_vec4_ok(d);
+    if (bf16) {
+        FGC_CHECK_ARG(w8_bf16_supported(p, d->max_deg), "fgc_conv_fwd: FGC_CONV_BF16: unsupported shape (cin=%d cout=%d "
+                      "max_deg=%d)", cin, d->cout, d->max_deg);
+        return launch_fwd_w8(p, ep, smem, d->max_deg, st, true);
+    }
     if (g.lpn == 8 && w8_supported(p, d->max_deg)) return launch_fwd_w8(p, ep, smem, d->max_deg, st);
     return launch_fwd<8>(p, ep, vec4, smem, st);
 }

@@ -7,7 +7,9 @@ namespace fgc {
 bool narrow_supported(const fgc_conv_desc* d);
 // forward (after the logit table `ag` has been computed); honours d->tile_list
 // zsave (may be NULL): [n, narrow_zld(cin)] receives the aggregates for the backward pass (FGC_CONV_SAVE_Z)
-int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, float* zsave, hipStream_t st);
+// out_bf16: y and y_pool are bf16 tensors (FGC_CONV_BF16); the input x0 and everything else stay fp32
+int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, float* zsave, hipStream_t st,
+                      bool out_bf16 = false);
 
 // backward of a narrow FIRST layer (io->dx0 == NULL).  `scratch` holds narrow_bwd_floats(d) floats and must survive
 // from the stage-2 call to the stage-8 call.

@@ -42,6 +42,7 @@ struct NarrowFwd {
     int zld;
     const int* tile_list;  // 32-row tiles (NULL = all); a workgroup takes 8 consecutive entries
     int n_tiles;
+    int out_bf16;          // y / y_pool are bf16 tensors
 };
 
 __device__ __forceinline__ int narrow_node(const int* tile_list, int n_tiles, int n, int& active) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
         const int row0 = (p.tile_list ? p.tile_list[t] : t) * TILE;
         for (int k = threadIdx.x; k < TILE * p.cout; k += NB) {
             const int r = k / p.cout, o = k % p.cout;
-            if (row0 + r < p.n) p.y[(size_t)(row0 + r) * p.cout + o] = yt[(tl * TILE + r) * ys + o];
+            if (row0 + r < p.n) st_act(p.y, (size_t)(row0 + r) * p.cout + o, yt[(tl * TILE + r) * ys + o], p.out_bf16);
         }
         if (p.y_pool) {
             for (int k = threadIdx.x; k < (TILE / 4) * p.cout; k += NB) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_kernel(NarrowFwd p) {
                         any = true;
                     }
                 }
-                if (any) p.y_pool[(size_t)((row0 >> 2) + pr) * p.cout + o] = mx;
+                if (any) st_act(p.y_pool, (size_t)((row0 >> 2) + pr) * p.cout + o, mx, p.out_bf16);
             }
         }
     }
@@ -330,10 +331,10 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_mma_kernel(NarrowFwd p) {
                 float val = acc[ot][t] * (dd[t] > 0 ? 1.0f / (float)dd[t] : 0.f);
                 if (!p.bias_mask || dd[t] > 0) val += bias_o[ot];
                 if (p.act) val = fmaxf(val, 0.f) - p.alpha * fmaxf(-val, 0.f);
-                p.y[(size_t)nd[t] * COUT + o] = val;
+                st_act(p.y, (size_t)nd[t] * COUT + o, val, p.out_bf16);
                 mx = fmaxf(mx, val);
             }
-            if (p.y_pool && nd[0] >= 0) p.y_pool[(size_t)(nd[0] >> 2) * COUT + o] = mx;
+            if (p.y_pool && nd[0] >= 0) st_act(p.y_pool, (size_t)(nd[0] >> 2) * COUT + o, mx, p.out_bf16);
         }
     }
 }
@@ -566,9 +567,10 @@ static int launch_narrow_fwd_mma_t(const NarrowFwd& p, hipStream_t st) {
     return FGC_OK;
 }
 
-int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, float* zsave, hipStream_t st) {
+int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* y_pool, float* zsave, hipStream_t st,
+                      bool out_bf16) {
     NarrowFwd p{d->n,    d->rowptr,    d->col, d->x0,   ag, d->W0, d->b, d->c0, d->cout, d->bias_mask, d->act,
-                d->alpha, y, y_pool, zsave, narrow_zld(d->c0), d->tile_list, d->n_tiles};
+                d->alpha, y, y_pool, zsave, narrow_zld(d->c0), d->tile_list, d->n_tiles, out_bf16 ? 1 : 0};
     // the network's first layer (6 -> 32) and its 3-channel sibling: per-node products on the matrix cores
     const bool mma = !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
                      ((uintptr_t)zsave % 16) == 0;

@@ -29,7 +29,9 @@ struct DataEpilogue {
 
 bool w8_supported(const CoreParams& p, int max_deg);
 // max_deg: the largest degree of the gathered graph (<= KMAX); <= 16 selects the 16-slot form of the fast kernel
-int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st);
-int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st);
+// bf16 = FGC_CONV_BF16 storage (needs w8_bf16_supported)
+bool w8_bf16_supported(const CoreParams& p, int max_deg);
+int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
+int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
 
 }  // namespace fgc

@@ -27,16 +27,22 @@ __device__ __forceinline__ f32x2 load_chunk2(const CoreParams& p, int row, int c
 }
 
 // N edge slots of one node: row ids (with q[8]) -> N buffer loads -> N x 9 packed FMAs.  Unconditional.
-template <int N>
+template <int N, bool BF>
 __device__ __forceinline__ void edge_batch(__amdgpu_buffer_rsrc_t rsrc, unsigned rowbytes, unsigned laneoff,
                                            const float* qk, f32x2 (&z)[FGC_M]) {
     f32x2 q89[N], xv[N];
+    unsigned xw[N];
 #pragma unroll
     for (int t = 0; t < N; ++t) q89[t] = *reinterpret_cast<const f32x2*>(qk + t * QLD + 8);   // q[8], row id
 #pragma unroll
     for (int t = 0; t < N; ++t) {
         const unsigned off = __umul24((unsigned)__float_as_int(q89[t][1]), rowbytes) + laneoff;
-        xv[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+        if constexpr (BF) xw[t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);      // two bf16 channels
+        else xv[t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    }
+    if constexpr (BF) {
+#pragma unroll
+        for (int t = 0; t < N; ++t) xv[t] = bf2_to_f2(xw[t]);
     }
 #pragma unroll
     for (int t = 0; t < N; ++t) {
@@ -55,10 +61,14 @@ __device__ __forceinline__ void edge_batch(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // ds_read_b64.  The generic form keeps per-lane degree tests (exec masking) and 64-bit addressing.
 // QS: edge slots per node kept in LDS - 16 when the host knows that no node has more edges (each of the 16 softmax lanes
 // of a node then owns one slot instead of two, and the tile needs 12 KB less LDS), KMAX otherwise
-template <bool DATA, bool FAST, int QS>
+// BF: bf16 storage (FGC_CONV_BF16).  The gathered rows, y / y_pool (forward), r and dx (data gradient) are bf16; the
+// aggregate tile is kept in LDS as bf16 and the tile product runs on v_mfma_f32_16x16x32_bf16 (fp32 accumulators).  The
+// soft assignment, the aggregation FMAs and every epilogue stay fp32.  FAST shapes only.
+template <bool DATA, bool FAST, int QS, bool BF = false>
 __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+    static_assert(!BF || FAST, "the bf16 form exists for the fast shapes only");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, ZSTRIDE, QS);
+    const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS);
     constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
     float* dagt = s.extra;  // DATA: [TILE][24]
     const int tile0 = block_tile0(p);
@@ -181,6 +191,16 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                     *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
                     // da | dg behind the node's r row: [du; dv] = (da | dg)^T x rides in the dW0 GEMM
+                    if constexpr (BF) {
+                        u32x2* rt = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)i * de.rld +
+                                                             (de.rld - 24));
+                        rt[0] = f4_to_bf4(f32x4{da[0], da[1], da[2], da[3]});
+                        rt[1] = f4_to_bf4(f32x4{da[4], da[5], da[6], da[7]});
+                        rt[2] = f4_to_bf4(f32x4{da[8], 0.f, 0.f, 0.f});
+                        rt[3] = f4_to_bf4(f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]});
+                        rt[4] = f4_to_bf4(f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]});
+                        rt[5] = f4_to_bf4(f32x4{dgsum[8], 0.f, 0.f, 0.f});
+                    } else {
                     float* rt = de.r + (size_t)i * de.rld + (de.rld - 24);
                     *reinterpret_cast<f32x4*>(rt) = f32x4{da[0], da[1], da[2], da[3]};
                     *reinterpret_cast<f32x4*>(rt + 4) = f32x4{da[4], da[5], da[6], da[7]};
@@ -188,6 +208,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                     *reinterpret_cast<f32x4*>(rt + 12) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
                     *reinterpret_cast<f32x4*>(rt + 16) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                     *reinterpret_cast<f32x4*>(rt + 20) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
+                    }
                 } else {
 #pragma unroll
                     for (int m = 0; m < 24; ++m) t[m] = 0.f;
@@ -223,20 +244,21 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         if (FAST) {
             const bool first = pass * KC < p.c0;                                   // wave-uniform
             const float* base = first ? p.src0 : p.src1;
-            const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * 4u;
-            const unsigned laneoff = (unsigned)(first ? cbase : cbase - p.c0) * 4u;
+            constexpr unsigned ESZ = BF ? 2u : 4u;                                  // bytes per stored channel
+            const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * ESZ;
+            const unsigned laneoff = (unsigned)(first ? cbase : cbase - p.c0) * ESZ;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
             // whole batches of 8 edge slots, then the remainder rounded up to a pair (its own straight-line code:
             // every row of a batch is requested before the first FMA, and nothing in a batch is conditional)
             int k0 = 0;
-            for (; k0 + 8 <= dwave; k0 += 8) edge_batch<8>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+            for (; k0 + 8 <= dwave; k0 += 8) edge_batch<8, BF>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
             const int rem = dwave - k0;
             if (rem > 4) {
-                if (rem > 6) edge_batch<8>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
-                else edge_batch<6>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+                if (rem > 6) edge_batch<8, BF>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+                else edge_batch<6, BF>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
             } else if (rem > 0) {
-                if (rem > 2) edge_batch<4>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
-                else edge_batch<2>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+                if (rem > 2) edge_batch<4, BF>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
+                else edge_batch<2, BF>(rsrc, rowbytes, laneoff, qb + k0 * QLD, z);
             }
         } else
         for (int k0 = 0; k0 < d; k0 += RB) {
@@ -261,21 +283,60 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         }        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
             const int j = tile0 + node;
             if (j < p.n && cbase < p.cg) {
+                if constexpr (BF) {
+                    unsigned* rr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)j * de.rld + cbase);
+#pragma unroll
+                    for (int m = 0; m < FGC_M; ++m) rr[(m * p.cg) >> 1] = f2_to_bf2(z[m][0], z[m][1]);
+                } else {
                 float* rr = de.r + (size_t)j * de.rld + cbase;
 #pragma unroll
                 for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(rr + m * p.cg) = z[m];
+                }
             }
             if (!want_gemm) continue;
         }
         if (pass > 0) __syncthreads();  // previous pass' MFMA reads of ztile are done
-        {
+        if constexpr (BF) {
+            unsigned* zr = reinterpret_cast<unsigned*>(s.ztile) + (size_t)node * (ZSTRIDE_BF / 2) + cl;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) zr[m * (KC / 2)] = f2_to_bf2(z[m][0], z[m][1]);
+        } else {
             float* zr = s.ztile + (size_t)node * ZSTRIDE + 2 * cl;
 #pragma unroll
             for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(zr + m * KC) = z[m];
         }
         __syncthreads();
         // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
-        {
+        if constexpr (BF) {
+            // nine 32-deep k-steps per pass, split over the wave's k-part; B fragment = 8 bf16 per lane out of the
+            // packed operand [pass][k-step][column tile][lane], A fragment = one ds_read_b128 per row tile
+            constexpr int KS = KPASS / 32;
+            const int ks0 = __builtin_amdgcn_readfirstlane(KS * kpart / kparts);
+            const int ks1 = __builtin_amdgcn_readfirstlane(KS * (kpart + 1) / kparts);
+            const u32x4* Wp16 = reinterpret_cast<const u32x4*>(p.Wp);
+            const char* zb = reinterpret_cast<const char*>(s.ztile);
+            auto loadb = [&](int ks) {
+                const int kk = min(ks, ks1 - 1);
+                return Wp16[((size_t)(pass * KS + kk) * nct + ct) * 64 + lane];
+            };
+            auto mmb = [&](int ks, const u32x4& b) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(zb + (size_t)(r * 16 + lr) * (ZSTRIDE_BF * 2) + ks * 64 + lq * 16);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                    acc[r], 0, 0, 0);
+                }
+            };
+            u32x4 b0 = loadb(ks0), b1 = loadb(ks0 + 1);
+            int ks = ks0;
+            for (; ks + 2 <= ks1; ks += 2) {
+                mmb(ks, b0);
+                b0 = loadb(ks + 2);
+                mmb(ks + 1, b1);
+                b1 = loadb(ks + 3);
+            }
+            if (ks < ks1) mmb(ks, b0);
+        } else {
             const size_t wrow0 = (size_t)pass * (KPASS >> 2);
             auto loadb = [&](int g) {
                 const int gg = min(g, kg1 - 1);
@@ -358,11 +419,11 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 val *= inv;
                 if (!fe.bias_mask || dd > 0) val += bias_o;
                 if (fe.act) val = fmaxf(val, 0.f) - fe.alpha * fmaxf(-val, 0.f);
-                fe.y[(size_t)i * p.nout + o] = val;
+                st_act(fe.y, (size_t)i * p.nout + o, val, BF);
                 mx = fmaxf(mx, val);
                 any = true;
             }
-            if (fe.y_pool && any) fe.y_pool[(size_t)((tile0 >> 2) + pr) * p.nout + o] = mx;
+            if (fe.y_pool && any) st_act(fe.y_pool, (size_t)((tile0 >> 2) + pr) * p.nout + o, mx, BF);
         }
     } else {
         const int group = 1 << de.shiftf;
@@ -396,11 +457,11 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             if (!any) continue;
             const size_t srow = (size_t)((tile0 >> de.shiftf) + sr);
             if (c < de.c0f) {
-                float* o = de.dx0 + srow * de.c0f + c;
-                *o = de.acc0 ? *o + val : val;
+                const size_t o = srow * de.c0f + c;
+                st_act(de.dx0, o, de.acc0 ? ld_act(de.dx0, o, BF) + val : val, BF);
             } else if (de.dx1) {
-                float* o = de.dx1 + srow * de.c1f + (c - de.c0f);
-                *o = de.acc1 ? *o + val : val;
+                const size_t o = srow * de.c1f + (c - de.c0f);
+                st_act(de.dx1, o, de.acc1 ? ld_act(de.dx1, o, BF) + val : val, BF);
             }
         }
     }
@@ -422,36 +483,46 @@ static bool w8_fast(const CoreParams& p) {
     return p.cg % 32 == 0 && (p.c1 == 0 || p.c0 % 32 == 0) && (size_t)p.n * 4 * 128 < 0xFFFFFFFFull;
 }
 
-template <bool DATA, bool FAST, int QS>
+template <bool DATA, bool FAST, int QS, bool BF = false>
 static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST, QS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST, QS, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr = true;
     }
     smem -= (size_t)TILE * (KMAX - QS) * QLD * 4;     // the caller sized the tile for KMAX slots
-    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS>),
+    if (BF) smem -= (size_t)TILE * (ZSTRIDE * 4 - ZSTRIDE_BF * 2);   // ... and for the fp32 aggregate tile
+    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF>),
                dim3(core_grid(p)), dim3(W8_THREADS), smem, p, fe, de);
     FGC_CHECK_LAUNCH("conv_w8_kernel");
     return FGC_OK;
 }
 
+// bf16 storage: the fast shapes with 32 .. 128 output columns (the out tile that aliases the bf16 aggregate tile fits)
+bool w8_bf16_supported(const CoreParams& p, int max_deg) {
+    const int nct = p.npad >> 4;
+    return w8_supported(p, max_deg) && w8_fast(p) && (nct == 2 || nct == 4 || nct == 8) && p.nout == p.npad;
+}
+
 template <bool DATA>
 static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, int max_deg,
-                     hipStream_t st) {
+                     bool bf16, hipStream_t st) {
+    if (bf16)
+        return max_deg <= 16 ? launch_w8f<DATA, true, 16, true>(p, fe, de, smem, st)
+                             : launch_w8f<DATA, true, KMAX, true>(p, fe, de, smem, st);
     if (!w8_fast(p)) return launch_w8f<DATA, false, KMAX>(p, fe, de, smem, st);
     return max_deg <= 16 ? launch_w8f<DATA, true, 16>(p, fe, de, smem, st)
                          : launch_w8f<DATA, true, KMAX>(p, fe, de, smem, st);
 }
 
-int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st) {
+int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16) {
     DataEpilogue de{};
-    return launch_w8<false>(p, ep, de, smem, max_deg, st);
+    return launch_w8<false>(p, ep, de, smem, max_deg, bf16, st);
 }
-int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st) {
+int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16) {
     FwdEpilogue fe{};
-    return launch_w8<true>(p, fe, ep, smem, max_deg, st);
+    return launch_w8<true>(p, fe, ep, smem, max_deg, bf16, st);
 }
 
 }  // namespace fgc

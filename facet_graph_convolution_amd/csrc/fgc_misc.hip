@@ -37,22 +37,28 @@ __global__ void pool4_fwd_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 // tf.reduce_max gradient: dy split evenly over the entries equal to the max
+// bf16: all four tensors are bf16 (FGC_CONV_BF16 storage; rounding is monotone, so the stored maximum still equals the
+// stored entries it came from)
 __global__ void pool4_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                  const float* __restrict__ dy, float* __restrict__ dx, int64_t count, int c,
-                                 int accumulate) {
+                                 int accumulate, int bf16) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c;
         const int col = (int)(i % c);
-        const float m = y[i];
-        const float* p = x + (r * 4) * c + col;
-        float* q = dx + (r * 4) * c + col;
-        const float e0 = p[0] == m ? 1.f : 0.f, e1 = p[c] == m ? 1.f : 0.f, e2 = p[2 * c] == m ? 1.f : 0.f,
-                    e3 = p[3 * c] == m ? 1.f : 0.f;
-        const float g = dy[i] / (e0 + e1 + e2 + e3);
-        if (accumulate) {
-            q[0] += e0 * g; q[c] += e1 * g; q[2 * c] += e2 * g; q[3 * c] += e3 * g;
-        } else {
-            q[0] = e0 * g; q[c] = e1 * g; q[2 * c] = e2 * g; q[3 * c] = e3 * g;
+        const float m = ld_act(y, i, bf16);
+        const size_t b = (size_t)(r * 4) * c + col;
+        float e[4];
+        float ne = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e[k] = ld_act(x, b + (size_t)k * c, bf16) == m ? 1.f : 0.f;
+            ne += e[k];
+        }
+        const float g = ld_act(dy, i, bf16) / ne;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t o = b + (size_t)k * c;
+            st_act(dx, o, accumulate ? ld_act(dx, o, bf16) + e[k] * g : e[k] * g, bf16);
         }
     }
 }
@@ -343,8 +349,17 @@ extern "C" int fgc_pool4_bwd(const float* x, const float* y, const float* dy, fl
                              int32_t accumulate, void* stream) {
     FGC_CHECK_ARG(x && y && dy && dx && n_out > 0 && c > 0, "fgc_pool4_bwd: bad arguments");
     const int64_t cnt = (int64_t)n_out * c;
-    FGC_LAUNCH("pool4_bwd_kernel", ST, pool4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, dy, dx, cnt, c, accumulate);
+    FGC_LAUNCH("pool4_bwd_kernel", ST, pool4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, dy, dx, cnt, c, accumulate, 0);
     FGC_CHECK_LAUNCH("fgc_pool4_bwd");
+    return FGC_OK;
+}
+extern "C" int fgc_pool4_bwd_bf16(const void* x, const void* y, const void* dy, void* dx, int32_t n_out, int32_t c,
+                                  int32_t accumulate, void* stream) {
+    FGC_CHECK_ARG(x && y && dy && dx && n_out > 0 && c > 0, "fgc_pool4_bwd_bf16: bad arguments");
+    const int64_t cnt = (int64_t)n_out * c;
+    FGC_LAUNCH("pool4_bwd_kernel", ST, pool4_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, (const float*)x, (const float*)y,
+               (const float*)dy, (float*)dx, cnt, c, accumulate, 1);
+    FGC_CHECK_LAUNCH("fgc_pool4_bwd_bf16");
     return FGC_OK;
 }
 extern "C" int fgc_upsample4_fwd(const float* x, float* y, int32_t n_in, int32_t c, void* stream) {

@@ -1,0 +1,595 @@
+// Per-facet MLP cin -> hidden -> cout with bf16-STORED activations (FGC_CONV_BF16 companion of fgc_mlp.hip; the
+// reference is fp32 only: /root/reference/Code/model.py:763-769,937-941, train.py:409-427).
+//
+// x (and dx in backward) are bf16 tensors; W1, b1, W2, b2 and every gradient of them stay fp32 (master weights).  The
+// matrix products with the 1024-wide hidden layer run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; bias, leaky
+// ReLU, the 1024 -> 3 layer and every sum over nodes stay fp32 on the vector ALU / in the accumulators.  The hidden
+// activation is never stored (recomputed in backward), exactly as in the fp32 kernels.
+//
+// Fragment layouts of v_mfma_f32_16x16x32_bf16 (MI355X guide): lane l = (lr = l & 15, lq = l >> 4) holds
+//   A[row lr][k = 8*lq + j],  B[k = 8*lq + j][col lr],  j = 0..7  (16 bytes each);  C/D: col = lr, row = 4*lq + reg.
+#include <algorithm>
+
+#include "fgc_reduce.h"
+
+namespace fgc {
+
+constexpr int MB_THREADS = 256;
+constexpr int MB_FWD_T = 64;       // rows per forward tile (as fgc_mlp.hip: fgc_mlp_num_partials counts these)
+constexpr int MB_FWD_RT = MB_FWD_T / 16;
+constexpr int MB_T = 32;           // rows per backward tile
+constexpr int MB_RT = MB_T / 16;
+
+// W1 [cin, hidden] fp32 -> B fragments [k-step][column tile][lane][8] bf16 (k = input channel, 32 per step)
+__global__ void mlp_pack_bf16_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
+    const int nct = hidden >> 4;
+    const size_t total = (size_t)(cin >> 5) * nct * 512;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int ct = rest % nct, ks = (int)(rest / nct);
+        const int c = ks * 32 + 8 * (lane >> 4) + j;
+        Wp[idx] = f_to_bf(W1[(size_t)c * hidden + ct * 16 + (lane & 15)]);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t count4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<u32x2*>(dst)[i] = f4_to_bf4(reinterpret_cast<const f32x4*>(src)[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  A workgroup = 64 rows; wave w computes the hidden column tiles w, w+4, ... for all four 16-row tiles and folds
+// them into the second layer on the spot.  The x fragments (16 bytes per lane, k-step and row tile) come straight from
+// global memory once and stay in registers.  KS = cin / 32.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int CO>
+__global__ __launch_bounds__(MB_THREADS, 4) void mlp_fwd_bf16_kernel(const unsigned short* __restrict__ x, int n, int hidden,
+                                                                     int cout, const u32x4* __restrict__ Wp16,
+                                                                     const float* __restrict__ b1,
+                                                                     const float* __restrict__ W2,
+                                                                     const float* __restrict__ b2, float alpha,
+                                                                     float* __restrict__ y, float* __restrict__ abs_partial) {
+    __shared__ float ypart[4 * MB_FWD_T * 4];
+    __shared__ float red[4];
+    constexpr int CIN = KS * 32;
+    const int row0 = blockIdx.x * MB_FWD_T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int nct = hidden >> 4;
+    u32x4 a[MB_FWD_RT][KS];
+#pragma unroll
+    for (int r = 0; r < MB_FWD_RT; ++r) {
+        const int row = min(row0 + r * 16 + lr, n - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            a[r][ks] = *reinterpret_cast<const u32x4*>(x + (size_t)row * CIN + ks * 32 + 8 * lq);
+    }
+    float yp[MB_FWD_RT][4][CO];
+#pragma unroll
+    for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) yp[r][t][o] = 0.f;
+
+    u32x4 bnext[KS];
+    float bbn = 0.f, w2n[CO];
+    auto fetch_weights = [&](int ct) {   // (clamped: always a valid load)
+        ct = min(ct, nct - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bnext[ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
+        bbn = b1[ct * 16 + lr];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) w2n[o] = W2[(size_t)(ct * 16 + lr) * cout + min(o, cout - 1)];
+    };
+    fetch_weights(wave);
+    for (int ct = wave; ct < nct; ct += 4) {
+        u32x4 bcur[KS];
+        float w2[CO];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
+        const float bb = bbn;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) w2[o] = o < cout ? w2n[o] : 0.f;
+        fetch_weights(ct + 4);
+        f32x4 h[MB_FWD_RT];
+#pragma unroll
+        for (int r = 0; r < MB_FWD_RT; ++r) h[r] = f32x4{bb, bb, bb, bb};   // the bias rides in the accumulator
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int r = 0; r < MB_FWD_RT; ++r)
+                h[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[r][ks]),
+                                                              __builtin_bit_cast(bf16x8, bcur[ks]), h[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = h[r][t];
+                v = fmaxf(v, 0.f) - alpha * fmaxf(-v, 0.f);
+#pragma unroll
+                for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
+            }
+    }
+    // reduce over the 16 column lanes, then over the four waves (fixed order)
+#pragma unroll
+    for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                float v = yp[r][t][o];
+                FGC_ROW16_SUM(v);
+                yp[r][t][o] = v;
+            }
+    if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int o = 0; o < CO; ++o) ypart[(wave * MB_FWD_T + r * 16 + lq * 4 + t) * 4 + o] = yp[r][t][o];
+    }
+    __syncthreads();
+    float asum = 0.f;
+    for (int t = threadIdx.x; t < MB_FWD_T * cout; t += MB_THREADS) {
+        const int r = t / cout, o = t % cout;
+        const int row = row0 + r;
+        if (row < n) {
+            float v = b2[o];
+            v += ypart[(0 * MB_FWD_T + r) * 4 + o];
+            v += ypart[(1 * MB_FWD_T + r) * 4 + o];
+            v += ypart[(2 * MB_FWD_T + r) * 4 + o];
+            v += ypart[(3 * MB_FWD_T + r) * 4 + o];
+            y[(size_t)row * cout + o] = v;
+            asum += fabsf(v);
+        }
+    }
+    if (abs_partial) {
+        for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off);
+        if (lane == 0) red[wave] = asum;
+        __syncthreads();
+        if (threadIdx.x == 0) abs_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward = two kernels, because the two big products want opposite loop orders and the bf16 MFMA makes recomputing
+// the hidden layer nearly free (a fused kernel with the fp32 kernel's structure kept ~200 registers of partial sums
+// alive and spilled; giving the waves of a workgroup the same rows cost three barriers per 32-row tile):
+//   mlp_bwd_dx_bf16_kernel   row major: a wave owns 32 rows and walks ALL hidden columns, 32 at a time:
+//        h = x W1 + b1 (MFMA), dh = (dy W2^T) * lrelu'(h) (vector ALU, fp32), dx += dh W1^T (MFMA; dh through a
+//        wave-private bf16 LDS tile into the A layout).  dx leaves as bf16, complete: no partial slabs.
+//   mlp_bwd_w_bf16_kernel    column major: a wave owns 64 hidden columns (blockIdx.y) and walks its share of the
+//        32-row tiles with dW1 / db1 / dW2 partial sums in registers:
+//        dW1 += x^T dh: K = the 32 rows of the tile, ONE MFMA per (16 input channels, 16 hidden columns); B = dh
+//        straight out of the registers (k order: row tile, then 4*lq + reg), A = x^T out of a wave-private LDS tile
+//        read in that same k order.  One fp32 slab per wave, summed in fixed order by reduce_jobs.
+// No barrier inside either loop: nothing is shared between the waves of a workgroup except read-only weights.
+// MT = cin / 16.
+// ---------------------------------------------------------------------------------------------
+constexpr int MBB_THREADS = 256;
+constexpr int MBB_WAVES = MBB_THREADS / 64;
+constexpr int MBW_HCW = 64;               // hidden columns per wave of the parameter-gradient kernel
+constexpr int MBW_CT = MBW_HCW / 16;
+
+__device__ __forceinline__ void mb_load_rows(const unsigned short* __restrict__ x, const float* __restrict__ dy, int n,
+                                             int cout, int row0, int cin, int lane, u32x4* ax /* [MB_RT][KS] */, int ks_n,
+                                             float* dyw) {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r) {
+        const int row = row0 + r * 16 + lr;
+        for (int ks = 0; ks < ks_n; ++ks) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + (size_t)min(row, n - 1) * cin + ks * 32 + 8 * lq);
+            ax[r * ks_n + ks] = row < n ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // dy rows of the tile into the wave's LDS tile [32][4]: lane l < 32 owns row l
+    const int rr = row0 + (lane & 31);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const float g = dy[(size_t)min(rr, n - 1) * cout + min(o, cout - 1)];
+        v[o] = (rr < n && o < cout) ? g : 0.f;
+    }
+    if (lane < 32) *reinterpret_cast<f32x4*>(dyw + lane * 4) = v;
+}
+
+template <int MT>
+__global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_kernel(
+    const unsigned short* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
+    const u32x4* __restrict__ Wp16, const unsigned short* __restrict__ W1h /* [cin][hidden] bf16 */,
+    const float* __restrict__ b1, const float* __restrict__ W2, float alpha, unsigned short* __restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CIN = MT * 16;
+    constexpr int KS = CIN / 32;
+    constexpr int DHS = 32 * 2 + 32;          // bytes per row (= node) of a wave's dh tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    char* dhw = smem_raw + wave * (MB_T * DHS + MB_T * 16);
+    float* dyw = reinterpret_cast<float*>(dhw + MB_T * DHS);
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(dhw);
+    const int nct = hidden >> 4;
+    const int tile = blockIdx.x * MBB_WAVES + wave;
+    const int row0 = tile * MB_T;
+    if (row0 >= n) return;                    // (whole wave; nothing below is shared between waves)
+    u32x4 ax[MB_RT * KS];
+    mb_load_rows(x, dy, n, cout, row0, CIN, lane, ax, KS, dyw);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    f32x4 dyr[MB_RT][4];
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dyr[r][t] = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lq * 4 + t) * 4);
+    f32x4 dxacc[MB_RT][MT];
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dxacc[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weights of one pair of column tiles (W1 fragments, b1, W2 rows, W1 rows for the dx product): clamped, so that the
+    // pair after the last is a valid (unused) load; fetched one pair ahead
+    struct PairW {
+        u32x4 bw[2][KS];
+        float bb[2];
+        float w2[2][3];
+        u32x4 bt[MT];
+    };
+    auto fetch = [&](int pp, PairW& w) {
+        pp = min(pp, (nct >> 1) - 1);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ct = pp * 2 + c2;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w.bw[c2][ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
+            w.bb[c2] = b1[ct * 16 + lr];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) w.w2[c2][o] = W2[(size_t)(ct * 16 + lr) * cout + min(o, cout - 1)];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            w.bt[m] = *reinterpret_cast<const u32x4*>(W1h + (size_t)(m * 16 + lr) * hidden + pp * 32 + 8 * lq);
+    };
+    auto pair = [&](const PairW& w) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            f32x4 h[MB_RT];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{w.bb[c2], w.bb[c2], w.bb[c2], w.bb[c2]};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int r = 0; r < MB_RT; ++r)
+                    h[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[r * KS + ks]),
+                                                                  __builtin_bit_cast(bf16x8, w.bw[c2][ks]), h[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float pre = h[r][t];
+                    const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
+                    float g = dyr[r][t][0] * w.w2[c2][0];
+                    if (cout > 1) g = fmaf(dyr[r][t][1], w.w2[c2][1], g);
+                    if (cout > 2) g = fmaf(dyr[r][t][2], w.w2[c2][2], g);
+                    d16[((r * 16 + lq * 4 + t) * DHS) / 2 + c2 * 16 + lr] = f_to_bf(g * slope);
+                }
+        }
+        // same wave wrote and reads: LDS ops of one wave are ordered; the compiler inserts the lgkmcnt wait
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        u32x4 ad[MB_RT];
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r) ad[r] = *reinterpret_cast<const u32x4*>(dhw + (r * 16 + lr) * DHS + lq * 16);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+                dxacc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ad[r]),
+                                                                     __builtin_bit_cast(bf16x8, w.bt[m]), dxacc[r][m], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next pair overwrites the dh tile
+    };
+    // cout > 3 (a fourth output column) is folded in by a second sweep below: the network's heads have three
+    PairW wa, wb;
+    const int npairs = nct >> 1;
+    fetch(0, wa);
+#pragma unroll 1
+    for (int pp = 0; pp < npairs; pp += 2) {
+        fetch(pp + 1, wb);
+        pair(wa);
+        fetch(pp + 2, wa);
+        if (pp + 1 < npairs) pair(wb);
+    }
+    // C layout: column = input channel lr of tile m, rows 4*lq + t
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = row0 + r * 16 + lq * 4 + t;
+            if (row < n) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) dx[(size_t)row * CIN + m * 16 + lr] = f_to_bf(dxacc[r][m][t]);
+            }
+        }
+}
+
+template <int MT, int CO>
+__global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
+    const unsigned short* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
+    const u32x4* __restrict__ Wp16, const float* __restrict__ b1, const float* __restrict__ W2, float alpha,
+    float* __restrict__ dW1_slab /* [walkers][cin][hidden] */, float* __restrict__ db1_slab /* [walkers][hidden] */,
+    float* __restrict__ dW2_slab /* [walkers][hidden][4] */, float* __restrict__ db2_slab /* [walkers][4] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CIN = MT * 16;
+    constexpr int KS = CIN / 32;
+    constexpr int XTS = MB_T * 2 + 8;         // bytes per row (= input channel) of a wave's transposed x tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    char* xT = smem_raw + wave * (CIN * XTS + MB_T * 16);
+    float* dyw = reinterpret_cast<float*>(xT + CIN * XTS);
+    unsigned short* xT16 = reinterpret_cast<unsigned short*>(xT);
+    const int hc0 = blockIdx.y * MBW_HCW;
+    const int nct = hidden >> 4;
+    const int ntiles = (n + MB_T - 1) / MB_T;
+    const int walker = blockIdx.x * MBB_WAVES + wave, nwalkers = gridDim.x * MBB_WAVES;
+
+    u32x4 bw[MBW_CT][KS];
+    float bb[MBW_CT], w2[MBW_CT][CO];
+#pragma unroll
+    for (int c = 0; c < MBW_CT; ++c) {
+        const int ct = (hc0 >> 4) + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bw[c][ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
+        bb[c] = b1[ct * 16 + lr];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) w2[c][o] = o < cout ? W2[(size_t)(ct * 16 + lr) * cout + o] : 0.f;
+    }
+    f32x4 dW1acc[MBW_CT][MT];
+    float dW2acc[MBW_CT][CO], db1acc[MBW_CT], db2acc[CO];
+#pragma unroll
+    for (int c = 0; c < MBW_CT; ++c) {
+        db1acc[c] = 0.f;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) dW2acc[c][o] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) db2acc[o] = 0.f;
+
+#pragma unroll 1
+    for (int tile = walker; tile < ntiles; tile += nwalkers) {
+        const int row0 = tile * MB_T;
+        u32x4 ax[MB_RT * KS];
+        mb_load_rows(x, dy, n, cout, row0, CIN, lane, ax, KS, dyw);
+        // x^T of the tile for the dW1 product
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = ks * 32 + 8 * lq + 2 * e;
+                    xT16[(c * XTS) / 2 + r * 16 + lr] = (unsigned short)(ax[r * KS + ks][e] & 0xFFFFu);
+                    xT16[((c + 1) * XTS) / 2 + r * 16 + lr] = (unsigned short)(ax[r * KS + ks][e] >> 16);
+                }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        f32x4 dyr[MB_RT][4];
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dyr[r][t] = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lq * 4 + t) * 4);
+        if (blockIdx.y == 0 && lr == 0) {     // db2 = column sums of dy (hidden slice 0 only): one lane per row
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) db2acc[o] += dyr[r][t][o];
+        }
+        u32x4 af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const char* row = xT + (m * 16 + lr) * XTS;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(row + lq * 8);          // rows 4*lq .. +3
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(row + 32 + lq * 8);     // rows 16 + 4*lq .. +3
+            af[m] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int c = 0; c < MBW_CT; ++c) {
+            __builtin_amdgcn_sched_barrier(0);    // one column tile at a time
+            f32x4 h[MB_RT], dh[MB_RT];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{bb[c], bb[c], bb[c], bb[c]};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int r = 0; r < MB_RT; ++r)
+                    h[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[r * KS + ks]),
+                                                                  __builtin_bit_cast(bf16x8, bw[c][ks]), h[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float pre = h[r][t];
+                    const float hact = pre > 0.f ? pre : alpha * pre;
+                    const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
+                    float g = 0.f;
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        g = fmaf(dyr[r][t][o], w2[c][o], g);
+                        dW2acc[c][o] = fmaf(hact, dyr[r][t][o], dW2acc[c][o]);
+                    }
+                    g *= slope;
+                    dh[r][t] = g;
+                    db1acc[c] += g;
+                }
+            // k = r*16 + 4*lq + t: element j of both fragments is (r = j >> 2, t = j & 3)
+            const u32x4 bf = u32x4{f2_to_bf2(dh[0][0], dh[0][1]), f2_to_bf2(dh[0][2], dh[0][3]), f2_to_bf2(dh[1][0], dh[1][1]),
+                                   f2_to_bf2(dh[1][2], dh[1][3])};
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                dW1acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), __builtin_bit_cast(bf16x8, bf),
+                                                                      dW1acc[c][m], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile overwrites the LDS tiles
+    }
+    // parameter-gradient slabs of this wave (slab index = its walker id)
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float v = db2acc[o];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane == 0) db2_slab[walker * 4 + o] = v;
+        }
+        if (lane == 0)
+            for (int o = CO; o < 4; ++o) db2_slab[walker * 4 + o] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < MBW_CT; ++c) {
+        const int col = hc0 + c * 16 + lr;
+        // dW1acc C layout: column = lr (hidden column), row = 4*lq + t (input channel within tile m)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dW1_slab[((size_t)walker * CIN + m * 16 + lq * 4 + t) * hidden + col] = dW1acc[c][m][t];
+        float v = db1acc[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) db1_slab[(size_t)walker * hidden + col] = v;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float w = dW2acc[c][o];
+            w += __shfl_xor(w, 16);
+            w += __shfl_xor(w, 32);
+            if (lq == 0) dW2_slab[((size_t)walker * hidden + col) * 4 + o] = w;
+        }
+        if (lq == 0)
+            for (int o = CO; o < 4; ++o) dW2_slab[((size_t)walker * hidden + col) * 4 + o] = 0.f;
+    }
+}
+
+}  // namespace fgc
+
+using namespace fgc;
+
+// row walkers (waves) of the parameter-gradient kernel: each keeps its partial sums in registers and writes one slab
+static int mb_gx(int n) {
+    const int ntiles = cdiv(n, MB_T);
+    const int wg = cdiv(ntiles, 4);
+    return (wg < 32 ? wg : 32) * 4;
+}
+
+extern "C" size_t fgc_mlp_bf16_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout) {
+    (void)cout;
+    return align_up((size_t)cin * hidden * 2, 256);
+}
+
+extern "C" size_t fgc_mlp_bwd_bf16_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout) {
+    (void)cout;
+    const size_t gx = mb_gx(n);
+    size_t b = 2 * align_up((size_t)cin * hidden * 2, 256);   // W1 as MFMA fragments and as bf16 rows
+    b += align_up(gx * (size_t)cin * hidden * 4, 256);         // dW1 slabs
+    b += align_up(gx * (size_t)hidden * 4, 256);               // db1 slabs
+    b += align_up(gx * (size_t)hidden * 4 * 4, 256);           // dW2 slabs
+    b += align_up((size_t)1024 * 4 * 4, 256);                  // db2 partials
+    b += align_up((reduce_tmp_floats(1024, 4) + reduce_tmp_floats((int)gx, (size_t)cin * hidden) +
+                   reduce_tmp_floats((int)gx, (size_t)hidden * 5)) * 4 + 256, 256);
+    return b;
+}
+
+static int mlp_bf16_check(const char* who, const void* x, int n, int cin, int hidden, int cout) {
+    FGC_CHECK_ARG(x && n > 0, "%s: null x / n=%d", who, n);
+    FGC_CHECK_ARG(cin == 32 || cin == 64 || cin == 128, "%s: cin=%d (the bf16 MLP takes 32, 64 or 128 input channels)", who, cin);
+    FGC_CHECK_ARG(hidden > 0 && hidden % 256 == 0, "%s: hidden=%d must be a multiple of 256", who, hidden);
+    FGC_CHECK_ARG(cout > 0 && cout <= 4, "%s: cout=%d outside [1,4]", who, cout);
+    FGC_CHECK_ARG((uintptr_t)x % 16 == 0, "%s: x needs 16-byte alignment", who);
+    return FGC_OK;
+}
+
+extern "C" int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
+                                const float* b1, const float* W2, const float* b2, float alpha, float* y,
+                                float* abs_partial, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = mlp_bf16_check("fgc_mlp_fwd_bf16", x, n, cin, hidden, cout);
+    if (rc) return rc;
+    FGC_CHECK_ARG(W1 && b1 && W2 && b2 && y, "fgc_mlp_fwd_bf16: null pointer");
+    FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bf16_workspace_bytes(cin, hidden, cout) && (uintptr_t)workspace % 16 == 0,
+                  "fgc_mlp_fwd_bf16: workspace too small or misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* Wp = (unsigned short*)workspace;
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
+    const unsigned short* x16 = (const unsigned short*)x;
+    const u32x4* Wp16 = (const u32x4*)Wp;
+    const dim3 grid(cdiv(n, MB_FWD_T));
+#define FGC_MB_FWD(KS)                                                                                                      \
+    do {                                                                                                                    \
+        if (cout <= 3)                                                                                                      \
+            FGC_LAUNCH("mlp_fwd_kernel", st, (mlp_fwd_bf16_kernel<KS, 3>), grid, dim3(MB_THREADS), 0, x16, n, hidden, cout, Wp16, \
+                       b1, W2, b2, alpha, y, abs_partial);                                                                  \
+        else                                                                                                                \
+            FGC_LAUNCH("mlp_fwd_kernel", st, (mlp_fwd_bf16_kernel<KS, 4>), grid, dim3(MB_THREADS), 0, x16, n, hidden, cout, Wp16, \
+                       b1, W2, b2, alpha, y, abs_partial);                                                                  \
+    } while (0)
+    if (cin == 32) FGC_MB_FWD(1);
+    else if (cin == 64) FGC_MB_FWD(2);
+    else FGC_MB_FWD(4);
+#undef FGC_MB_FWD
+    FGC_CHECK_LAUNCH("fgc_mlp_fwd_bf16");
+    return FGC_OK;
+}
+
+extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
+                                const float* W1, const float* b1, const float* W2, float alpha, void* dx, float* dW1,
+                                float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    int rc = mlp_bf16_check("fgc_mlp_bwd_bf16", x, n, cin, hidden, cout);
+    if (rc) return rc;
+    FGC_CHECK_ARG(dy && W1 && b1 && W2 && dx && dW1 && db1 && dW2 && db2, "fgc_mlp_bwd_bf16: null pointer");
+    FGC_CHECK_ARG((cin == 32 || cin == 64) && cout <= 3, "fgc_mlp_bwd_bf16: cin=%d cout=%d (cin 32 or 64, cout <= 3)", cin, cout);
+    FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_bf16_workspace_bytes(n, cin, hidden, cout) &&
+                      (uintptr_t)workspace % 16 == 0,
+                  "fgc_mlp_bwd_bf16: workspace too small or misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = mb_gx(n), gy = hidden / MBW_HCW;
+    char* w = (char*)workspace;
+    unsigned short* Wp = (unsigned short*)w;
+    w += align_up((size_t)cin * hidden * 2, 256);
+    unsigned short* W1h = (unsigned short*)w;
+    w += align_up((size_t)cin * hidden * 2, 256);
+    float* dW1_slab = (float*)w;
+    w += align_up((size_t)gx * cin * hidden * 4, 256);
+    float* db1_slab = (float*)w;
+    w += align_up((size_t)gx * hidden * 4, 256);
+    float* dW2_slab = (float*)w;
+    w += align_up((size_t)gx * hidden * 4 * 4, 256);
+    float* db2_part = (float*)w;
+    w += align_up((size_t)1024 * 4 * 4, 256);
+    float* rtmp = (float*)w;
+
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
+    FGC_LAUNCH("mlp_pack_kernel", st, cast_f32_bf16_kernel, dim3(cdiv(cin * hidden / 4, 256)), dim3(256), 0, W1, W1h,
+               (int64_t)cin * hidden / 4);
+    const unsigned short* x16 = (const unsigned short*)x;
+    const u32x4* Wp16 = (const u32x4*)Wp;
+    const int tiles = cdiv(n, MB_T);
+#define FGC_MB_BWD(MT)                                                                                                      \
+    do {                                                                                                                    \
+        constexpr int CIN_ = MT * 16;                                                                                       \
+        const size_t smem_dx = (size_t)MBB_WAVES * (MB_T * 96 + MB_T * 16);                                                 \
+        FGC_LAUNCH("mlp_bwd_kernel<dx>", st, (mlp_bwd_dx_bf16_kernel<MT>), dim3(cdiv(tiles, MBB_WAVES)), dim3(MBB_THREADS),  \
+                   smem_dx, x16, dy, n, hidden, cout, Wp16, W1h, b1, W2, alpha, (unsigned short*)dx);                       \
+        const size_t smem_w = (size_t)MBB_WAVES * ((size_t)CIN_ * (MB_T * 2 + 8) + MB_T * 16);                              \
+        FGC_LAUNCH("mlp_bwd_kernel<w>", st, (mlp_bwd_w_bf16_kernel<MT, 3>), dim3(gx / 4, gy), dim3(MBB_THREADS), smem_w, x16, \
+                   dy, n, hidden, cout, Wp16, b1, W2, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);                       \
+    } while (0)
+    if (cin == 32) FGC_MB_BWD(2);
+    else FGC_MB_BWD(4);
+#undef FGC_MB_BWD
+    FGC_CHECK_LAUNCH("fgc_mlp_bwd_bf16");
+    const RedJob jobs[4] = {
+        {dW1_slab, (size_t)cin * hidden, gx, cin * hidden, hidden, hidden, dW1},
+        {db1_slab, (size_t)hidden, gx, hidden, hidden, hidden, db1},
+        {dW2_slab, (size_t)hidden * 4, gx, hidden * 4, 4, cout, dW2},
+        {db2_part, (size_t)4, gx, 4, 4, cout, db2},
+    };
+    return reduce_jobs("reduce:mlp", jobs, 4, rtmp, st);
+}

@@ -180,8 +180,9 @@ class FacetDenoiser:
         plan / comm (facet sharding, shard.py): x, adjs, gt are still the WHOLE mesh; this rank keeps only its
         shard ([owned rows | halo rows] per level) and exchanges halos through `comm` between the layers."""
         dev = self.device
-        if self.dtype != "f32":
-            raise NotImplementedError("dtype %r: only the fp32 network is built" % self.dtype)
+        bf16 = self.dtype == "bf16"
+        if bf16 and plan is not None:
+            raise NotImplementedError("facet sharding of the bf16-storage network is not built (fp32 shards only)")
         xt = torch.as_tensor(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32))
         xt = xt.reshape(-1, xt.shape[-1]).contiguous()
         if xt.shape[1] != self.in_channels:
@@ -219,9 +220,14 @@ class FacetDenoiser:
         shapes = {"h1": (n0 + nh[0], 32), "p1": (n1 + nh[1], 32), "h2": (n1 + nh[1], 64), "p2": (n2 + nh[2], 64),
                   "h3": (n2 + nh[2], 128), "d3": (n2 + nh[1], 128), "u2": (n1 + nh[1], 64), "d2": (n1 + nh[0], 64),
                   "u1": (n0 + nh[0], 32), "d1": (n0, 32), "y0": (n0, 3), "nconv": (n0, 3)}
+        # dtype "bf16": every activation that crosses a layer boundary (and its gradient) is STORED as bf16; the network
+        # input, the 3-channel outputs, logit tables, per-edge d-logits and all parameters stay fp32 (include/fgc.h:
+        # FGC_CONV_BF16)
+        act = dict(dtype=torch.bfloat16, device=dev) if bf16 else f
         for k, sh in shapes.items():
-            B[k] = torch.zeros(*sh, **f)
-            B["g_" + k] = torch.zeros(*sh, **f)   # gradient twin
+            kw = f if k in ("y0", "nconv") else act
+            B[k] = torch.zeros(*sh, **kw)
+            B["g_" + k] = torch.zeros(*sh, **kw)   # gradient twin
         for lay in self.layers:
             B["ag_" + lay.name] = torch.empty(B[lay.x0].shape[0], AG_LD, **f)
         if self.multi_scale:
@@ -269,6 +275,8 @@ class FacetDenoiser:
             d.max_deg = g.max_deg
             # a narrow first layer leaves its aggregates in the forward workspace for the backward pass (training only)
             d.flags = _lib.CONV_SAVE_Z if (gt is not None and lay.name == "conv1" and self.save_z) else 0
+            if bf16:
+                d.flags |= _lib.CONV_BF16
             layer_flags[lay.name] = d.flags
             descs[lay.name] = d
             wsf[lay.name] = torch.empty(self.L.fgc_conv_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
@@ -295,12 +303,15 @@ class FacetDenoiser:
             io.accumulate0, io.accumulate1 = 0, 0
         ios["conv1"].dx0 = None
         ios["conv1"].dx1 = None
-        if layer_flags["conv1"] and not self.L.fgc_conv_bwd_needs_exchange(C.byref(descs["conv1"]), C.byref(ios["conv1"])):
+        if (layer_flags["conv1"] & _lib.CONV_SAVE_Z) and not self.L.fgc_conv_bwd_needs_exchange(
+                C.byref(descs["conv1"]), C.byref(ios["conv1"])):
             ios["conv1"].z_saved = wsf["conv1"].data_ptr()      # (the library took the narrow path: see FGC_CONV_SAVE_Z)
         else:
-            layer_flags["conv1"] = descs["conv1"].flags = 0
+            layer_flags["conv1"] = descs["conv1"].flags = layer_flags["conv1"] & ~_lib.CONV_SAVE_Z
         ws_f = max(ws_f, self.L.fgc_mlp_workspace_bytes(128, HIDDEN, 3))
         ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n0, 32, HIDDEN, 3))
+        if bf16:
+            ws_b = max(ws_b, self.L.fgc_mlp_bwd_bf16_workspace_bytes(n0, 32, HIDDEN, 3))
         B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)     # the MLP heads
         for k, t in wsf.items():
             B["wsf_" + k] = t
@@ -349,6 +360,19 @@ class FacetDenoiser:
     # ------------------------------------------------------------------------------------------
     def _st(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # entry points that differ between the fp32 and the bf16-storage network
+    @property
+    def _mlp_fwd(self):
+        return self.L.fgc_mlp_fwd_bf16 if self.dtype == "bf16" else self.L.fgc_mlp_fwd
+
+    @property
+    def _mlp_bwd(self):
+        return self.L.fgc_mlp_bwd_bf16 if self.dtype == "bf16" else self.L.fgc_mlp_bwd
+
+    @property
+    def _pool4_bwd(self):
+        return self.L.fgc_pool4_bwd_bf16 if self.dtype == "bf16" else self.L.fgc_pool4_bwd
 
     def _tag(self, name):
         if self.profile:
@@ -425,12 +449,12 @@ class FacetDenoiser:
                 W1, b1, W2, b2 = vals[self.slot[head]:self.slot[head] + 4]
                 xin = B[lay.y]
                 nrows = M["ns"][lay.level]
-                _lib.check(L.fgc_mlp_fwd(_p(xin), nrows, xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
+                _lib.check(self._mlp_fwd(_p(xin), nrows, xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
                                          _p(b2), LRELU_ALPHA, _p(B[out]), _p(B["abs_part" + out[1]]), _p(ws),
                                          ws.numel(), st), head)
         self._tag("fwd:mlp")
         W1, b1, W2, b2 = vals[self.slot["head0"]:self.slot["head0"] + 4]
-        _lib.check(L.fgc_mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
+        _lib.check(self._mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
                                  _p(B["y0"]), _p(B["abs_part"]), _p(ws), ws.numel(), st), "head0")
         self._tag("fwd:normalize")
         if not self.sharded:
@@ -485,16 +509,16 @@ class FacetDenoiser:
         vals, grads = self.params.values, self.params.grads
         s = self.slot["head0"]
         self._tag("bwd:mlp")
-        _lib.check(L.fgc_mlp_bwd(_p(B["d1"]), _p(B["g_y0"]), n0, 32, HIDDEN, 3, _p(vals[s]), _p(vals[s + 1]),
+        _lib.check(self._mlp_bwd(_p(B["d1"]), _p(B["g_y0"]), n0, 32, HIDDEN, 3, _p(vals[s]), _p(vals[s + 1]),
                                  _p(vals[s + 2]), LRELU_ALPHA, _p(B["g_d1"]), _p(grads[s]), _p(grads[s + 1]),
                                  _p(grads[s + 2]), _p(grads[s + 3]), _p(ws), ws.numel(), st), "head0 bwd")
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
             self._tag("bwd:" + name)
             if name == "conv2":   # g_h2 += d pool2
-                _lib.check(L.fgc_pool4_bwd(_p(B["h2"]), _p(B["p2"]), _p(B["g_p2"]), _p(B["g_h2"]), ns[2], 64, 1, st),
+                _lib.check(self._pool4_bwd(_p(B["h2"]), _p(B["p2"]), _p(B["g_p2"]), _p(B["g_h2"]), ns[2], 64, 1, st),
                            "pool2 bwd")
             if name == "conv1":   # g_h1 += d pool1
-                _lib.check(L.fgc_pool4_bwd(_p(B["h1"]), _p(B["p1"]), _p(B["g_p1"]), _p(B["g_h1"]), ns[1], 32, 1, st),
+                _lib.check(self._pool4_bwd(_p(B["h1"]), _p(B["p1"]), _p(B["g_p1"]), _p(B["g_h1"]), ns[1], 32, 1, st),
                            "pool1 bwd")
             d, io = M["descs"][name], M["ios"][name]
             lws = B["wsb_" + name]

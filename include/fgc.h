@@ -194,6 +194,17 @@ typedef struct fgc_conv_desc {
                                   * fgc_conv_workspace_bytes when the flag is set) so that the backward pass, given
                                   * fgc_conv_bwd_io.z_saved, does not recompute them for the weight gradient */
 
+#define FGC_CONV_BF16 8           /* fgc_conv_desc.flags: bf16 STORAGE / fp32 accumulate (a build extension: the reference is
+                                  * fp32 only, train.py:409-427).  x0, x1, y, y_pool and, in fgc_conv_bwd, dy, ds, r, dx0 and
+                                  * dx1 point to bf16 (uint16_t) tensors of the same shapes; the gathers move half the
+                                  * bytes and the dense contractions run on v_mfma_f32_16x16x32_bf16 with fp32
+                                  * accumulation.  Logit tables (ag, dag), per-edge d-logits (dl), parameters and
+                                  * parameter gradients stay fp32; the weight-gradient reduction over nodes multiplies the
+                                  * bf16-stored operands on the fp32 MFMA (exact products, fp32 sums).  Supported for the
+                                  * shapes of the network (widths that are multiples of 32, degrees <= 24); a narrow first
+                                  * layer (cin <= 8) keeps its fp32 input x0 and ds, and stores y / y_pool as bf16.
+                                  * Same flag in fgc_conv_bwd_io.flags is not needed: the descriptor's flag rules. */
+
 /* bytes of scratch the conv entry points need for this descriptor (packed weights) */
 size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d);
 
@@ -287,6 +298,19 @@ int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t cin, int32_t
                 const float* W1, const float* b1, const float* W2, float alpha, float* dx, float* dW1,
                 float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same MLP with bf16-STORED activations (companion of FGC_CONV_BF16; a build extension, the reference is fp32 only:
+ * train.py:409-427).  x [n, cin] and dx [n, cin] are bf16 (uint16_t) tensors, cin in {32, 64, 128} (backward: 32, 64),
+ * hidden a multiple of 256; parameters, their gradients, y and dy stay fp32.  The products with the hidden layer run on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation, everything else in fp32. */
+size_t fgc_mlp_bf16_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout);
+size_t fgc_mlp_bwd_bf16_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout);
+int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
+                     const float* b1, const float* W2, const float* b2, float alpha, float* y, float* abs_partial,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
+                     const float* W1, const float* b1, const float* W2, float alpha, void* dx, float* dW1, float* db1,
+                     float* dW2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Element-wise / reduction ops
  * ---------------------------------------------------------------------------------- */
@@ -298,6 +322,9 @@ int fgc_pool4_fwd(const float* x, float* y, int32_t n_out, int32_t c, void* stre
 /* gradient of max pooling, split evenly over ties (tf.reduce_max semantics).  accumulate: dx += */
 int fgc_pool4_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t n_out, int32_t c,
                   int32_t accumulate, void* stream);
+/* the same on bf16 tensors (all four; FGC_CONV_BF16 storage) */
+int fgc_pool4_bwd_bf16(const void* x, const void* y, const void* dy, void* dx, int32_t n_out, int32_t c,
+                       int32_t accumulate, void* stream);
 /* 1:4 upsampling by repetition (model.py:817-825) and its gradient (sum of 4 rows) */
 int fgc_upsample4_fwd(const float* x, float* y, int32_t n_in, int32_t c, void* stream);
 int fgc_upsample4_bwd(const float* dy, float* dx, int32_t n_in, int32_t c, int32_t accumulate, void* stream);
