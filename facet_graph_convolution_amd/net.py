@@ -69,7 +69,10 @@ class FlatParams:
         self.total = off
         self.device = torch.device(device)
         self.theta = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros_like(self.theta)
+        # the gradient buffer has a 4-float tail: a facet-sharded step puts its loss sum there, so that one all-reduce
+        # carries the gradient and the loss
+        self.grad_ext = torch.zeros(off + 4, dtype=torch.float32, device=self.device)
+        self.grad = self.grad_ext[:off]
         self.m = torch.zeros_like(self.theta)
         self.v = torch.zeros_like(self.theta)
         self.step = 0
@@ -135,6 +138,9 @@ class FacetDenoiser:
         # facet-sharded runs: compute the interior tiles of a layer while its halo rows travel (FGC_NO_OVERLAP=1: the
         # whole layer after a blocking exchange, for A/B timing)
         self.overlap = os.environ.get("FGC_NO_OVERLAP", "0") != "1"
+        # ... only where the interior is big enough to hide an exchange and to fill the GPU on its own: a layer of a
+        # coarse level has a few hundred tiles in all, splitting it costs more than the exchange it would cover
+        self.split_min_tiles = int(os.environ.get("FGC_SPLIT_MIN_TILES", "1024"))
         # one launch packs the weight operands of all layers, one pair sums all parameter gradients (each small launch
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
@@ -205,7 +211,11 @@ class FacetDenoiser:
             n_total = list(plan.n_total)
             own_lo = plan.levels[0].lo
             xt = xt[torch.from_numpy(plan.local_rows(0))]
+            real_flag = None
             if gtt is not None:
+                # which rows of the WHOLE mesh count in the loss (train.py:1283-1292): every rank can then count the
+                # real rows among a step's samples without asking the others
+                real_flag = (gtt.abs().sum(1) > 1e-3).to(torch.float32)
                 gtt = gtt[plan.levels[0].lo:plan.levels[0].hi]
         n0, n1, n2 = (g.n for g in graphs)
         if n0 != 4 * n1 or n1 != 4 * n2 or xt.shape[0] != n0 + nh[0]:
@@ -252,6 +262,8 @@ class FacetDenoiser:
         if gtt is not None:
             B["gt"] = gtt.contiguous().to(dev)
             B["gtr"] = torch.empty_like(B["gt"])
+            if plan is not None:
+                B["real_flag"] = real_flag.to(dev)
         # descriptors + workspace
         vals, grads = self.params.values, self.params.grads
         descs, ios, ws_f, ws_b = {}, {}, 0, 0
@@ -352,11 +364,14 @@ class FacetDenoiser:
     # ------------------------------------------------------------------------------------------
     # enqueue helpers (no allocation, no sync).  The schedules are GENERATORS: they yield an exchange request
     # wherever a facet-sharded run must talk to its peers; an unsharded run just drains them.
-    #   ("rows", level, tensor, parent)                    halo rows of `tensor` (parent: rows of the coarse parents)
-    #   ("rows_begin", level, tensor, parent, key) ... ("wait", key)   the same, split so that the kernels enqueued
-    #   ("edges_begin", level, key)                ... ("wait", key)   in between run while the rows travel
-    #   ("edges", level)                                   d-logits of incoming cross-shard edges
-    #   ("sum", tensor)                                    all-reduce
+    #   ("xchg", items, key)     ONE grouped exchange with every peer; items:
+    #        ("rows", level, tensor, parent)   halo rows of `tensor` (parent: rows of the coarse parents)
+    #        ("edges", level)                  d-logits of incoming cross-shard edges
+    #      key None: blocking.  Otherwise the kernels enqueued up to the matching ("wait", key) run while it travels
+    #   ("sum", tensor)          all-reduce
+    # Per step: 7 exchanges forward (everything a layer produces that a peer gathers goes out in one message right
+    # behind it: conv1 -> {h1, p1}, conv2 -> {h2, p2}), 7 backward (a layer's s rows and cross-edge d-logits together),
+    # two scalar all-reduces for normalizeTensor and its gradient, one all-reduce of gradient + loss sum: 17.
     # ------------------------------------------------------------------------------------------
     def _st(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -394,12 +409,15 @@ class FacetDenoiser:
         else:
             B["xr"].copy_(B["x"])
         vals = self.params.values
-        halo_before = {"conv2": [("p1", 1, False)], "conv3": [("p2", 2, False)], "dconv3": [("h3", 2, False)],
-                       "upconv2": [("d3", 1, True)], "dconv2": [("u2", 1, False)],
-                       "upconv1": [("d2", 0, True)], "dconv1": [("u1", 0, False)]}
-        # the skip connections are consumed six / two layers later: their halos travel under the layers in between
-        early = {"conv1": ("h1", 0, "dconv1"), "conv2": ("h2", 1, "dconv2")}
-        wait_before = {v[2]: v[0] for v in early.values()}
+        # what a layer's output feeds on OTHER ranks: sent in one grouped exchange right behind the layer; the consumer
+        # waits for it between its interior and its boundary tiles
+        send_after = {"conv1": [("rows", 0, "h1", False), ("rows", 1, "p1", False)],
+                      "conv2": [("rows", 1, "h2", False), ("rows", 2, "p2", False)],
+                      "conv3": [("rows", 2, "h3", False)], "dconv3": [("rows", 1, "d3", True)],
+                      "upconv2": [("rows", 1, "u2", False)], "dconv2": [("rows", 0, "d2", True)],
+                      "upconv1": [("rows", 0, "u1", False)]}
+        wait_before = {"conv2": "conv1", "conv3": "conv2", "dconv3": "conv3", "upconv2": "dconv3", "dconv2": "upconv2",
+                       "upconv1": "dconv2", "dconv1": "upconv1"}
         split = self.sharded and self.overlap
         packed = 0
         if self.batched:
@@ -414,36 +432,29 @@ class FacetDenoiser:
             d.flags = packed | lflags
             args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(lws),
                     lws.numel(), st)
-            reqs = halo_before.get(lay.name, []) if self.sharded else []
-            if split and reqs:
+            need = wait_before.get(lay.name) if self.sharded else None
+            if split and need and M["graphs"][lay.level].tiles["tiles_int"][1] >= self.split_min_tiles:
                 # interior tiles (they gather owned rows only) run while the halo rows travel; then the rest
-                for name, level, parent in reqs:
-                    yield ("rows_begin", level, B[name], parent, name)
                 g = M["graphs"][lay.level]
                 own_src = d.n >> d.shift
                 self._tag("fwd:" + lay.name)
                 d.tile_list, d.n_tiles = g.tiles["tiles_int"][0].data_ptr(), g.tiles["tiles_int"][1]
                 d.proj_row0, d.proj_rows = 0, own_src
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
-                for name, level, parent in reqs:
-                    yield ("wait", name)
-                if lay.name in wait_before:
-                    yield ("wait", wait_before[lay.name])
+                yield ("wait", need)
                 d.tile_list, d.n_tiles = g.tiles["tiles_bnd"][0].data_ptr(), g.tiles["tiles_bnd"][1]
                 d.proj_row0, d.proj_rows = own_src, (d.src_rows - own_src) or -1
                 d.flags = _lib.CONV_PACKED | lflags
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
                 d.tile_list, d.n_tiles, d.proj_row0, d.proj_rows, d.flags = None, 0, 0, 0, packed | lflags
             else:
-                for name, level, parent in reqs:
-                    yield ("rows", level, B[name], parent)
-                if self.sharded and lay.name in wait_before:
-                    yield ("wait", wait_before[lay.name])
+                if need:
+                    yield ("wait", need)
                 self._tag("fwd:" + lay.name)
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
-            if self.sharded and lay.name in early:
-                name, level, _ = early[lay.name]
-                yield ("rows_begin", level, B[name], False, name)
+            if self.sharded and lay.name in send_after:
+                items = [(k, lv, B[t], par) for k, lv, t, par in send_after[lay.name]]
+                yield ("xchg", items, lay.name)
             if self.multi_scale and lay.name in ("dconv3", "dconv2"):
                 head, out = ("head2", "y2") if lay.name == "dconv3" else ("head1", "y1")
                 W1, b1, W2, b2 = vals[self.slot[head]:self.slot[head] + 4]
@@ -484,11 +495,12 @@ class FacetDenoiser:
         else:
             B["loss"].zero_()
         if self.sharded:
-            # loss = sum over ranks of (sum of angles) / sum over ranks of (real rows)
-            tot = torch.stack([torch.nan_to_num(B["loss"][0] * B["loss"][1]), B["loss"][1]])
-            yield ("sum", tot)
-            B["loss"][0:1] = tot[0:1] / tot[1:2]
-            B["loss"][1:2] = tot[1:2]
+            # loss = sum over ranks of (sum of angles) / (real rows among ALL samples).  The count is known to every
+            # rank (flags of the whole mesh were kept at bind time), so the backward pass can start at once; the sum of
+            # angles rides in the tail of the gradient all-reduce at the end of the step
+            ext = self.params.grad_ext
+            ext[-4:-3] = torch.nan_to_num(B["loss"][0:1] * B["loss"][1:2])
+            B["loss"][1:2] = B["real_flag"][B["sample_ind"].long()].sum().reshape(1)
         if ns_samp:
             _lib.check(L.fgc_angular_loss_bwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, n0, _p(B["loss"]), 1.0,
                                               _p(B["g_nconv"]), st), "loss bwd")
@@ -533,35 +545,34 @@ class FacetDenoiser:
             g = M["graphs"][lay.level]
             call = lambda what: _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st),
                                            name + " bwd/" + what)
-            io.stages, io.flags = 1, base   # s = dy * lrelu'(y) / deg on owned rows
-            call("ds")
+            io.flags = base
             if not L.fgc_conv_bwd_needs_exchange(C.byref(d), C.byref(io)):
                 # first layer over a narrow input: its parameter gradients are sums over owned nodes, nothing to
                 # exchange (the flat-gradient all-reduce adds the ranks)
-                io.stages = 2 | 8
+                io.stages = 1 | 2 | 8
                 call("params")
                 continue
-            # the halo rows of s (from their owners) are first read by the data kernel: they travel under the
-            # d-logits kernel, which only reads the owned rows
-            yield ("rows_begin", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False, "ds")
-            io.stages = 2               # d-logits of owned edges (packs the operands of stages 2 and 4)
+            # s = dy * lrelu'(y) / deg on owned rows and the d-logits of owned edges, in one call (the deep d-logits kernel
+            # computes s in its prologue; packs the operands of stages 2 and 4 when the network did not)
+            io.stages = 1 | 2
             call("logits")
-            if self.overlap:
-                # d-logits of incoming cross-shard edges travel under the data kernel of the interior tiles
-                # (all in-edges from owned rows); boundary tiles and the weight gradients follow
-                yield ("edges_begin", lay.level, "dl")
+            # ONE grouped exchange per layer: the halo rows of s (their owners') and the d-logits of incoming cross-shard
+            # edges, both first read by the data kernel
+            items = [("rows", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False), ("edges", lay.level)]
+            if self.overlap and g.tiles["ttiles_int"][1] >= self.split_min_tiles:
+                # ... it travels under the data kernel of the interior tiles (all in-edges from owned rows); boundary
+                # tiles and the weight gradients follow
+                yield ("xchg", items, "bwd")
                 io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_int"][0].data_ptr(), g.tiles["ttiles_int"][1]
                 call("data/interior")
-                yield ("wait", "ds")
-                yield ("wait", "dl")
+                yield ("wait", "bwd")
                 io.stages = 4 | 8
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_bnd"][0].data_ptr(), g.tiles["ttiles_bnd"][1]
                 call("data/boundary")
                 io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
             else:
-                yield ("wait", "ds")
-                yield ("edges", lay.level)
+                yield ("xchg", items, None)
                 io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("data")
                 io.flags = 0
@@ -570,29 +581,28 @@ class FacetDenoiser:
             self._tag("bwd:reduce")
             _lib.check(L.fgc_conv_bwd_reduce(A["descs"], A["ios"], A["wsb"], A["count"], st), "reduce")
         if self.sharded:
-            yield ("sum", self.params.grad)     # every rank summed its own facets: one flat all-reduce
+            # every rank summed its own facets: one flat all-reduce (gradient + the loss sum in the tail)
+            yield ("sum", self.params.grad_ext)
+            B["loss"][0:1] = self.params.grad_ext[-4:-3] / B["loss"][1:2]
 
-    # ---- exchange requests -> (send buffer, send counts, receive view, receive counts) ---------------------
-    def _materialise(self, req):
+    # ---- exchange items -> (send buffer, send counts, receive view, receive counts) ------------------------
+    def _materialise(self, item):
         from . import ops
         M = self._mesh
-        kind = req[0]
-        if kind == "sum":
-            return ("sum", req[1])
-        g = M["graphs"][req[1]]
-        if kind in ("rows", "rows_begin"):
-            t, parent = req[2], req[3]
+        g = M["graphs"][item[1]]
+        if item[0] == "rows":
+            t, parent = item[2], item[3]
             tail = t.shape[0] - g.n_halo
             idx = g.send_parent_rows if parent else g.send_rows
             nsend = sum(g.send_counts)
             send = ops.gather_rows(t, idx[:nsend]) if nsend else t[:0]
-            return ("a2a", send, g.send_counts, t[tail:], g.recv_counts)
-        if kind in ("edges", "edges_begin"):
+            return (send, g.send_counts, t[tail:], g.recv_counts)
+        if item[0] == "edges":
             dl = M["B"]["dl"][:(g.nnz + g.n_cross_in) * DL_LD].view(-1, DL_LD)
             nsend = sum(g.cross_send_counts)
             send = ops.gather_rows(dl, g.send_edges[:nsend]) if nsend else dl[:0]
-            return ("a2a", send, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
-        raise ValueError(kind)
+            return (send, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
+        raise ValueError(item[0])
 
     def _drain(self, gen):
         """Run a schedule on this rank: no-op exchanges when unsharded, collectives through self.comm otherwise."""
@@ -600,15 +610,14 @@ class FacetDenoiser:
         for req in gen:
             if req[0] == "wait":
                 self.comm.finish(pending.pop(req[1]))
-                continue
-            m = self._materialise(req)
-            if req[0].endswith("_begin"):
-                pending[req[-1]] = self.comm.all_to_all_rows_begin(m[1], m[2], m[3], m[4])
-                continue
-            if m[0] == "sum":
-                self.comm.all_reduce_sum(m[1])
+            elif req[0] == "sum":
+                self.comm.all_reduce_sum(req[1])
             else:
-                self.comm.all_to_all_rows(m[1], m[2], m[3], m[4])
+                mats = [self._materialise(it) for it in req[1]]
+                if req[2] is None:
+                    self.comm.exchange(mats)
+                else:
+                    pending[req[2]] = self.comm.exchange_begin(mats)
 
     def _enqueue_forward(self, rotate):
         self._drain(self._forward_gen(rotate))
@@ -715,11 +724,11 @@ class FacetDenoiser:
                 stats["n"] += 1
                 stats["bytes"] += nbytes
 
-            def all_to_all_rows(self, send, sc, recv, rc):
-                self._t(lambda: comm.all_to_all_rows(send, sc, recv, rc), send.numel() * send.element_size())
+            def exchange(self, mats):
+                self._t(lambda: comm.exchange(mats), sum(m[0].numel() * m[0].element_size() for m in mats))
 
-            def all_to_all_rows_begin(self, send, sc, recv, rc):
-                self.all_to_all_rows(send, sc, recv, rc)
+            def exchange_begin(self, mats):
+                self.exchange(mats)
                 return None
 
             def finish(self, h):

@@ -14,10 +14,11 @@ thin rim.  Per graph level and rank the plan holds
   * the local transposed CSR for backward, whose edge ids address [owned edges | incoming cross-shard edges];
   * send lists: which owned rows / owned edges every peer needs, in the order the peer stores them.
 
-Exchanges per step: 7 row exchanges forward, per conv backward one row exchange (s = dy/deg) and one per-edge
-exchange (d logits of cross edges); one flat-gradient all-reduce, two scalar all-reduces for normalizeTensor and
-one for the loss.  Everything is an all-to-all of packed rows: with RCCL over xGMI every peer pair has its own
-link, so the exchange is one hop, never a ring.
+Exchanges per step (17 collectives): 7 grouped exchanges forward (everything a layer produces that peers gather, in one
+message right behind the layer), 7 backward (per conv the s = dy/deg rows and the d-logits of cross edges together), two
+scalar all-reduces for normalizeTensor and its gradient, one all-reduce of the flat gradient with the loss sum in its
+tail.  A grouped exchange is one RCCL group of point-to-point sends / receives: over xGMI every peer pair has its own
+link, so it is one hop, never a ring.
 """
 import numpy as np
 import torch
@@ -218,21 +219,45 @@ class DistComm:
         else:
             self.dist.all_to_all_single(recv, send, list(recv_counts), list(send_counts), group=self.group)
 
-    def all_to_all_rows_begin(self, send, send_counts, recv, recv_counts):
-        """Start the exchange and return a handle for `finish`: on RCCL the collective runs on the communicator's
-        own stream, so kernels enqueued between begin and finish overlap it (the skip-connection halos travel under
-        the encoder, the ds halos under the d-logits kernel).  `recv` must not be read, nor `send` reused, before
-        `finish`.  The host-staged gloo path exchanges synchronously here."""
+    # ---- grouped exchanges: several (send, send_counts, recv, recv_counts) blocks with every peer at once ----------
+    def _p2p_ops(self, mats):
+        """One isend / irecv per (block, peer) with rows to move.  RCCL runs the whole list as ONE group: every peer
+        pair uses its own xGMI link, nothing is packed or unpacked beyond the row gather the caller did - the rows land
+        in the halo tail of their tensor.  Both sides post the blocks in the same order, so the messages of a peer pair
+        match up."""
+        d = self.dist
+        ops = []
+        for send, sc, recv, rc in mats:
+            so, ro = np.cumsum([0] + list(sc)), np.cumsum([0] + list(rc))
+            for q in range(self.world):
+                if q == self.rank:
+                    continue
+                if sc[q]:
+                    ops.append(d.P2POp(d.isend, send[so[q]:so[q + 1]], q, self.group))
+                if rc[q]:
+                    ops.append(d.P2POp(d.irecv, recv[ro[q]:ro[q + 1]], q, self.group))
+        return ops
+
+    def exchange_begin(self, mats):
+        """Start ONE grouped exchange of all blocks and return a handle for `finish`: on RCCL it runs on the
+        communicator's own stream, so kernels enqueued between begin and finish overlap it.  The receive views must
+        not be read, nor the send buffers reused, before `finish`.  The host-staged gloo path exchanges synchronously."""
         if self.host_staged:
-            self.all_to_all_rows(send, send_counts, recv, recv_counts)
+            for m in mats:
+                self.all_to_all_rows(*m)
             return None
-        work = self.dist.all_to_all_single(recv, send, list(recv_counts), list(send_counts), group=self.group,
-                                           async_op=True)
-        return (work, send, recv)       # keeps the buffers alive until the wait
+        ops = self._p2p_ops(mats)
+        if not ops:
+            return None
+        return (self.dist.batch_isend_irecv(ops), mats)     # keeps the buffers alive until the wait
+
+    def exchange(self, mats):
+        self.finish(self.exchange_begin(mats))
 
     def finish(self, handle):
         if handle is not None:
-            handle[0].wait()            # the current stream waits for the collective; the host does not block
+            for w in handle[0]:
+                w.wait()                # the current stream waits for the group; the host does not block
 
     def _gloo_a2a(self, r, s, recv_counts, send_counts):
         # gloo has no all_to_all_single on every build: P2P rounds instead
@@ -300,26 +325,29 @@ def sim_run(nets, make_gen):
             return
         assert all(r is not None for r in reqs), "shards disagree on the exchange schedule"
         assert len({r[0] for r in reqs}) == 1, "shards disagree on the exchange schedule"
-        if reqs[0][0] == "wait":       # the exchange already happened at its "..._begin"
+        if reqs[0][0] == "wait":       # the exchange already happened when it was begun
             continue
-        mats = [n._materialise(r) for n, r in zip(nets, reqs)]
-        if mats[0][0] == "sum":
-            tot = mats[0][1].clone()
-            for m in mats[1:]:
-                tot += m[1]
-            for m in mats:
-                m[1].copy_(tot)
+        if reqs[0][0] == "sum":
+            tot = reqs[0][1].clone()
+            for r in reqs[1:]:
+                tot += r[1]
+            for r in reqs:
+                r[1].copy_(tot)
             continue
-        for dst, md in enumerate(mats):
-            recv, recv_counts = md[3], md[4]
-            ro = np.cumsum([0] + list(recv_counts))
-            for src, ms in enumerate(mats):
-                if src == dst or not recv_counts[src]:
-                    continue
-                send, send_counts = ms[1], ms[2]
-                so = np.cumsum([0] + list(send_counts))
-                assert send_counts[dst] == recv_counts[src], (src, dst, send_counts[dst], recv_counts[src])
-                recv[ro[src]:ro[src + 1]].copy_(send[so[dst]:so[dst + 1]])
+        nitems = len(reqs[0][1])
+        assert all(len(r[1]) == nitems for r in reqs), "shards disagree on the exchange schedule"
+        for k in range(nitems):
+            mats = [n._materialise(r[1][k]) for n, r in zip(nets, reqs)]
+            for dst, md in enumerate(mats):
+                recv, recv_counts = md[2], md[3]
+                ro = np.cumsum([0] + list(recv_counts))
+                for src, ms in enumerate(mats):
+                    if src == dst or not recv_counts[src]:
+                        continue
+                    send, send_counts = ms[0], ms[1]
+                    so = np.cumsum([0] + list(send_counts))
+                    assert send_counts[dst] == recv_counts[src], (src, dst, send_counts[dst], recv_counts[src])
+                    recv[ro[src]:ro[src + 1]].copy_(send[so[dst]:so[dst + 1]])
 
 
 def sim_forward_backward(nets, rotate=True):

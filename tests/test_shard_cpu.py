@@ -91,6 +91,23 @@ def _worker(rank, world, port, golden_dir, out):
             comm.all_to_all_rows(send, P.send_counts, t[P.n_own:], P.recv_counts)
             ok &= bool(torch.equal(t[:, 0], torch.from_numpy(ids).float()))
             ok &= bool((t[:, 1] == 7.0).all())
+        # the grouped form a multi-GPU step uses: two levels' rows with every peer in ONE batch of point-to-point
+        # operations (on RCCL one group; here gloo moves CPU tensors through the same isend / irecv list)
+        comm.host_staged = False
+        ts, mats = [], []
+        for l in (0, 1):
+            P = plan.levels[l]
+            ids = plan.local_rows(l)
+            t = torch.zeros(len(ids), 2 + l)
+            t[:P.n_own, 0] = torch.arange(P.lo, P.hi, dtype=torch.float32)
+            send = t[torch.from_numpy(np.concatenate(P.send_rows)).long()].contiguous()
+            mats.append((send, P.send_counts, t[P.n_own:], P.recv_counts))
+            ts.append((t, ids))
+        h = comm.exchange_begin(mats)
+        comm.finish(h)
+        for t, ids in ts:
+            ok &= bool(torch.equal(t[:, 0], torch.from_numpy(ids).float()))
+        comm.host_staged = True
         s = torch.tensor([float(rank + 1)])
         comm.all_reduce_sum(s)
         ok &= s.item() == world * (world + 1) / 2

@@ -10,8 +10,8 @@ from facet_graph_convolution_amd.shard import ShardPlan, graphs_to_host_csr
 
 class NullComm:
     world, rank, host_staged = 8, 0, False
-    def all_to_all_rows(self, *a): pass
-    def all_to_all_rows_begin(self, *a): return None
+    def exchange(self, mats): pass
+    def exchange_begin(self, mats): return None
     def finish(self, h): pass
     def all_reduce_sum(self, t): pass
 
