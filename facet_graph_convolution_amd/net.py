@@ -246,6 +246,10 @@ class FacetDenoiser:
                 B["nconv" + k] = torch.empty(nk, 3, **f)
                 B["abs_part" + k] = torch.empty(self.L.fgc_mlp_num_partials(nk), **f)
                 B["norm_scratch" + k] = torch.zeros(2 + self.L.fgc_norm_num_partials(nk), **f)
+                if gtt is not None and plan is None:
+                    B["g_y" + k] = torch.zeros(nk, 3, **f)
+                    B["g_nconv" + k] = torch.zeros(nk, 3, **f)
+                    B["loss" + k] = torch.zeros(2, **f)
         # shared backward scratch, sized for the largest user
         max_ds = max((ns[l.level] + nh[l.level]) * self._cout(l) for l in self.layers)
         max_r = max(ns[l.level] * (FGC_M * self._cout(l) + 24) for l in self.layers)
@@ -264,6 +268,17 @@ class FacetDenoiser:
             B["gtr"] = torch.empty_like(B["gt"])
             if plan is not None:
                 B["real_flag"] = real_flag.to(dev)
+            elif self.multi_scale:
+                # ground truth of the coarse heads (build extension, see train_step): the fine normals pooled with
+                # "average ignoring zero rows" (model.py:792-814) and renormalised; rows of fake nodes only stay zero
+                from . import ops
+                g = B["gt"]
+                for k in ("1", "2"):
+                    g = ops.pool4_avg_iz(g)
+                    nrm = g.norm(dim=1, keepdim=True)
+                    g = torch.where(nrm > 0, g / nrm.clamp_min(1e-20), torch.zeros_like(g)).contiguous()
+                    B["gt" + k] = g
+                    B["gtr" + k] = torch.empty_like(g)
         # descriptors + workspace
         vals, grads = self.params.values, self.params.grads
         descs, ios, ws_f, ws_b = {}, {}, 0, 0
@@ -315,6 +330,11 @@ class FacetDenoiser:
             io.accumulate0, io.accumulate1 = 0, 0
         ios["conv1"].dx0 = None
         ios["conv1"].dx1 = None
+        if self.multi_scale and gt is not None and plan is None:
+            # training the three heads: the coarse heads write their input gradients into g_d3 / g_d2 first, the
+            # up-convolutions then add theirs
+            ios["upconv2"].accumulate0 = 1
+            ios["upconv1"].accumulate0 = 1
         if (layer_flags["conv1"] & _lib.CONV_SAVE_Z) and not self.L.fgc_conv_bwd_needs_exchange(
                 C.byref(descs["conv1"]), C.byref(ios["conv1"])):
             ios["conv1"].z_saved = wsf["conv1"].data_ptr()      # (the library took the narrow path: see FGC_CONV_SAVE_Z)
@@ -322,6 +342,9 @@ class FacetDenoiser:
             layer_flags["conv1"] = descs["conv1"].flags = layer_flags["conv1"] & ~_lib.CONV_SAVE_Z
         ws_f = max(ws_f, self.L.fgc_mlp_workspace_bytes(128, HIDDEN, 3))
         ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n0, 32, HIDDEN, 3))
+        if self.multi_scale:
+            ws_b = max(ws_b, self.L.fgc_mlp_bwd_workspace_bytes(n1, 64, HIDDEN, 3),
+                       self.L.fgc_mlp_bwd_workspace_bytes(n2, 128, HIDDEN, 3))
         if bf16:
             ws_b = max(ws_b, self.L.fgc_mlp_bwd_bf16_workspace_bytes(n0, 32, HIDDEN, 3))
         B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)     # the MLP heads
@@ -519,6 +542,36 @@ class FacetDenoiser:
             _lib.check(L.fgc_normalize_bwd_apply(_p(B["y0"]), n0, 3.0 * M["n_total"][0], _p(sc), _p(B["g_y0"]), st),
                        "normalize bwd 2")
         vals, grads = self.params.values, self.params.grads
+        if self.multi_scale:
+            if self.sharded or self.dtype != "f32":
+                raise NotImplementedError("training the multi-scale heads: unsharded fp32 network only")
+            # Build extension: the reference trains the coarse heads through a point-set loss on the vertex update
+            # (train.py:1075-1105; SURVEY.md section 2: out of scope).  Here every head gets the angular loss of the fine
+            # head (train.py:1272-1294) against the pooled ground truth, on the same sampled rows modulo the level's size.
+            for k, name, head in (("2", "dconv3", "head2"), ("1", "dconv2", "head1")):
+                lvl = int(k)
+                nk = ns[lvl]
+                y, nc, part, sc = B["y" + k], B["nconv" + k], B["abs_part" + k], B["norm_scratch" + k]
+                self._tag("bwd:head" + k)
+                _lib.check(L.fgc_normalize_fwd(_p(y), nk, _p(part), part.numel(), _p(nc), _p(sc), st), "normalize")
+                gtk = B["gt" + k]
+                if rotate:
+                    _lib.check(L.fgc_rotate_rows(_p(gtk), _p(B["gtr" + k]), nk, 1, _p(B["R"]), st), "rotate gt")
+                    gtk = B["gtr" + k]
+                sk = torch.remainder(B["sample_ind"], nk)
+                B["sample_ind" + k] = sk        # (kept alive until the kernels have run)
+                _lib.check(L.fgc_angular_loss_fwd(_p(nc), _p(gtk), _p(sk), sk.numel(), _p(B["loss" + k]), st), "loss")
+                _lib.check(L.fgc_angular_loss_bwd(_p(nc), _p(gtk), _p(sk), sk.numel(), nk, _p(B["loss" + k]), 1.0,
+                                                  _p(B["g_nconv" + k]), st), "loss bwd")
+                _lib.check(L.fgc_normalize_bwd(_p(y), _p(B["g_nconv" + k]), nk, _p(B["g_y" + k]), _p(sc), st),
+                           "normalize bwd")
+                lay = next(l for l in self.layers if l.name == name)
+                xin = B[lay.y]
+                hs = self.slot[head]
+                _lib.check(L.fgc_mlp_bwd(_p(xin), _p(B["g_y" + k]), nk, xin.shape[1], HIDDEN, 3, _p(vals[hs]),
+                                         _p(vals[hs + 1]), _p(vals[hs + 2]), LRELU_ALPHA, _p(B["g_" + lay.y]),
+                                         _p(grads[hs]), _p(grads[hs + 1]), _p(grads[hs + 2]), _p(grads[hs + 3]), _p(ws),
+                                         ws.numel(), st), head + " bwd")
         s = self.slot["head0"]
         self._tag("bwd:mlp")
         _lib.check(self._mlp_bwd(_p(B["d1"]), _p(B["g_y0"]), n0, 32, HIDDEN, 3, _p(vals[s]), _p(vals[s + 1]),

@@ -228,6 +228,35 @@ def train_loss(x, adjs, gt, params, sample_ind, R):
     return faceNormalsLoss(n_conv[:, idx], gt_r[:, idx]), n_conv
 
 
+def pooled_gt(gt):
+    """NOT in the reference (build extension, facet_graph_convolution_amd.net multi-scale training): ground truth of the
+    coarse heads = the fine normals pooled with avg_ignore_zeros (ref: model.py:792-814) and renormalised; rows that pool
+    only fake nodes stay zero."""
+    g = avg_ignore_zeros_pool(gt, 2)
+    nrm = g.norm(dim=-1, keepdim=True)
+    return torch.where(nrm > 0, g / nrm.clamp_min(1e-20), torch.zeros_like(g))
+
+
+def train_loss_ms(x, adjs, gt, params, sample_ind, R):
+    """NOT in the reference (its multi-scale training runs a point-set loss through the vertex update, train.py:1075-1105):
+    the three heads of get_model_reg_multi_scale(multiScale=True), each through normalizeTensor and faceNormalsLoss against
+    the pooled ground truth on the sampled rows modulo the level's size.  Returns (loss0 + loss1 + loss2, [loss_k])."""
+    x_r, gt_r = rotate_inputs(x, gt, R)
+    ys = get_model_reg_multi_scale(x_r, adjs, params, multiScale=True)
+    gts = [gt_r, None, None]
+    g = gt
+    for k in (1, 2):
+        g = pooled_gt(g)
+        gts[k] = torch.matmul(g, R.to(x.dtype).t())
+    idx = torch.as_tensor(sample_ind, dtype=torch.long)
+    losses = []
+    for y, g in zip(ys, gts):
+        n_conv = normalizeTensor(y)
+        ik = idx % y.shape[1]
+        losses.append(faceNormalsLoss(n_conv[:, ik], g[:, ik]))
+    return losses[0] + losses[1] + losses[2], losses
+
+
 def adam_step_tf1(params, grads, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     """TensorFlow-1 Adam (train.py:520 uses tf.train.AdamOptimizer() defaults).
 

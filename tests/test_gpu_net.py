@@ -362,3 +362,38 @@ def test_graph_replay_survives_a_device_synchronise():
     """)
     r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "replay ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_multiscale_training_step_matches_oracle(golden_dir):
+    """Training the three heads (build extension: angular loss per level against the pooled ground truth; the
+    reference's point-set objective is out of scope): losses and all 52 gradients against torch autograd through the
+    oracle's multi-scale network."""
+    from oracle import model_ref as R
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    net, prep = _bind(golden_dir, "ico3", 0, multi_scale=True)
+    x, adjs, gt = prep["x"], [prep["adj0"], prep["adj1"], prep["adj2"]], prep["gt"]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    net.set_samples(samp)
+    net.set_rotation(Rm)
+    net.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    params = [p.requires_grad_(True) for p in R.init_params(0, multi_scale=True)]
+    tot, losses = R.train_loss_ms(torch.tensor(x.astype(np.float32)), [torch.tensor(a.astype(np.int32)) for a in adjs],
+                                  torch.tensor(gt.astype(np.float32)), params, samp, torch.tensor(Rm.astype(np.float32)))
+    tot.backward()
+    got = [net.buffers["loss"][0].item(), net.buffers["loss1"][0].item(), net.buffers["loss2"][0].item()]
+    for a, b in zip(got, losses):
+        assert abs(a - b.item()) < 1e-4 * abs(b.item()), (got, [l.item() for l in losses])
+    assert len(net.params.grads) == 52
+    for i, (g, p) in enumerate(zip(net.params.grads, params)):
+        scale = max(p.grad.abs().max().item(), 1e-3)
+        assert (g.cpu() - p.grad).abs().max().item() / scale < 2e-3, "grad %d (%s)" % (i, net.params.spec[i])
+    # and it trains
+    rs = np.random.RandomState(0)
+    first = None
+    for it in range(25):
+        loss = net.train_step(sample_ind=rs.randint(x.shape[1], size=4000), R=np.eye(3))
+        tot_l = loss[0].item() + net.buffers["loss1"][0].item() + net.buffers["loss2"][0].item()
+        first = tot_l if first is None else first
+    assert tot_l < 0.7 * first
