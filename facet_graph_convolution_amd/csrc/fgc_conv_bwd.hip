@@ -15,6 +15,8 @@
 // No float atomics anywhere: every sum has a fixed order, results are bitwise reproducible.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
 #include "fgc_reduce.h"
@@ -1353,6 +1355,136 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K3 for bf16-stored operands ON the bf16 matrix cores (FGC_CONV_BF16).  C[P,Q] = sum_rows A[row,P] * X[row >> shift, Q]
+// reduces over the rows, the slow index of both operands, while a v_mfma_f32_16x16x32_bf16 fragment wants 8 consecutive k
+// of ONE output row / column in a lane.  The transposition is done by the LDS read: a chunk of 32 rows of A (up to 320
+// columns) and of X (QT * 16 columns) is staged row-major, as it lies in memory (16-byte pieces, coalesced), and read back
+// with ds_read_b64_tr_b16: per 16-lane group a 4 row x 16 column block comes back column-major, lane i holding column i
+// of the four rows.  Two such reads (rows 4*lq .. +3 and 16 + 4*lq .. +3) are a whole fragment; A and X use the same row
+// order, so the permuted k is consistent.  Row strides == 32 bytes mod 256, an odd multiple of 32: the eight rows a
+// 32-lane half touches land on eight disjoint 32-byte bank spans.  Wave w owns row tiles 5w .. 5w+4 of the product
+// (columns of A) and all column tiles: 18 transposed reads per 20 MFMAs.  The kernel streams: what bounds it is how fast
+// the rows of r arrive, so the next chunk travels through registers under the current one.  fp32 accumulators; slabs and
+// their fixed-order sum as for the fp32 kernels.
+// ---------------------------------------------------------------------------------------------
+constexpr int TNB_THREADS = 256;
+constexpr int TNB_PC = 320;               // columns of A per workgroup
+constexpr int TNB_AS = TNB_PC * 2 + 32;   // LDS row strides in bytes
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 tnb_frag(const char* tile, int stride, int col0, int lq, int lr) {
+    // block rows 4*lq + q (then 16 + 4*lq + q), columns col0 + 4*p .. +3 for lane 4*q + p of the group
+    const char* a = tile + (4 * lq + (lr >> 2)) * stride + (col0 + 4 * (lr & 3)) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 16 * stride));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
+template <int QT>
+__global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsigned short* __restrict__ A, int lda, int P,
+                                                                      const unsigned short* __restrict__ x0,
+                                                                      const unsigned short* __restrict__ x1, int c0, int c1,
+                                                                      int shift, int rows, int rows_per_split,
+                                                                      float* __restrict__ slab) {
+    constexpr int QC = QT * 16;
+    constexpr int XS = QC * 2 + 32;
+    constexpr int APC = TNB_PC / 8;                                  // 16-byte pieces per row of the A chunk
+    constexpr int NA = 32 * APC / TNB_THREADS;                       // pieces per thread: 5
+    static_assert(32 * APC % TNB_THREADS == 0 && 32 * (QC / 8) <= TNB_THREADS, "staging shape");
+    __shared__ __attribute__((aligned(16))) char As[2][32 * TNB_AS];
+    __shared__ __attribute__((aligned(16))) char Xs[2][32 * XS];
+    const int Q = c0 + c1;
+    const int npc = (P + TNB_PC - 1) / TNB_PC;
+    const int pc = blockIdx.x % npc, qc = blockIdx.x / npc;
+    const int p0 = pc * TNB_PC, q0 = qc * QC;
+    const int pw = min(P - p0, TNB_PC);                              // valid columns of A here (a multiple of 8)
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_end = min(rows, r_begin + rows_per_split);
+    const int nchunks = (r_end - r_begin + 31) >> 5;
+
+    u32x4 ra[NA], rx;
+    const int xrow = min(tid, 32 * (QC / 8) - 1) / (QC / 8), xcol = (min(tid, 32 * (QC / 8) - 1) % (QC / 8)) * 8;
+    const int qcol = q0 + xcol;
+    const bool x_first = qcol < c0;
+    const unsigned short* xsrc = x_first ? x0 : x1;
+    const int xld = x_first ? c0 : c1;
+    const int xoff = min(x_first ? qcol : qcol - c0, xld - 8);
+    auto fetch = [&](int ch) {
+        const int rb = r_begin + ch * 32;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int t = tid + i * TNB_THREADS;
+            const int row = min(rb + t / APC, r_end - 1);
+            const int col = p0 + min((t % APC) * 8, pw - 8);
+            ra[i] = *reinterpret_cast<const u32x4*>(A + (size_t)row * lda + col);
+        }
+        rx = *reinterpret_cast<const u32x4*>(xsrc + (size_t)(min(rb + xrow, r_end - 1) >> shift) * xld + xoff);
+    };
+    auto stage = [&](int ch, int buf) {
+        const int rb = r_begin + ch * 32;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int t = tid + i * TNB_THREADS;
+            const int r = t / APC, c = (t % APC) * 8;
+            const bool ok = rb + r < r_end && c < pw;
+            *reinterpret_cast<u32x4*>(&As[buf][r * TNB_AS + c * 2]) = ok ? ra[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+        if (tid < 32 * (QC / 8)) {
+            const bool ok = rb + xrow < r_end && qcol < Q;
+            *reinterpret_cast<u32x4*>(&Xs[buf][xrow * XS + xcol * 2]) = ok ? rx : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    f32x4 acc[5][QT];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nchunks > 0) {
+        fetch(0);
+        stage(0, 0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) fetch(ch + 1);
+        u32x4 af[5], bq[QT];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) af[i] = tnb_frag(As[buf], TNB_AS, (wave * 5 + i) * 16, lq, lr);
+#pragma unroll
+        for (int j = 0; j < QT; ++j) bq[j] = tnb_frag(Xs[buf], XS, j * 16, lq, lr);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < QT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bq[j]),
+                                                                   acc[i][j], 0, 0, 0);
+        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);     // (the other buffer: its readers finished before the last barrier)
+        __syncthreads();
+    }
+    // C layout: column = lr -> q, row = 4*lq + reg -> p
+    float* out = slab + (size_t)blockIdx.y * P * Q;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pp = p0 + (wave * 5 + i) * 16 + lq * 4 + t, qq = q0 + j * 16 + lr;
+                if (pp < p0 + pw && qq < Q) out[(size_t)pp * Q + qq] = acc[i][j][t];
+            }
+}
+
+static bool tn_bf16_ok(int P, int c0, int c1) {
+    if (getenv("FGC_NO_TNBF16") && getenv("FGC_NO_TNBF16")[0] == '1') return false;
+    const int Q = c0 + c1;
+    return P % 8 == 0 && c0 % 8 == 0 && c1 % 8 == 0 && Q % 32 == 0 && (c1 == 0 || c0 % 16 == 0) && c0 >= 8 && (c1 == 0 || c1 >= 8);
+}
+
 int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,
                           int rows_per_split, int nsplits, float* slab, hipStream_t st) {
     if (c0 <= 32 && c0 % 2 == 0) {
@@ -1410,6 +1542,12 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.db_part = take((size_t)w.nb_db * d->cout);
     w.dc_part = take((size_t)cdiv(d->n, TILE) * 12);
     w.splitW = tn_splits(FGC_M * d->cout + 24, cin, d->n);
+    if ((d->flags & FGC_CONV_BF16) && tn_bf16_ok(FGC_M * d->cout + 24, d->c0, d->c1)) {
+        // the bf16 kernel's workgroups own up to 320 x 64 of the product: one or two per CU in all
+        static const int target = getenv("FGC_TNB_WGS") ? atoi(getenv("FGC_TNB_WGS")) : 256;   // (developer knob)
+        const int tiles = cdiv(FGC_M * d->cout + 24, TNB_PC) * cdiv(cin, 64);
+        w.splitW = std::max(1, std::min(target / tiles, cdiv(d->n, 256)));
+    }
     w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
     w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
                   reduce_tmp_floats(cdiv(d->n, TILE), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
@@ -1674,7 +1812,17 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const int ns = cdiv(d->n, rps);
         const dim3 g1(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
-        if (bf16 && cin <= 32 && d->c1 == 0)
+        if (bf16 && tn_bf16_ok(PL, d->c0, d->c1)) {
+            const unsigned short* r16 = (const unsigned short*)io->r;
+            const unsigned short *h0 = (const unsigned short*)d->x0, *h1 = (const unsigned short*)d->x1;
+            const int npc = cdiv(PL, TNB_PC);
+            if (cin % 64 == 0)
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<4>), dim3(npc * (cin / 64), ns), dim3(TNB_THREADS), 0, r16, PL,
+                           PL, h0, h1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+            else
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<2>), dim3(npc * (cin / 32), ns), dim3(TNB_THREADS), 0, r16, PL,
+                           PL, h0, h1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
+        } else if (bf16 && cin <= 32 && d->c1 == 0)
             FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<2, true>), dim3(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL,
                        PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else if (bf16)
