@@ -157,6 +157,21 @@ def kernel_flops(kind, n, nnz, cin, cout, M=9):
     raise ValueError(kind)
 
 
+def kernel_bytes(kind, layer, n, nnz, cin, cout, elem):
+    """Algorithmic HBM bytes of one conv launch (SURVEY.md section 8d convention: every tensor of the layer once, the CSR
+    once; weights, logit tables and per-edge scratch are not algorithmic).  An up-convolution reads the coarse tensor:
+    cin / 4 per fine node."""
+    cin_eff = cin / 4.0 if layer.startswith("upconv") else cin
+    csr = 4.0 * (n + nnz)
+    if kind == "fwd":
+        return elem * n * (cin_eff + cout) + csr
+    if kind == "bwd_logits":       # dy, y, x
+        return elem * n * (2 * cout + cin_eff) + csr
+    if kind == "bwd_data":         # s in, dx out
+        return elem * n * (cout + cin_eff) + csr
+    return None
+
+
 def algorithmic_bytes_fwd_bwd(net, elem=4):
     """SURVEY.md section 8d convention: each tensor crossing a layer boundary written once, read once per consumer;
     CSR read once per conv; weights and fused ops free.  Backward moves the same tensors as gradients plus
@@ -435,6 +450,7 @@ def main(argv=None):
         dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net.layer_dims()}
         total_ms = sum(ms for _, ms in prof.values())
         rows = []
+        abytes = {}
         for key, (cnt, ms) in prof.items():
             tag, kern = key.split("/", 1)
             phase, layer = (tag.split(":") + [""])[:2]
@@ -450,10 +466,15 @@ def main(argv=None):
                     kind = "bwd_weight"
             avg_us = ms / cnt * 1e3
             fl = kernel_flops(kind, *dims[layer]) if kind else None
+            by = kernel_bytes(kind, layer, *dims[layer], 2 if args.dtype == "bf16" else 4) if kind else None
             if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern):
                 # 32 -> 1024 -> 3 per padded node; the backward recomputes the hidden layer and adds dW and dx
                 fl = 2.0 * dims["conv1"][0] * 1024 * (32 + 3) * (3 if "mlp_bwd_kernel" in kern else 1)
+                if "<" in kern:      # the bf16 backward is two launches (dx: 2 of the 3 products, w: 2 of the 3)
+                    fl = fl * 2.0 / 3.0
+                by = dims["conv1"][0] * (32 * (2 if args.dtype == "bf16" else 4) + 12.0) * (2 if "bwd" in kern else 1)
             rows.append((ms, key, cnt, avg_us, fl))
+            abytes[key] = by
         rows.sort(reverse=True)
         if args.dump_kernels and rank == 0:
             with open(args.dump_kernels, "w") as fh:
@@ -468,8 +489,8 @@ def main(argv=None):
         # transpose); HBM bytes per launch of each family's reported launch from the PMC passes kept under profiles/
         # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md); null when no pass is recorded
         traffic_db = {}
-        tpath = os.path.join(REPO, "profiles", "r2_traffic_families.json")
-        if os.path.exists(tpath) and args.nu == 250 and args.nv == 200 and args.dtype == "f32":
+        tpath = os.path.join(REPO, "profiles", "r2_traffic_families%s.json" % ("_bf16" if args.dtype == "bf16" else ""))
+        if os.path.exists(tpath) and args.nu == 250 and args.nv == 200:
             traffic_db = json.load(open(tpath))
         fam = {}
         for ms, key, cnt, avg_us, fl in rows:
@@ -485,14 +506,29 @@ def main(argv=None):
             top = sorted((r for r in f["rows"] if r[4]), key=lambda r: (-r[4], r[1]))[0]
             ach = top[4] / (top[3] * 1e-6) / 1e12
             tr = traffic_db.get(top[1])
+            ab = abytes.get(top[1])
             families.append({"family": name, "share_of_step": round(f["ms"] / total_ms, 4),
+                             "algorithmic_bytes": ab,
+                             "hbm_gbs": round(ab / (top[3] * 1e-6) / 1e9, 1) if ab else None,
+                             "hbm_frac": round(ab / (top[3] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if ab else None,
                              "us_per_step": round(f["ms"] / args.steps * 1e3, 1),
                              "family_tflops": round(f["flop"] / (f["ms"] * 1e-3) / 1e12, 2),
                              "family_frac": round(f["flop"] / (f["ms"] * 1e-3) / 1e12 / peak, 4),
                              "kernel": top[1], "avg_kernel_us": round(top[3], 2), "launch_flops": top[4],
                              "achieved": round(ach, 2), "frac": round(ach / peak, 4),
                              "traffic": tr["hbm_bytes_per_launch"] if tr else None})
-        if families:
+        if families and args.dtype == "bf16":
+            # bf16 storage: the matrix products are 16x cheaper, the bound to quote is HBM - the
+            # kernels are far from it too: they are bound by vector-ALU issue in the aggregation
+            d = families[0]
+            roofline = {"bound": "hbm", "kernel": d["kernel"], "family": d["family"], "achieved": d["hbm_gbs"],
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": d["traffic"],
+                        "avg_kernel_us": d["avg_kernel_us"], "launch_bytes": d["algorithmic_bytes"],
+                        "mfma_tflops": d["achieved"], "mfma_frac": d["frac"],
+                        "family_share_of_step": d["share_of_step"],
+                        "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
+                        "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step")}
+        elif families:
             d = families[0]
             roofline = {"bound": "mfma", "kernel": d["kernel"], "family": d["family"], "achieved": d["achieved"],
                         "peak": peak, "unit": "TFLOP/s", "frac": d["frac"], "traffic": d["traffic"],

@@ -49,8 +49,12 @@ def label(names):
             i = cnt.get("tn", 0)
             key = "bwd:%s/gemm_tn_kernel:dW" % (BWD[i] if i < 7 else "conv1")
             cnt["tn"] = i + 1
+        elif s.startswith("mlp_bwd_dx"):
+            key = "bwd:mlp/mlp_bwd_kernel<dx>"
+        elif s.startswith("mlp_bwd_w"):
+            key = "bwd:mlp/mlp_bwd_kernel<w>"
         elif s.startswith("mlp_bwd") or s.startswith("mlp_fwd"):
-            key = "%s:mlp/%s" % ("bwd" if "bwd" in s else "fwd", s.split("<")[0])
+            key = "%s:mlp/%s" % ("bwd" if "bwd" in s else "fwd", "mlp_bwd_kernel" if "bwd" in s else "mlp_fwd_kernel")
         else:
             key = "other/" + s.split("<")[0]
         cnt[s.split("<")[0]] = c + 1
