@@ -589,7 +589,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 
     const int nct = KPASS >> 4;   // 18
     const int okg = opad >> 4;
-    const f32x4* Wq4 = reinterpret_cast<const f32x4*>(lp.Wq);
+    const __amdgpu_buffer_rsrc_t wq_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lp.Wq), 0, -1, 0x00020000);
     int dn[NPW];
 #pragma unroll
     for (int nn = 0; nn < NPW; ++nn) dn[nn] = __builtin_amdgcn_readfirstlane(min(s.deg[wave * NPW + nn], KMAX));
@@ -640,12 +640,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // (buffer loads: the lane's part of the offset is a loop invariant, the k-group's part scalar - the indexed form
+                // spent a 64-bit multiply-add chain per fragment on the vector ALU, which the fp32 MFMA shares)
                 auto loadw = [&](int g, f32x4 (&b)[K1_CTW]) {
                     const int gg = min(g, okg - 1);
+                    const unsigned soff = (unsigned)((pass * (opad >> 2) + gg * 4) * KPASS * 16);
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c) {
                         const int ct = min(wave + c * 4, nct - 1);
-                        b[c] = Wq4[((size_t)pass * (opad >> 2) + gg * 4 + lq) * KPASS + ct * 16 + lr];
+                        b[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                             wq_rs, (unsigned)((lq * KPASS + ct * 16 + lr) * 16), soff, 0));
                     }
                 };
                 auto mmw = [&](int g, const f32x4 (&b)[K1_CTW]) {
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreP
 
     constexpr int nct = KPASS >> 4;   // 18
     const int kso = cout >> 5;
-    const u32x4* Wq16 = reinterpret_cast<const u32x4*>(lp.Wq);
+    const __amdgpu_buffer_rsrc_t wq_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lp.Wq), 0, -1, 0x00020000);
     unsigned short* zt16 = reinterpret_cast<unsigned short*>(s.ztile);
     const char* ztb = reinterpret_cast<const char*>(s.ztile);
     int dn[NPW], rowid[NPW];
@@ -890,7 +894,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreP
                 u32x4 b[K1_CTW];
 #pragma unroll
                 for (int c = 0; c < K1_CTW; ++c)
-                    b[c] = Wq16[((size_t)(pass * kso + ks) * nct + min(wave + c * 4, nct - 1)) * 64 + lane];
+                    b[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         wq_rs, (unsigned)((min(wave + c * 4, nct - 1) * 64 + lane) * 16),
+                                                         (unsigned)((pass * kso + ks) * nct * 1024), 0));
                 u32x4 a[RT];
 #pragma unroll
                 for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const u32x4*>(dst + (r * 16 + lr) * obytes + ks * 64 + lq * 16);

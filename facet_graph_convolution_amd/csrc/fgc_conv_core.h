@@ -106,15 +106,19 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
     const int i = tile0 + node;
     int d = 0, e0 = 0;
     float ctr[FGC_M];
+    // logit table, edge list and per-edge d-logits through buffer descriptors: a gather costs one v_mad_u32_u24 for its
+    // 32-bit offset instead of a 64-bit multiply-add chain on the vector ALU (which the fp32 MFMA shares)
+    const __amdgpu_buffer_rsrc_t ag_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ag), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.col), 0, -1, 0x00020000);
     if (i < p.n) {
         e0 = p.rowptr[i];
         d = p.rowptr[i + 1] - e0;
-        const float* ar = p.ag + (size_t)(i >> p.ag_shift) * FGC_AG_LD + p.ctr_off;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+        const unsigned ao = __umul24((unsigned)(i >> p.ag_shift), FGC_AG_LD * 4u) + (unsigned)p.ctr_off * 4u;
+        const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, ao, 0, 0));
+        const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, ao + 16u, 0, 0));
         ctr[0] = a0[0]; ctr[1] = a0[1]; ctr[2] = a0[2]; ctr[3] = a0[3];
         ctr[4] = a1[0]; ctr[5] = a1[1]; ctr[6] = a1[2]; ctr[7] = a1[3];
-        ctr[8] = ar[8];
+        ctr[8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ag_rs, ao + 32u, 0, 0));
     }
     if (kl == 0) {
         s.deg[node] = d;
@@ -130,14 +134,16 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const int kk = kbase + kl + 8 * t;
-        jj[t] = kk < kend ? p.col[e0 + kk] : 0;
+        // (unconditional, clamped into the node's list: no exec-masked load)
+        const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(e0 + min(kk, max(kend - 1, 0))) * 4u, 0, 0);
+        jj[t] = kk < kend ? jv : 0;
     }
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-        const float* gr = p.ag + (size_t)(jj[t] >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
-        g0[t] = *reinterpret_cast<const f32x4*>(gr);
-        g1[t] = *reinterpret_cast<const f32x4*>(gr + 4);
-        g8[t] = gr[8];
+        const unsigned go = __umul24((unsigned)(jj[t] >> p.ag_shift), FGC_AG_LD * 4u) + (unsigned)p.nbr_off * 4u;
+        g0[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go, 0, 0));
+        g1[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go + 16u, 0, 0));
+        g8[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ag_rs, go + 32u, 0, 0));
     }
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {

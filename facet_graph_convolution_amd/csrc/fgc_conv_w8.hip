@@ -87,15 +87,20 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         float ctr[FGC_M];
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) ctr[m] = 0.f;
+        // the logit table and the edge list through buffer descriptors: a gather then costs one v_mad_u32_u24 for its
+        // 32-bit offset instead of a 64-bit multiply-add chain (the fp32 MFMA and the vector ALU share a SIMD's issue:
+        // every vector instruction saved here is matrix time gained)
+        const __amdgpu_buffer_rsrc_t ag_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ag), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t col_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.col), 0, -1, 0x00020000);
         if (i < p.n) {
             e0 = p.rowptr[i];
             d = min(p.rowptr[i + 1] - e0, QS);
-            const float* ar = p.ag + (size_t)(i >> p.ag_shift) * FGC_AG_LD + p.ctr_off;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+            const unsigned ao = __umul24((unsigned)(i >> p.ag_shift), FGC_AG_LD * 4u) + (unsigned)p.ctr_off * 4u;
+            const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, ao, 0, 0));
+            const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, ao + 16u, 0, 0));
             ctr[0] = a0[0]; ctr[1] = a0[1]; ctr[2] = a0[2]; ctr[3] = a0[3];
             ctr[4] = a1[0]; ctr[5] = a1[1]; ctr[6] = a1[2]; ctr[7] = a1[3];
-            ctr[8] = ar[8];
+            ctr[8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ag_rs, ao + 32u, 0, 0));
         }
         // DATA: the node's da row (written by the d-logits kernel) is needed only after the dl sums below; asked for
         // here it costs no extra memory round trip
@@ -120,14 +125,16 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
-            jj[t] = k < d ? p.col[e0 + k] : 0;
+            // (unconditional, clamped into the node's list: no exec-masked load)
+            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(e0 + min(k, max(d - 1, 0))) * 4u, 0, 0);
+            jj[t] = k < d ? jv : 0;
         }
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
-            const float* gr = p.ag + (size_t)(jj[t] >> p.ag_shift) * FGC_AG_LD + p.nbr_off;
-            g0[t] = *reinterpret_cast<const f32x4*>(gr);
-            g1[t] = *reinterpret_cast<const f32x4*>(gr + 4);
-            g8[t] = gr[8];
+            const unsigned go = __umul24((unsigned)(jj[t] >> p.ag_shift), FGC_AG_LD * 4u) + (unsigned)p.nbr_off * 4u;
+            g0[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go, 0, 0));
+            g1[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go + 16u, 0, 0));
+            g8[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ag_rs, go + 32u, 0, 0));
         }
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
@@ -162,12 +169,13 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             q[8] = l[8] * inv;
             q[9] = __int_as_float(jj[t] >> p.shift);
             if (DATA) {
-                const float* dr = de.dl + (size_t)p.eid[e0 + k] * FGC_DL_LD;
-                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dr);
-                const f32x4 d1 = *reinterpret_cast<const f32x4*>(dr + 4);
+                const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(de.dl), 0, -1, 0x00020000);
+                const unsigned dof = __umul24((unsigned)p.eid[e0 + k], FGC_DL_LD * 4u);
+                const f32x4 d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof, 0, 0));
+                const f32x4 d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof + 16u, 0, 0));
                 dgsum[0] += d0[0]; dgsum[1] += d0[1]; dgsum[2] += d0[2]; dgsum[3] += d0[3];
                 dgsum[4] += d1[0]; dgsum[5] += d1[1]; dgsum[6] += d1[2]; dgsum[7] += d1[3];
-                dgsum[8] += dr[8];
+                dgsum[8] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dl_rs, dof + 32u, 0, 0));
             }
         }
         if (DATA) {  // dg_j = sum over in-edges of dl: reduce the 16 softmax lanes of the node
@@ -313,11 +321,13 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             constexpr int KS = KPASS / 32;
             const int ks0 = __builtin_amdgcn_readfirstlane(KS * kpart / kparts);
             const int ks1 = __builtin_amdgcn_readfirstlane(KS * (kpart + 1) / kparts);
-            const u32x4* Wp16 = reinterpret_cast<const u32x4*>(p.Wp);
             const char* zb = reinterpret_cast<const char*>(s.ztile);
+            const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, -1, 0x00020000);
+            const unsigned w_lane = (unsigned)((ct * 64 + lane) * 16);
+            const unsigned w_ks = (unsigned)(nct * 1024);                          // bytes per k-step
             auto loadb = [&](int ks) {
                 const int kk = min(ks, ks1 - 1);
-                return Wp16[((size_t)(pass * KS + kk) * nct + ct) * 64 + lane];
+                return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, (unsigned)(pass * KS + kk) * w_ks, 0));
             };
             auto mmb = [&](int ks, const u32x4& b) {
 #pragma unroll
@@ -337,10 +347,15 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             }
             if (ks < ks1) mmb(ks, b0);
         } else {
-            const size_t wrow0 = (size_t)pass * (KPASS >> 2);
+            // packed weights through a buffer descriptor: the lane's part of the offset is computed once, the k-group's part
+            // is scalar (the plain indexed form spent two 64-bit multiplies per fragment load on the vector ALU)
+            const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, -1, 0x00020000);
+            const unsigned w_lane = (unsigned)((lq * p.npad + ct * 16 + lr) * 16);
+            const unsigned w_kg = (unsigned)(p.npad * 64);                         // bytes per k-group (4 rows of float4)
+            const unsigned w_pass = (unsigned)pass * (unsigned)(KPASS >> 4) * w_kg;
             auto loadb = [&](int g) {
                 const int gg = min(g, kg1 - 1);
-                return Wp4[(wrow0 + gg * 4 + lq) * p.npad + ct * 16 + lr];
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, w_pass + (unsigned)gg * w_kg, 0));
             };
             auto loada = [&](int g, f32x4 (&a)[RT]) {
                 const int gg = min(g, kg1 - 1);
@@ -400,10 +415,13 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
     if (!DATA) {
         // thread -> (pooled row group, column): W8_THREADS is a multiple of every supported width, so a thread keeps its
         // column over the walk and the bias is read once
-        const int o = tid % p.nout, pstep = W8_THREADS / p.nout;
+        // (FAST: the width is 16, 32, 64 or 128: shifts instead of the ~40-instruction integer divisions)
+        const int osh = 31 - __builtin_clz(p.nout);
+        const bool pow2 = FAST && (p.nout & (p.nout - 1)) == 0;
+        const int o = pow2 ? (tid & (p.nout - 1)) : tid % p.nout, pstep = pow2 ? (W8_THREADS >> osh) : W8_THREADS / p.nout;
         const float bias_o = fe.bias[o];
         // (threads past the last whole row of columns sit out: widths that do not divide W8_THREADS)
-        for (int pr = tid < pstep * p.nout ? tid / p.nout : TILE; pr < TILE / 4; pr += pstep) {
+        for (int pr = tid < pstep * p.nout ? (pow2 ? tid >> osh : tid / p.nout) : TILE; pr < TILE / 4; pr += pstep) {
             float mx = -INFINITY;
             bool any = false;
 #pragma unroll
@@ -430,14 +448,16 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         const int nsrc = TILE / group;
         // thread -> (source row, input channel): the channel stays put over the walk (W8_THREADS is a multiple of every
         // supported width), so the 18 u / v entries of the logit term are read once per thread, not once per element
-        const int c = tid % de.cin, sstep = W8_THREADS / de.cin;
+        const int csh = 31 - __builtin_clz(de.cin);
+        const bool pow2 = FAST && (de.cin & (de.cin - 1)) == 0;
+        const int c = pow2 ? (tid & (de.cin - 1)) : tid % de.cin, sstep = pow2 ? (W8_THREADS >> csh) : W8_THREADS / de.cin;
         float uc[FGC_M], vc[FGC_M];
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) {
             uc[m] = de.u[m * de.cin + c];
             vc[m] = de.v[m * de.cin + c];
         }
-        for (int sr = tid < sstep * de.cin ? tid / de.cin : nsrc; sr < nsrc; sr += sstep) {
+        for (int sr = tid < sstep * de.cin ? (pow2 ? tid >> csh : tid / de.cin) : nsrc; sr < nsrc; sr += sstep) {
             float val = 0.f;
             bool any = false;
             for (int q = 0; q < group; ++q) {
