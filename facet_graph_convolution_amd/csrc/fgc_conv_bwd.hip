@@ -608,7 +608,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
         for (int nn = 0; nn < NPW; ++nn) {
             const int node = wave * NPW + nn;
             const int e = max(min(ebase + lr, dn[nn] - 1), 0);
-            rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]) : 0;
+            rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[(size_t)node * qnode_stride(QS) + e * QLD + 9]) : 0;
             dq[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int pass = 0; pass < p.passes; ++pass) {
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                     if (dn[nn] <= 16) continue;            // wave-uniform
                     const int node = wave * NPW + nn;
                     const int e = min(16 + lr, dn[nn] - 1);
-                    const int row = __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]);
+                    const int row = __float_as_int(s.qbuf[(size_t)node * qnode_stride(QS) + e * QLD + 9]);
                     const unsigned off = __umul24((unsigned)row, rowbytes) + laneoff;
                     const f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                     const f32x4 x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64u, 0, 0));
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
             for (int et = 0; et < ntile; ++et) {
                 const int edge = ebase + 16 * et + lr;
                 const bool ok = edge < d;
-                const float* qr = s.qbuf + ((size_t)node * QS + min(edge, d - 1)) * QLD;
+                const float* qr = s.qbuf + (size_t)node * qnode_stride(QS) + min(edge, d - 1) * QLD;
                 f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
                 else if (lq == 2) q[0] = qr[8];
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreP
         const int node = wave * NPW + nn;
         dn[nn] = __builtin_amdgcn_readfirstlane(min(s.deg[node], KMAX));
         const int e = max(min(lr, dn[nn] - 1), 0);
-        rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]) : 0;
+        rowid[nn] = dn[nn] > 0 ? __float_as_int(s.qbuf[(size_t)node * qnode_stride(QS) + e * QLD + 9]) : 0;
         dq[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int mrow = lr < FGC_M ? lr : FGC_M - 1;  // rows 9..15 of the product are never read
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreP
             if constexpr (LONG) {
                 if (dn[nn] > 16) {                      // wave-uniform: edge slots 16..23
                     const int e = min(16 + lr, dn[nn] - 1);
-                    const int row = __float_as_int(s.qbuf[((size_t)node * QS + e) * QLD + 9]);
+                    const int row = __float_as_int(s.qbuf[(size_t)node * qnode_stride(QS) + e * QLD + 9]);
                     const u32x4 x1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                    rsrc, __umul24((unsigned)row, rowbytes) + laneoff, 0, 0));
                     dq_hi[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreP
         for (int et = 0; et < ntile; ++et) {
             const int edge = 16 * et + lr;
             const bool ok = edge < d;
-            const float* qr = s.qbuf + ((size_t)node * QS + min(edge, d - 1)) * QLD;
+            const float* qr = s.qbuf + (size_t)node * qnode_stride(QS) + min(edge, d - 1) * QLD;
             f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
             if (lq < 2) q = *reinterpret_cast<const f32x4*>(qr + 4 * lq);
             else if (lq == 2) q[0] = qr[8];

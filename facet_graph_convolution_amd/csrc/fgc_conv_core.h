@@ -27,6 +27,10 @@ constexpr int TILE = 32;        // nodes per workgroup
 #endif
 constexpr int KMAX = FGC_KMAX;  // >= K_faces (23) edge slots per node kept in LDS
 constexpr int QLD = 12;         // floats per edge in qbuf: q[0..8], [9] = source row of the neighbour (int bits)
+// floats between the q tables of consecutive nodes.  With 16 slots the plain stride (16 * 12 floats = 768 B) is a multiple
+// of the 256-byte bank row: the two nodes a ds_read_b128 lane group spans read the same banks (2-way conflict on every q
+// read of the aggregation phase, three per edge slot).  Four floats of padding move the second node one 16-byte slot on.
+constexpr int qnode_stride(int qslots) { return qslots * QLD + (qslots == 16 ? 4 : 0); }
 constexpr int NTHREADS = 256;
 constexpr int MAX_NPAD = 128;   // GEMM N limit (cout / cin of the transposed op)
 
@@ -83,14 +87,14 @@ __device__ __forceinline__ Smem carve(char* base, int zstride, int qslots = KMAX
     s.ztile = reinterpret_cast<float*>(base);
     size_t off = (size_t)TILE * zstride * 4;
     s.qbuf = reinterpret_cast<float*>(base + off);
-    off += (size_t)TILE * qslots * QLD * 4;
+    off += (size_t)TILE * qnode_stride(qslots) * 4;
     s.deg = reinterpret_cast<int*>(base + off);
     off += (2 * TILE + 4) * 4;
     s.extra = reinterpret_cast<float*>(base + off);
     return s;
 }
 static inline size_t smem_core_bytes(int zstride, int qslots = KMAX) {
-    return (size_t)TILE * zstride * 4 + (size_t)TILE * qslots * QLD * 4 + (2 * TILE + 4) * 4;
+    return (size_t)TILE * zstride * 4 + (size_t)TILE * qnode_stride(qslots) * 4 + (2 * TILE + 4) * 4;
 }
 
 // ---- phase S: per-edge soft assignment ------------------------------------------------------
@@ -166,7 +170,7 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
             sum += l[m];
         }
         const float inv = 1.0f / sum;
-        float* q = s.qbuf + ((size_t)node * QS + k) * QLD;
+        float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
         *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
         *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
         q[8] = l[8] * inv;

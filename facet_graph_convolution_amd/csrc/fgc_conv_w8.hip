@@ -112,7 +112,11 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             da1 = *reinterpret_cast<const f32x4*>(dr + 4);
             da8 = dr[8];
         }
-        if (kl == 0) s.deg[node] = d;
+        if (kl == 0) {
+            s.deg[node] = d;
+            // 1 / degree for the epilogue, divided once per node here instead of once per output element there
+            s.deg[TILE + 4 + node] = __float_as_int(d > 0 ? 1.0f / (float)d : 0.f);
+        }
         if (FAST) {  // largest degree among the 4 nodes of this wave, rounded up to a whole batch of 8 edge slots
             const int dmax = max(max(__builtin_amdgcn_readlane(d, 0), __builtin_amdgcn_readlane(d, 16)),
                                  max(__builtin_amdgcn_readlane(d, 32), __builtin_amdgcn_readlane(d, 48)));
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             const int k = kl + 16 * t;
             if (k >= d) {
                 if (FAST && k < dfill) {  // zero-weight slot pointing at a valid row
-                    float* q = s.qbuf + ((size_t)node * QS + k) * QLD;
+                    float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
                     *reinterpret_cast<f32x4*>(q) = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(q + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
                     q[8] = 0.f;
@@ -157,13 +161,14 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 #pragma unroll
             for (int m = 1; m < FGC_M; ++m) mx = fmaxf(mx, l[m]);
             float sum = 0.f;
+            const float nmx = -mx * 1.4426950408889634f;
 #pragma unroll
             for (int m = 0; m < FGC_M; ++m) {
-                l[m] = __expf(l[m] - mx);
+                l[m] = __builtin_amdgcn_exp2f(fmaf(l[m], 1.4426950408889634f, nmx));   // exp(l - mx): one fma + v_exp_f32
                 sum += l[m];
             }
             const float inv = 1.0f / sum;
-            float* q = s.qbuf + ((size_t)node * QS + k) * QLD;
+            float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
             *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
             *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
             q[8] = l[8] * inv;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 
     const int cl = kl;
     const int d = s.deg[node];
-    const float* qb = s.qbuf + (size_t)node * QS * QLD;
+    const float* qb = s.qbuf + (size_t)node * qnode_stride(QS);
     for (int pass = 0; pass < p.passes; ++pass) {
         // ---------------- phase A: z[m][2] = sum_k q[k][m] * x_j(k)[2]; every row is requested before the first FMA
         f32x2 z[FGC_M];
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         for (int pr = tid < pstep * p.nout ? (pow2 ? tid >> osh : tid / p.nout) : TILE; pr < TILE / 4; pr += pstep) {
             float mx = -INFINITY;
             bool any = false;
+            const size_t ybase = (size_t)(tile0 + pr * 4) * p.nout + o;   // (one 64-bit multiply for the four rows)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = pr * 4 + q;
@@ -433,11 +439,10 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 for (int kp = 0; kp < kparts; ++kp) val += otile[((size_t)kp * TILE + row) * oldd + o];
                 const int dd = s.deg[row];
                 // deg was clamped to KMAX for the edge loops; the true degree equals it here (host guarantees <= 24)
-                const float inv = dd > 0 ? 1.0f / (float)dd : 0.f;
-                val *= inv;
+                val *= __int_as_float(s.deg[TILE + 4 + row]);
                 if (!fe.bias_mask || dd > 0) val += bias_o;
                 if (fe.act) val = fmaxf(val, 0.f) - fe.alpha * fmaxf(-val, 0.f);
-                st_act(fe.y, (size_t)i * p.nout + o, val, BF);
+                st_act(fe.y, ybase + (size_t)(q * p.nout), val, BF);
                 mx = fmaxf(mx, val);
                 any = true;
             }
@@ -511,7 +516,7 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
                             160 * 1024);
         attr = true;
     }
-    smem -= (size_t)TILE * (KMAX - QS) * QLD * 4;     // the caller sized the tile for KMAX slots
+    smem -= (size_t)TILE * (qnode_stride(KMAX) - qnode_stride(QS)) * 4;     // the caller sized the tile for KMAX slots
     if (BF) smem -= (size_t)TILE * (ZSTRIDE * 4 - ZSTRIDE_BF * 2);   // ... and for the fp32 aggregate tile
     FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF>),
                dim3(core_grid(p)), dim3(W8_THREADS), smem, p, fe, de);
