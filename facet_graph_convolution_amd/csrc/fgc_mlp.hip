@@ -47,12 +47,14 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int n, 
 // hidden pre-activation slab for column tile ct: h[rt] (C layout: col = lane&15, row = rt*16 + (lane>>4)*4 + reg)
 // KG > 0: the number of 16-wide k groups is known at compile time (the loop unrolls and all fragment loads are issued
 // before the first MFMA); KG == 0: runtime kg
+// init: the bias of the slab's column (lane lr), which rides in the accumulator: one vector add per element less next to the
+// fp32 MFMAs, which share the SIMD with the vector ALU
 template <int RT, int KG = 0>
 __device__ __forceinline__ void hidden_slab(const float* xt, int xs, int kg, const f32x4* __restrict__ Wp4, int hidden,
-                                            int ct, f32x4 (&h)[RT]) {
+                                            int ct, f32x4 (&h)[RT], float init = 0.f) {
     const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RT; ++r) h[r] = f32x4{init, init, init, init};
     if constexpr (KG > 0) kg = KG;
 #pragma unroll KG > 0 ? KG : 1
     for (int g = 0; g < kg; ++g) {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(c
             for (int o = 0; o < CO; ++o) w2[o] = o < cout ? w2n[o] : 0.f;
             fetch_weights(ct + 4);
 #pragma unroll
-            for (int r = 0; r < MLP_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < MLP_RT; ++r) h[r] = f32x4{bb, bb, bb, bb};   // the bias rides in the accumulator
 #pragma unroll
             for (int g = 0; g < NB; ++g) {
                 f32x4 a[MLP_RT];
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(c
                         h[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], bcur[g][t], h[r], 0, 0, 0);
             }
         } else {
-            hidden_slab(xt, xs, kg, Wp4, hidden, ct, h);
             const int col = ct * 16 + lr;
             bb = b1[col];
+            hidden_slab(xt, xs, kg, Wp4, hidden, ct, h, bb);
 #pragma unroll
             for (int o = 0; o < CO; ++o) w2[o] = o < cout ? W2[(size_t)col * cout + o] : 0.f;
         }
@@ -148,8 +150,9 @@ __global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(c
         for (int r = 0; r < MLP_RT; ++r)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float v = h[r][t] + bb;
-                v = fmaxf(v, 0.f) - alpha * fmaxf(-v, 0.f);
+                float v = h[r][t];
+                v = fmaxf(v, alpha * v);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host): bit-identical to
+                                            // relu(v) - alpha relu(-v), one instruction less
 #pragma unroll
                 for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
             }
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
             __builtin_amdgcn_sched_barrier(0);
             const int ctl = wave * MLP_BWD_CTW + c;          // column tile within the workgroup's slice
             f32x4 h[BWD_RT];
-            hidden_slab<BWD_RT, FGC_MLP_BWD_KG(MLP_BWD_MT)>(xt, xs, kg, Ws4, WLD, ctl, h);
             const float bb = b1s[ctl * 16 + lr];
+            hidden_slab<BWD_RT, FGC_MLP_BWD_KG(MLP_BWD_MT)>(xt, xs, kg, Ws4, WLD, ctl, h, bb);
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(W2s + (ctl * 16 + lr) * 4);
             f32x4 dh[BWD_RT];
 #pragma unroll
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
                 for (int t = 0; t < 4; ++t) {
                     const int rr = r * 16 + lq * 4 + t;
                     const f32x4 dyr = *reinterpret_cast<const f32x4*>(dyt + rr * 4);
-                    const float pre = h[r][t] + bb;
-                    const float hact = fmaxf(pre, 0.f) - alpha * fmaxf(-pre, 0.f);
+                    const float pre = h[r][t];
+                    const float hact = fmaxf(pre, alpha * pre);   // (0 <= alpha <= 1, checked by the host)
                     // d lrelu: relu'(pre) + alpha*relu'(-pre), both 0 at pre == 0 (TF relu gradient)
                     const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
                     float g = 0.f;
@@ -531,6 +534,7 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
     FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_fwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_workspace_bytes(cin, hidden, cout),
                   "fgc_mlp_fwd: workspace too small");
+    FGC_CHECK_ARG(alpha >= 0.f && alpha <= 1.f, "fgc_mlp_fwd: alpha=%g outside [0,1] (the reference uses 0.1, model.py:846)", alpha);
     hipStream_t st = (hipStream_t)stream;
     const int kpad = mlp_kpad(cin);
     float* Wp = (float*)workspace;
@@ -562,6 +566,7 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 128, "fgc_mlp_bwd: n=%d cin=%d (cin must be in [1,128])", n, cin);
     FGC_CHECK_ARG(hidden > 0 && hidden % 256 == 0, "fgc_mlp_bwd: hidden=%d must be a multiple of 256", hidden);
     FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_bwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
+    FGC_CHECK_ARG(alpha >= 0.f && alpha <= 1.f, "fgc_mlp_bwd: alpha=%g outside [0,1] (the reference uses 0.1, model.py:846)", alpha);
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout),
                   "fgc_mlp_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                   fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));

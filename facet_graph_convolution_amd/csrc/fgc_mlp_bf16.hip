@@ -106,7 +106,7 @@ __global__ __launch_bounds__(MB_THREADS, 4) void mlp_fwd_bf16_kernel(const unsig
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = h[r][t];
-                v = fmaxf(v, 0.f) - alpha * fmaxf(-v, 0.f);
+                v = fmaxf(v, alpha * v);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host)
 #pragma unroll
                 for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
             }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float pre = h[r][t];
-                    const float hact = pre > 0.f ? pre : alpha * pre;
+                    const float hact = fmaxf(pre, alpha * pre);
                     const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
                     float g = 0.f;
 #pragma unroll
@@ -505,12 +505,17 @@ static int mlp_bf16_check(const char* who, const void* x, int n, int cin, int hi
     FGC_CHECK_ARG((uintptr_t)x % 16 == 0, "%s: x needs 16-byte alignment", who);
     return FGC_OK;
 }
+static int mlp_bf16_alpha(const char* who, float alpha) {
+    FGC_CHECK_ARG(alpha >= 0.f && alpha <= 1.f, "%s: alpha=%g outside [0,1] (the reference uses 0.1, model.py:846)", who, alpha);
+    return FGC_OK;
+}
 
 extern "C" int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
                                 const float* b1, const float* W2, const float* b2, float alpha, float* y,
                                 float* abs_partial, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = mlp_bf16_check("fgc_mlp_fwd_bf16", x, n, cin, hidden, cout);
     if (rc) return rc;
+    if ((rc = mlp_bf16_alpha("fgc_mlp_fwd_bf16", alpha))) return rc;
     FGC_CHECK_ARG(W1 && b1 && W2 && b2 && y, "fgc_mlp_fwd_bf16: null pointer");
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bf16_workspace_bytes(cin, hidden, cout) && (uintptr_t)workspace % 16 == 0,
                   "fgc_mlp_fwd_bf16: workspace too small or misaligned");
@@ -543,6 +548,7 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
                                 void* stream) {
     int rc = mlp_bf16_check("fgc_mlp_bwd_bf16", x, n, cin, hidden, cout);
     if (rc) return rc;
+    if ((rc = mlp_bf16_alpha("fgc_mlp_bwd_bf16", alpha))) return rc;
     FGC_CHECK_ARG(dy && W1 && b1 && W2 && dx && dW1 && db1 && dW2 && db2, "fgc_mlp_bwd_bf16: null pointer");
     FGC_CHECK_ARG((cin == 32 || cin == 64) && cout <= 3, "fgc_mlp_bwd_bf16: cin=%d cout=%d (cin 32 or 64, cout <= 3)", cin, cout);
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_bf16_workspace_bytes(n, cin, hidden, cout) &&
