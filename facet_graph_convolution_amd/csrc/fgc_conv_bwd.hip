@@ -1178,6 +1178,20 @@ __device__ __forceinline__ void tn_load(const float* __restrict__ A, int lda, in
     }
 }
 
+// Workgroup -> (output tile, node-range split) of the weight-gradient GEMMs.  Workgroups are dealt round-robin over the
+// 8 XCDs, each with a private L2.  With the plain (tile, split) grid the tiles of one split - which read the SAME rows of r
+// and x - land on different XCDs and every L2 fetches those rows from HBM again (dconv2: x came in ten times).  Here all
+// tiles of a split run on one XCD, next to each other in dispatch order: the rows are fetched once and the other tiles
+// hit in L2.  The grid is padded to 8 * ceil(splits / 8) splits; workgroups of a padding split return at once.
+// Same work per (tile, split), same slabs, same sums: results are unchanged bit for bit.
+__device__ __forceinline__ bool tn_block(int ntiles, int nsplits, int& tile, int& split) {
+    const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+    tile = idx % ntiles;
+    split = (idx / ntiles) * 8 + xcd;
+    return split < nsplits;
+}
+static inline dim3 tn_grid(int ntiles, int nsplits) { return dim3((unsigned)(ntiles * 8 * cdiv(nsplits, 8))); }
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, int P,
                                                       const float* __restrict__ x0, const float* __restrict__ x1,
@@ -1186,10 +1200,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     __shared__ float red[4][64][65];
     const int Q = c0 + c1;
     const int npt = (P + 63) >> 6;
-    const int pt = blockIdx.x % npt, qt = blockIdx.x / npt;
+    int tile_id, split_id;
+    if (!tn_block(npt * ((Q + 63) >> 6), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id)) return;
+    const int pt = tile_id % npt, qt = tile_id / npt;
     const int p0 = pt * 64, q0 = qt * 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_begin = split_id * rows_per_split;
     const int r_end = min(rows, r_begin + rows_per_split);
     const int nsteps = (r_end - r_begin + 3) >> 2;
     const int pbase = p0 + 4 * lr, qbase = q0 + 4 * lr;
@@ -1227,7 +1243,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < 4; ++t) red[wave][4 * (lq * 4 + t) + i][4 * lr + j] = acc[i][j][t];
     __syncthreads();
-    float* out = slab + (size_t)blockIdx.y * P * Q;
+    float* out = slab + (size_t)split_id * P * Q;
     for (int t = tid; t < 64 * 64; t += 256) {
         const int pp = t >> 6, qq = t & 63;
         if (p0 + pp < P && q0 + qq < Q)
@@ -1255,11 +1271,13 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     __shared__ float red[2][64][65];
     const int Q = c0 + c1;
     const int npt = (P + 63) >> 6;
-    const int pt = blockIdx.x % npt, qt = blockIdx.x / npt;
+    int tile_id, split_id;
+    if (!tn_block(npt * ((Q + 16 * NJ - 1) / (16 * NJ)), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id)) return;
+    const int pt = tile_id % npt, qt = tile_id / npt;
     const int p0 = pt * 64, q0 = qt * (16 * NJ);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_begin = split_id * rows_per_split;
     const int r_end = min(rows, r_begin + rows_per_split);
     const int nsteps = (r_end - r_begin + 3) >> 2;
     // column quads of this lane, clamped into the operands (results of clamped columns are never stored)
@@ -1354,7 +1372,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
     if (wave == 0) put(0);
     if (wave == 2) put(1);
     __syncthreads();
-    float* out = slab + (size_t)blockIdx.y * P * Q;
+    float* out = slab + (size_t)split_id * P * Q;
     for (int t = tid; t < 64 * 16 * NJ; t += 256) {
         const int pp = t / (16 * NJ), qq = t % (16 * NJ);
         if (p0 + pp < P && q0 + qq < Q) out[(size_t)(p0 + pp) * Q + q0 + qq] = red[0][pp][qq] + red[1][pp][qq];
@@ -1403,12 +1421,14 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsi
     __shared__ __attribute__((aligned(16))) char Xs[2][32 * XS];
     const int Q = c0 + c1;
     const int npc = (P + TNB_PC - 1) / TNB_PC;
-    const int pc = blockIdx.x % npc, qc = blockIdx.x / npc;
+    int tile_id, split_id;
+    if (!tn_block(npc * (Q / QC), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id)) return;
+    const int pc = tile_id % npc, qc = tile_id / npc;
     const int p0 = pc * TNB_PC, q0 = qc * QC;
     const int pw = min(P - p0, TNB_PC);                              // valid columns of A here (a multiple of 8)
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r_begin = blockIdx.y * rows_per_split;
+    const int r_begin = split_id * rows_per_split;
     const int r_end = min(rows, r_begin + rows_per_split);
     const int nchunks = (r_end - r_begin + 31) >> 5;
 
@@ -1473,7 +1493,7 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsi
         __syncthreads();
     }
     // C layout: column = lr -> q, row = 4*lq + reg -> p
-    float* out = slab + (size_t)blockIdx.y * P * Q;
+    float* out = slab + (size_t)split_id * P * Q;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -1494,11 +1514,11 @@ static bool tn_bf16_ok(int P, int c0, int c1) {
 int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,
                           int rows_per_split, int nsplits, float* slab, hipStream_t st) {
     if (c0 <= 32 && c0 % 2 == 0) {
-        const dim3 grid(cdiv(P, 64), nsplits);
+        const dim3 grid = tn_grid(cdiv(P, 64), nsplits);
         FGC_LAUNCH(tag, st, gemm_tn_stream_kernel<2>, grid, dim3(256), 0, A, lda, P, x0, (const float*)nullptr, c0, 0, 0, rows,
                    rows_per_split, slab);
     } else {
-        const dim3 grid(cdiv(P, 64) * cdiv(c0, 64), nsplits);
+        const dim3 grid = tn_grid(cdiv(P, 64) * cdiv(c0, 64), nsplits);
         FGC_LAUNCH(tag, st, gemm_tn_stream_kernel<4>, grid, dim3(256), 0, A, lda, P, x0, (const float*)nullptr, c0, 0, 0, rows,
                    rows_per_split, slab);
     }
@@ -1506,13 +1526,26 @@ int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const
     return FGC_OK;
 }
 
+static int tn_rows_per_slab(int n, int splits) { return cdiv(cdiv(n, splits), 4) * 4; }
+
+// A split count near `desired` (at most `maxs`) whose EFFECTIVE number of slabs is a multiple of 8: tn_block gives every
+// XCD the slabs s = xcd, xcd + 8, ...; with 27 slabs two XCDs would work through four of them and six through three.
+int tn_balanced_splits(int desired, int maxs, int rows) {
+    desired = std::max(1, std::min(desired, maxs));
+    for (int delta = 0; delta < 24; ++delta)
+        for (int sgn = 1; sgn >= -1; sgn -= 2) {
+            const int s = desired + sgn * delta;
+            if (s >= 8 && s <= maxs && cdiv(rows, tn_rows_per_slab(rows, s)) % 8 == 0) return s;
+        }
+    return desired;
+}
+
+// An XCD has 32 CUs x 4 resident workgroups of these kernels = 128 slots and is given tiles x (slabs / 8) workgroups:
+// as many slabs as fill those slots once (a count just above 96 or 128 leaves a few CUs with one workgroup more than the
+// rest, and the launch waits for them).
 static int tn_splits(int P, int Q, int rows) {
     const int tiles = cdiv(P, 64) * cdiv(Q, 64);
-    int s = 768 / tiles;
-    const int maxs = cdiv(rows, 256);
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
-    return s;
+    return tn_balanced_splits(8 * std::max(1, 128 / tiles), cdiv(rows, 128), rows);
 }
 
 struct BwdWorkspace {
@@ -1552,7 +1585,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
         // the bf16 kernel's workgroups own up to 320 x 64 of the product: one or two per CU in all
         static const int target = getenv("FGC_TNB_WGS") ? atoi(getenv("FGC_TNB_WGS")) : 256;   // (developer knob)
         const int tiles = cdiv(FGC_M * d->cout + 24, TNB_PC) * cdiv(cin, 64);
-        w.splitW = std::max(1, std::min(target / tiles, cdiv(d->n, 256)));
+        w.splitW = tn_balanced_splits(target / tiles, cdiv(d->n, 256), d->n);
     }
     w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
     w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
@@ -1561,8 +1594,6 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.bytes = off;
     return w;
 }
-
-static int tn_rows_per_slab(int n, int splits) { return cdiv(cdiv(n, splits), 4) * 4; }
 
 // the five fixed-order sums behind a layer's parameter gradients (slabs of the weight-gradient GEMM, db and dc partials)
 static void conv_param_jobs(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, const BwdWorkspace& w, RedJob* jobs) {
@@ -1816,26 +1847,26 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const int P = FGC_M * cout, PL = P + 24;
         const int rps = tn_rows_per_slab(d->n, w.splitW);
         const int ns = cdiv(d->n, rps);
-        const dim3 g1(cdiv(PL, 64) * cdiv(cin, 64), ns);
+        const dim3 g1 = tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
         if (bf16 && tn_bf16_ok(PL, d->c0, d->c1)) {
             const unsigned short* r16 = (const unsigned short*)io->r;
             const unsigned short *h0 = (const unsigned short*)d->x0, *h1 = (const unsigned short*)d->x1;
             const int npc = cdiv(PL, TNB_PC);
             if (cin % 64 == 0)
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<4>), dim3(npc * (cin / 64), ns), dim3(TNB_THREADS), 0, r16, PL,
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<4>), tn_grid(npc * (cin / 64), ns), dim3(TNB_THREADS), 0, r16, PL,
                            PL, h0, h1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
             else
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<2>), dim3(npc * (cin / 32), ns), dim3(TNB_THREADS), 0, r16, PL,
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<2>), tn_grid(npc * (cin / 32), ns), dim3(TNB_THREADS), 0, r16, PL,
                            PL, h0, h1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
         } else if (bf16 && cin <= 32 && d->c1 == 0)
-            FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<2, true>), dim3(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL,
+            FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<2, true>), tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL,
                        PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else if (bf16)
             FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<4, true>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                        d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else if (stream_ok && cin <= 32 && d->c1 == 0)
-            FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, dim3(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
+            FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
                        d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
         else if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<4>, g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
                                   d->c0, d->c1, d->shift, d->n, rps, w.slab);

@@ -24,6 +24,7 @@ int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
                       int nb_db, int parts, RedJob* jobs_out, hipStream_t st);
 
 // streaming TN GEMM (fgc_conv_bwd.hip): slab[split][P][c0] = A[rows of the split, P]^T x0[rows of the split, c0]
+int tn_balanced_splits(int desired, int maxs, int rows);   // slab count of a weight-gradient GEMM, XCD-balanced
 int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,
                           int rows_per_split, int nsplits, float* slab, hipStream_t st);
 

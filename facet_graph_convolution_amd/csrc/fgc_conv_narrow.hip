@@ -590,10 +590,7 @@ size_t narrow_bwd_floats(const fgc_conv_desc* d) {
 }
 
 int narrow_splits(const fgc_conv_desc* d) {
-    int s = 768 / cdiv(d->cout, 64);
-    const int maxs = cdiv(d->n, 256);
-    if (s > maxs) s = maxs;
-    return s < 1 ? 1 : s;
+    return tn_balanced_splits(768 / cdiv(d->cout, 64), cdiv(d->n, 256), d->n);
 }
 
 // stage 2 of the first layer's backward: everything except db (stage 1 left its partials) and the final sums

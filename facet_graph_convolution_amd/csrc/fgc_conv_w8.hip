@@ -13,6 +13,12 @@
 
 namespace fgc {
 
+// developer knock-outs for phase timing (results are wrong with any bit set; never set in the shipped build):
+// 1 = no MFMA instructions (operand loads kept), 2 = no aggregation FMAs (gathers kept), 4 = no soft-assignment math,
+// 8 = no matrix phase at all (barriers kept), 16 = no row gathers, 32 = no output epilogue, 64 = no logit-row gathers
+#ifndef FGC_KO
+#define FGC_KO 0
+#endif
 constexpr int W8_THREADS = 512;
 constexpr int W8_LPN = 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -54,6 +60,49 @@ __device__ __forceinline__ void edge_batch(__amdgpu_buffer_rsrc_t rsrc, unsigned
     }
 }
 
+// PIPE form (FAST, 16 slots): the rows of a pass are requested one phase ahead of their FMAs - pass 0 together with the
+// logit rows of the soft assignment, pass p + 1 before the matrix phase of pass p - so that a tile's chain of dependent
+// memory round trips is rowptr -> col -> (logit rows | rows of pass 0) instead of one more trip per 8-slot batch and
+// pass.  Slots [T0, T0 + N) of one node; `raw` holds the rows as loaded (fp32 pair, or one dword of two bf16).
+template <int T0, int N, bool BF>
+__device__ __forceinline__ void gather_rows(__amdgpu_buffer_rsrc_t rsrc, unsigned rowbytes, unsigned laneoff,
+                                            const float* qb, f32x2 (&raw)[16]) {
+    unsigned rid[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) rid[t] = (unsigned)__float_as_int(qb[(T0 + t) * QLD + 9]);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const unsigned off = __umul24(rid[t], rowbytes) + laneoff;
+        if (FGC_KO & 16) { raw[T0 + t] = f32x2{__uint_as_float(off), 1.f}; continue; }
+        if constexpr (BF) raw[T0 + t][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        else raw[T0 + t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    }
+}
+template <int T0, int N, bool BF>
+__device__ __forceinline__ void fma_rows(const float* qb, const f32x2 (&raw)[16], f32x2 (&z)[FGC_M]) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const float* qk = qb + (T0 + t) * QLD;
+        f32x2 xv;
+        if constexpr (BF) xv = bf2_to_f2(__builtin_bit_cast(unsigned, raw[T0 + t][0]));
+        else xv = raw[T0 + t];
+        if (FGC_KO & 2) { z[t % FGC_M] += xv; continue; }
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(qk + 4);
+        const float q8 = qk[8];
+        z[0] += q0[0] * xv; z[1] += q0[1] * xv; z[2] += q0[2] * xv; z[3] += q0[3] * xv;
+        z[4] += q1[0] * xv; z[5] += q1[1] * xv; z[6] += q1[2] * xv; z[7] += q1[3] * xv;
+        z[8] += q8 * xv;
+    }
+}
+// the 16 lanes that write and read a node's q table sit in one wave, whose LDS accesses execute in order: ordering the
+// compiler is all that is needed between the soft-assignment and the aggregation phase (no s_barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // FAST: every pass gathers 32 valid channels from ONE source (cg % 32 == 0 and the concat boundary on a pass boundary:
 // all network layers except conv1).  Then the edge loop is branch-free: qbuf is padded with zero-weight edges up to
 // the wave's largest degree rounded up to 8, all lanes run the same (scalar) trip count, rows are fetched with
@@ -70,11 +119,47 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS);
     constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
+    constexpr bool PIPE = FAST && QS == 16;            // rows requested one phase ahead (gather_rows / fma_rows)
     float* dagt = s.extra;  // DATA: [TILE][24]
     const int tile0 = block_tile0(p);
     const int tid = threadIdx.x;
     const int node = tid >> 4, kl = tid & 15;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    // ---------------- MFMA tiling: wave w owns column tile (w % nct) and k-part (w / nct)
+    const int nct = p.npad >> 4;              // 1, 2, 4 or 8
+    const int nsh = 31 - __builtin_clz(nct);
+    const int kparts = 8 >> nsh;
+    const int ct = __builtin_amdgcn_readfirstlane(wave & (nct - 1));
+    const int kpart = __builtin_amdgcn_readfirstlane(wave >> nsh);
+    // units of the reduction index per pass: 16-deep k-groups (fp32, four MFMAs deep) or 32-deep k-steps (bf16)
+    constexpr int UPP = BF ? KPASS / 32 : KPASS / 16;
+    const int u0 = __builtin_amdgcn_readfirstlane((UPP * kpart) >> (3 - nsh));
+    const int u1 = __builtin_amdgcn_readfirstlane((UPP * (kpart + 1)) >> (3 - nsh));
+    // packed weights through a buffer descriptor: the lane's part of the offset is computed once, the unit's part is
+    // scalar (the plain indexed form spent two 64-bit multiplies per fragment load on the vector ALU)
+    //   fp32: [unit][4 rows of float4: lq][npad columns]     bf16: [unit][column tile][lane] x 8 bf16
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, -1, 0x00020000);
+    const unsigned w_lane = BF ? (unsigned)((ct * 64 + lane) * 16) : (unsigned)((lq * p.npad + ct * 16 + lr) * 16);
+    const unsigned w_unit = BF ? (unsigned)(nct * 1024) : (unsigned)(p.npad * 64);
+    auto loadw = [&](int pass, int u) {
+        const int uu = min(u, u1 - 1);
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, (unsigned)(pass * UPP + uu) * w_unit, 0));
+    };
+    f32x2 xa[16];                                      // PIPE: the rows in flight
+    const float* qb = s.qbuf + (size_t)node * qnode_stride(QS);
+    // PIPE: request this lane's two channels of the node's neighbour rows for a pass (slots 0-7, and 8-11 / 12-15 when
+    // a node of the wave has that many edges; every slot of the table holds a valid row id)
+    auto issue = [&](int pass, int dw) {
+        constexpr unsigned ESZ = BF ? 2u : 4u;
+        const bool first = pass * KC < p.c0;                                   // wave-uniform
+        const float* base = first ? p.src0 : p.src1;
+        const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * ESZ;
+        const unsigned laneoff = (unsigned)(pass * KC + 2 * kl - (first ? 0 : p.c0)) * ESZ;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+        gather_rows<0, 8, BF>(rsrc, rowbytes, laneoff, qb, xa);
+        if (dw > 8) gather_rows<8, 4, BF>(rsrc, rowbytes, laneoff, qb, xa);
+        if (dw > 12) gather_rows<12, 4, BF>(rsrc, rowbytes, laneoff, qb, xa);
+    };
 
     // ---------------- phase S: per-edge soft assignment (edges kl and kl + 16 of this thread's node)
     int dwave = 0;  // FAST: wave-uniform trip count of the edge loop
@@ -136,20 +221,28 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
             const unsigned go = __umul24((unsigned)(jj[t] >> p.ag_shift), FGC_AG_LD * 4u) + (unsigned)p.nbr_off * 4u;
+            if (FGC_KO & 64) { g0[t] = g1[t] = f32x4{__uint_as_float(go), 0.f, 1.f, 2.f}; g8[t] = 0.f; continue; }
             g0[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go, 0, 0));
             g1[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go + 16u, 0, 0));
             g8[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ag_rs, go + 32u, 0, 0));
+        }
+        if constexpr (PIPE) {
+            // the row ids go to the table first (slots past the degree: row 0 with weight zero), and the rows of pass 0
+            // leave right behind the logit rows
+            s.qbuf[(size_t)node * qnode_stride(QS) + kl * QLD + 9] = __int_as_float(jj[0] >> p.shift);
+            wave_lds_sync();
+            issue(0, dwave);
         }
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
             if (k >= d) {
-                if (FAST && k < dfill) {  // zero-weight slot pointing at a valid row
+                if (FAST && (PIPE || k < dfill)) {  // zero-weight slot pointing at a valid row
                     float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
                     *reinterpret_cast<f32x4*>(q) = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(q + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
                     q[8] = 0.f;
-                    q[9] = __int_as_float(0);
+                    if (!PIPE) q[9] = __int_as_float(0);
                 }
                 continue;
             }
@@ -158,6 +251,13 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             l[4] = ctr[4] + g1[t][0]; l[5] = ctr[5] + g1[t][1]; l[6] = ctr[6] + g1[t][2]; l[7] = ctr[7] + g1[t][3];
             l[8] = ctr[8] + g8[t];
             float mx = l[0];
+            if (FGC_KO & 4) {
+                float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
+                *reinterpret_cast<f32x4*>(q) = f32x4{l[0], l[1], l[2], l[3]};
+                *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4], l[5], l[6], l[7]};
+                q[8] = l[8];
+                continue;
+            }
 #pragma unroll
             for (int m = 1; m < FGC_M; ++m) mx = fmaxf(mx, l[m]);
             float sum = 0.f;
@@ -172,7 +272,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
             *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
             q[8] = l[8] * inv;
-            q[9] = __int_as_float(jj[t] >> p.shift);
+            if (!PIPE) q[9] = __int_as_float(jj[t] >> p.shift);
             if (DATA) {
                 const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(de.dl), 0, -1, 0x00020000);
                 const unsigned dof = __umul24((unsigned)p.eid[e0 + k], FGC_DL_LD * 4u);
@@ -229,17 +329,9 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
             }
         }
     }
-    __syncthreads();
+    if constexpr (PIPE) wave_lds_sync();      // a node's table is written and read by the 16 lanes of one wave
+    else __syncthreads();
 
-    // ---------------- MFMA tiling: wave w owns column tile (w % nct) and k-part (w / nct)
-    const int nct = p.npad >> 4;              // 1, 2, 4 or 8
-    const int kparts = 8 / nct;
-    const int ct = __builtin_amdgcn_readfirstlane(wave % nct);
-    const int kpart = __builtin_amdgcn_readfirstlane(wave / nct);
-    const int kg_total = KPASS >> 4;
-    const int kg0 = __builtin_amdgcn_readfirstlane(kg_total * kpart / kparts);
-    const int kg1 = __builtin_amdgcn_readfirstlane(kg_total * (kpart + 1) / kparts);
-    const f32x4* Wp4 = reinterpret_cast<const f32x4*>(p.Wp);
     f32x4 acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -247,14 +339,19 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
 
     const int cl = kl;
     const int d = s.deg[node];
-    const float* qb = s.qbuf + (size_t)node * qnode_stride(QS);
-    for (int pass = 0; pass < p.passes; ++pass) {
+    auto do_pass = [&](int pass) {
         // ---------------- phase A: z[m][2] = sum_k q[k][m] * x_j(k)[2]; every row is requested before the first FMA
         f32x2 z[FGC_M];
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) z[m] = f32x2{0.f, 0.f};
         const int cbase = pass * KC + 2 * cl;
-        if (FAST) {
+        if constexpr (PIPE) {
+            fma_rows<0, 8, BF>(qb, xa, z);
+            if (dwave > 8) fma_rows<8, 4, BF>(qb, xa, z);
+            if (dwave > 12) fma_rows<12, 4, BF>(qb, xa, z);
+            // the next pass' rows travel under this pass' matrix phase
+            if (pass + 1 < p.passes) issue(pass + 1, dwave);
+        } else if (FAST) {
             const bool first = pass * KC < p.c0;                                   // wave-uniform
             const float* base = first ? p.src0 : p.src1;
             constexpr unsigned ESZ = BF ? 2u : 4u;                                  // bytes per stored channel
@@ -306,7 +403,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
                 for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(rr + m * p.cg) = z[m];
                 }
             }
-            if (!want_gemm) continue;
+            if (!want_gemm) return;
         }
         if (pass > 0) __syncthreads();  // previous pass' MFMA reads of ztile are done
         if constexpr (BF) {
@@ -320,91 +417,77 @@ __global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, Fw
         }
         __syncthreads();
         // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
-        if constexpr (BF) {
-            // nine 32-deep k-steps per pass, split over the wave's k-part; B fragment = 8 bf16 per lane out of the
-            // packed operand [pass][k-step][column tile][lane], A fragment = one ds_read_b128 per row tile
-            constexpr int KS = KPASS / 32;
-            const int ks0 = __builtin_amdgcn_readfirstlane(KS * kpart / kparts);
-            const int ks1 = __builtin_amdgcn_readfirstlane(KS * (kpart + 1) / kparts);
-            const char* zb = reinterpret_cast<const char*>(s.ztile);
-            const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, -1, 0x00020000);
-            const unsigned w_lane = (unsigned)((ct * 64 + lane) * 16);
-            const unsigned w_ks = (unsigned)(nct * 1024);                          // bytes per k-step
-            auto loadb = [&](int ks) {
-                const int kk = min(ks, ks1 - 1);
-                return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, (unsigned)(pass * KS + kk) * w_ks, 0));
-            };
-            auto mmb = [&](int ks, const u32x4& b) {
+        if (FGC_KO & 8) return;
+        // A fragments: one ds_read_b128 per row tile (fp32: 4 k of a 16-deep group, bf16: 8 k of a 32-deep step)
+        auto loada = [&](int g, f32x4 (&a)[RT]) {
+            const int gg = min(g, u1 - 1);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * ZSTRIDE + gg * 16 + lq * 4);
+        };
+        auto mm = [&](const f32x4 (&a)[RT], const u32x4& bw) {
+            const f32x4 b = __builtin_bit_cast(f32x4, bw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    const u32x4 a = *reinterpret_cast<const u32x4*>(zb + (size_t)(r * 16 + lr) * (ZSTRIDE_BF * 2) + ks * 64 + lq * 16);
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                                    acc[r], 0, 0, 0);
+                    if (FGC_KO & 1) asm volatile("" ::"v"(a[r][t]), "v"(b[t]));
+                    else acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r], 0, 0, 0);
                 }
-            };
-            u32x4 b0 = loadb(ks0), b1 = loadb(ks0 + 1);
-            int ks = ks0;
-            for (; ks + 2 <= ks1; ks += 2) {
-                mmb(ks, b0);
-                b0 = loadb(ks + 2);
-                mmb(ks + 1, b1);
-                b1 = loadb(ks + 3);
+        };
+        const char* zb = reinterpret_cast<const char*>(s.ztile);
+        auto mmb = [&](int ks, const u32x4& b) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(zb + (size_t)(r * 16 + lr) * (ZSTRIDE_BF * 2) + ks * 64 + lq * 16);
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                acc[r], 0, 0, 0);
             }
-            if (ks < ks1) mmb(ks, b0);
+        };
+        if constexpr (BF) {
+            // nine 32-deep k-steps per pass, split over the wave's k-part
+            int ks = u0;
+            u32x4 b0 = loadw(pass, ks), b1 = loadw(pass, ks + 1);
+            for (; ks + 2 <= u1; ks += 2) {
+                mmb(ks, b0);
+                b0 = loadw(pass, ks + 2);
+                mmb(ks + 1, b1);
+                b1 = loadw(pass, ks + 3);
+            }
+            if (ks < u1) mmb(ks, b0);
         } else {
-            // packed weights through a buffer descriptor: the lane's part of the offset is computed once, the k-group's part
-            // is scalar (the plain indexed form spent two 64-bit multiplies per fragment load on the vector ALU)
-            const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, -1, 0x00020000);
-            const unsigned w_lane = (unsigned)((lq * p.npad + ct * 16 + lr) * 16);
-            const unsigned w_kg = (unsigned)(p.npad * 64);                         // bytes per k-group (4 rows of float4)
-            const unsigned w_pass = (unsigned)pass * (unsigned)(KPASS >> 4) * w_kg;
-            auto loadb = [&](int g) {
-                const int gg = min(g, kg1 - 1);
-                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, w_pass + (unsigned)gg * w_kg, 0));
-            };
-            auto loada = [&](int g, f32x4 (&a)[RT]) {
-                const int gg = min(g, kg1 - 1);
-#pragma unroll
-                for (int r = 0; r < RT; ++r)
-                    a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * ZSTRIDE + gg * 16 + lq * 4);
-            };
-            auto mm = [&](const f32x4 (&a)[RT], const f32x4& b) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < RT; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r], 0, 0, 0);
-            };
-            f32x4 b0 = loadb(kg0), b1 = loadb(kg0 + 1), b2 = loadb(kg0 + 2), b3 = loadb(kg0 + 3);
+            int g = u0;
+            u32x4 b0 = loadw(pass, g), b1 = loadw(pass, g + 1), b2 = loadw(pass, g + 2), b3 = loadw(pass, g + 3);
             f32x4 a0[RT], a1[RT];
-            int g = kg0;
             loada(g, a0);
-            for (; g + 4 <= kg1; g += 4) {
+            for (; g + 4 <= u1; g += 4) {
                 loada(g + 1, a1);
                 mm(a0, b0);
-                b0 = loadb(g + 4);
+                b0 = loadw(pass, g + 4);
                 loada(g + 2, a0);
                 mm(a1, b1);
-                b1 = loadb(g + 5);
+                b1 = loadw(pass, g + 5);
                 loada(g + 3, a1);
                 mm(a0, b2);
-                b2 = loadb(g + 6);
+                b2 = loadw(pass, g + 6);
                 loada(g + 4, a0);
                 mm(a1, b3);
-                b3 = loadb(g + 7);
+                b3 = loadw(pass, g + 7);
             }
-            if (g < kg1) {
+            if (g < u1) {
                 loada(g + 1, a1);
                 mm(a0, b0);
             }
-            if (g + 1 < kg1) {
+            if (g + 1 < u1) {
                 loada(g + 2, a0);
                 mm(a1, b1);
             }
-            if (g + 2 < kg1) mm(a0, b2);
+            if (g + 2 < u1) mm(a0, b2);
         }
-    }
+    };
+    for (int pass = 0; pass < p.passes; ++pass) do_pass(pass);
     if (!want_gemm) return;
+    if (FGC_KO & 32) { if (acc[0][0] == 123.f && acc[RT - 1][3] == 5.f) s.ztile[tid] = acc[0][1]; return; }
     __syncthreads();
     // ---------------- accumulators -> LDS (aliases ztile), k-parts summed in fixed order by the epilogue
     const int oldd = p.npad + 4;
