@@ -154,4 +154,15 @@ static inline ConvGeom conv_geom(int cin, int cout) {
     return g;
 }
 
+// leaky ReLU for 0 <= alpha <= 1 as max(v, alpha v) in two instructions.  fmaxf (and v_med3 with +inf, which the
+// compiler folds back into it) puts a canonicalising v_max_f32(v, v) in front of the maximum because it cannot see that
+// an MFMA result is never a signalling NaN: a third vector instruction per hidden activation next to the fp32 MFMAs.
+// Same value as fmaxf(v, alpha * v) for every non-NaN input.
+__device__ __forceinline__ float lrelu01(float v, float alpha) {
+    const float av = alpha * v;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(av));
+    return r;
+}
+
 }  // namespace fgc

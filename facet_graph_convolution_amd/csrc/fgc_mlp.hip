@@ -151,7 +151,7 @@ __global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(c
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = h[r][t];
-                v = fmaxf(v, alpha * v);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host): bit-identical to
+                v = lrelu01(v, alpha);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host): bit-identical to
                                             // relu(v) - alpha relu(-v), one instruction less
 #pragma unroll
                 for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
@@ -243,8 +243,11 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
     float* dyt = xt + BWD_T * xs;                                   // [BWD_T][4]
     float* dht = dyt + BWD_T * 4;                                   // [4 waves][BWD_T][MLP_DHS]
     float* dxp = dht + 4 * BWD_T * MLP_DHS;                              // [4 waves][BWD_T][kpad+4]  ([1][..] when MT > 2)
-    float* Ws = dxp + (MLP_BWD_MT <= 2 ? 4 : 1) * BWD_T * (KP + MLP_XPAD) + 3;  // [KP/4][WLD][4], 16-byte aligned below
-    Ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Ws)) & ~(uintptr_t)15);
+    // [KP/4][WLD][4]; every region before it is a multiple of four floats, so it is 16-byte aligned as it stands (an
+    // integer round trip to align the pointer hides from the compiler that this is LDS: every access to the weight slice
+    // became a FLAT load that waits on both the memory and the LDS counter)
+    static_assert((BWD_T * xs) % 4 == 0 && (4 * BWD_T * MLP_DHS) % 4 == 0 && (BWD_T * (KP + MLP_XPAD)) % 4 == 0, "LDS carve alignment");
+    float* Ws = dxp + (MLP_BWD_MT <= 2 ? 4 : 1) * BWD_T * (KP + MLP_XPAD);
     float* b1s = Ws + (KP / 4) * WLD * 4;                           // [HCW]
     float* W2s = b1s + HCW;                                         // [HCW][4]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
                     const int rr = r * 16 + lq * 4 + t;
                     const f32x4 dyr = *reinterpret_cast<const f32x4*>(dyt + rr * 4);
                     const float pre = h[r][t];
-                    const float hact = fmaxf(pre, alpha * pre);   // (0 <= alpha <= 1, checked by the host)
+                    const float hact = lrelu01(pre, alpha);   // (0 <= alpha <= 1, checked by the host)
                     // d lrelu: relu'(pre) + alpha*relu'(-pre), both 0 at pre == 0 (TF relu gradient)
                     const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
                     float g = 0.f;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(MB_THREADS, 4) void mlp_fwd_bf16_kernel(const unsig
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = h[r][t];
-                v = fmaxf(v, alpha * v);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host)
+                v = lrelu01(v, alpha);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host)
 #pragma unroll
                 for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
             }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float pre = h[r][t];
-                    const float hact = fmaxf(pre, alpha * pre);
+                    const float hact = lrelu01(pre, alpha);
                     const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
                     float g = 0.f;
 #pragma unroll
