@@ -165,10 +165,7 @@ __global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(c
 #pragma unroll
             for (int o = 0; o < CO; ++o) {
                 float v = yp[r][t][o];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
+                FGC_ROW16_SUM(v);      // DPP adds; lane lr == 0 (the one that is stored) sums in the xor-butterfly order
                 yp[r][t][o] = v;
             }
     if (lr == 0) {
@@ -347,7 +344,7 @@ __global__ __launch_bounds__(MLP_THREADS, FGC_MLP_BWD_WAVES) void mlp_bwd_kernel
                     const float pre = h[r][t];
                     const float hact = lrelu01(pre, alpha);   // (0 <= alpha <= 1, checked by the host)
                     // d lrelu: relu'(pre) + alpha*relu'(-pre), both 0 at pre == 0 (TF relu gradient)
-                    const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
+                    const float slope = lrelu01_slope(pre, alpha);
                     float g = 0.f;
 #pragma unroll
                     for (int o = 0; o < CO; ++o) {

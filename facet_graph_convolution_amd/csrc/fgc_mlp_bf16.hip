@@ -267,7 +267,7 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float pre = h[r][t];
-                    const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
+                    const float slope = lrelu01_slope(pre, alpha);
                     float g = dyr[r][t][0] * w.w2[c2][0];
                     if (cout > 1) g = fmaf(dyr[r][t][1], w.w2[c2][1], g);
                     if (cout > 2) g = fmaf(dyr[r][t][2], w.w2[c2][2], g);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
                 for (int t = 0; t < 4; ++t) {
                     const float pre = h[r][t];
                     const float hact = lrelu01(pre, alpha);
-                    const float slope = pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f);
+                    const float slope = lrelu01_slope(pre, alpha);
                     float g = 0.f;
 #pragma unroll
                     for (int o = 0; o < CO; ++o) {
