@@ -554,11 +554,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 *reinterpret_cast<f32x4*>(dst + r * ostride + o4 * 4) = counts ? g : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
-            if (tid < OKG * 16) {
+            {
+                // column sums of the tile with ALL threads: P = 256 / columns adjacent lanes share a column (rows part,
+                // part + P, ...) and add up on the DPP crossbar in a fixed order.  (One thread per column walking the 32
+                // rows was a chain of 32 dependent LDS reads in front of a barrier, once per tile.)
+                constexpr int C = OKG * 16, P = NTHREADS / C;
+                static_assert(P == 8 || P == 4, "two or three DPP steps");
+                const int col = tid / P, part = tid % P;
                 float acc = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < TILE; ++r) acc += dst[r * ostride + tid];
-                lp.db_part[(size_t)(tile0 / TILE) * (OKG * 16) + tid] = acc;
+#pragma unroll
+                for (int j = 0; j < TILE / P; ++j) acc += dst[(part + P * j) * ostride + col];
+                acc += fgc_dpp_c<0xB1>(acc);
+                acc += fgc_dpp_c<0x4E>(acc);
+                if (P == 8) acc += fgc_dpp_c<0x141>(acc);
+                if (part == 0) lp.db_part[(size_t)(tile0 / TILE) * C + col] = acc;
             }
             __syncthreads();
         } else {
