@@ -187,8 +187,6 @@ class FacetDenoiser:
         shard ([owned rows | halo rows] per level) and exchanges halos through `comm` between the layers."""
         dev = self.device
         bf16 = self.dtype == "bf16"
-        if bf16 and plan is not None:
-            raise NotImplementedError("facet sharding of the bf16-storage network is not built (fp32 shards only)")
         xt = torch.as_tensor(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float32))
         xt = xt.reshape(-1, xt.shape[-1]).contiguous()
         if xt.shape[1] != self.in_channels:
@@ -611,7 +609,8 @@ class FacetDenoiser:
             call("logits")
             # ONE grouped exchange per layer: the halo rows of s (their owners') and the d-logits of incoming cross-shard
             # edges, both first read by the data kernel
-            items = [("rows", lay.level, B["ds"][:nloc * cout].view(nloc, cout), False), ("edges", lay.level)]
+            ds_rows = (B["ds"].view(torch.bfloat16) if self.dtype == "bf16" else B["ds"])[:nloc * cout].view(nloc, cout)
+            items = [("rows", lay.level, ds_rows, False), ("edges", lay.level)]
             if self.overlap and g.tiles["ttiles_int"][1] >= self.split_min_tiles:
                 # ... it travels under the data kernel of the interior tiles (all in-edges from owned rows); boundary
                 # tiles and the weight gradients follow
@@ -645,6 +644,10 @@ class FacetDenoiser:
         g = M["graphs"][item[1]]
         if item[0] == "rows":
             t, parent = item[2], item[3]
+            if t.dtype == torch.bfloat16:
+                # a row of C bf16 channels travels as C / 2 dwords (every exchanged width is even): the row gather and the
+                # point-to-point messages only move bytes
+                t = t.view(torch.float32)
             tail = t.shape[0] - g.n_halo
             idx = g.send_parent_rows if parent else g.send_rows
             nsend = sum(g.send_counts)

@@ -300,14 +300,14 @@ def graphs_to_host_csr(adjs):
     return out
 
 
-def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0):
+def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0, dtype="f32"):
     """`world` shard networks of one mesh inside ONE process (parity tests of the sharded schedule on a single GPU)."""
     from .net import FacetDenoiser
     gh = graphs_to_host_csr(adjs)
     nets = []
     for r in range(world):
         plan = ShardPlan(gh, r, world)
-        nets.append(FacetDenoiser(device, seed=seed).bind_mesh(x, adjs, gt=gt, plan=plan))
+        nets.append(FacetDenoiser(device, seed=seed, dtype=dtype).bind_mesh(x, adjs, gt=gt, plan=plan))
     return nets
 
 

@@ -53,3 +53,14 @@ def test_multi_scale_denoising_mode_sharded_and_single():
     assert a["metric"].startswith("facets/sec (multi-scale") and a["loss_deg"] is None
     b = _bench(["--gpus", "2", "--multi-scale", "--scaling", "strong"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["exchange"]["collectives_per_step"] > 0
+
+
+def test_two_ranks_bf16_storage_over_gloo():
+    """BASELINE config 3 sharded: the bf16-storage network over two ranks; the halo rows travel as bf16, so the same
+    exchanges move fewer bytes than the fp32 run of the same mesh."""
+    a = _bench(["--gpus", "2"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
+    b = _bench(["--gpus", "2", "--dtype", "bf16"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
+    assert b["dtype"] == "bf16" and b["n_gpus"] == 2 and 0 < b["loss_deg"] < 180
+    assert b["exchange"]["collectives_per_step"] == a["exchange"]["collectives_per_step"]
+    # (on this small mesh the flat-gradient all-reduce, fp32 in both, is most of the bytes)
+    assert b["exchange"]["bytes_sent_per_step"] < a["exchange"]["bytes_sent_per_step"]
