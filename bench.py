@@ -344,6 +344,7 @@ def main(argv=None):
     S_loc = [net.local_samples_device(s) for s in samp_host] if (shard and train) else None
     torch.cuda.synchronize()
     counter = [0]
+    graph_mode = [False]      # sharded extra: replay the schedule from per-segment hipGraphs
 
     def step():
         k = counter[0] % nsteps_total
@@ -352,7 +353,7 @@ def main(argv=None):
             net.forward_multi_scale() if args.multi_scale else net.forward(rotate=False)
             return
         net.set_step_inputs_device(S_all[k], R_all[k], S_loc[k] if S_loc else None)
-        net.forward_backward(rotate=True, capture=bool(args.graph) and not shard)
+        net.forward_backward(rotate=True, capture=bool(args.graph) or graph_mode[0])
         if world > 1 and not shard:
             if backend == "nccl":
                 dist.all_reduce(net.params.grad, op=dist.ReduceOp.AVG)
@@ -415,6 +416,15 @@ def main(argv=None):
         tg, loss_g = walk(net_g, True)
         hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": loss_g, "matches_eager": loss_g == loss_e}
         del net_g, net_e
+    elif shard and train and not args.graph:
+        # sharded: the launches between two exchanges replayed as one hipGraph each, the exchanges eager in between
+        graph_mode[0] = True
+        step()                                # eager warm-up + capture
+        step()
+        tg = timed_block()
+        graph_mode[0] = False
+        hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": net.buffers["loss"][0].item(),
+                    "graphs_per_step": sum(len(sg) for sg in net._graph_fb[0]), "matches_eager": None}
 
     # forward-only rate (BASELINE config 2 wording), untimed extra
     torch.cuda.synchronize()

@@ -390,6 +390,8 @@ class FacetDenoiser:
     #        ("edges", level)                  d-logits of incoming cross-shard edges
     #      key None: blocking.  Otherwise the kernels enqueued up to the matching ("wait", key) run while it travels
     #   ("sum", tensor)          all-reduce
+    #   ("call", fn)             launches whose arguments change from step to step (a rank's own loss samples): run by
+    #                            an eager call, also between the hipGraphs of a captured schedule (_capture_segments)
     # Per step: 7 exchanges forward (everything a layer produces that a peer gathers goes out in one message right
     # behind it: conv1 -> {h1, p1}, conv2 -> {h2, p2}), 7 backward (a layer's s rows and cross-edge d-logits together),
     # two scalar all-reduces for normalizeTensor and its gradient, one all-reduce of gradient + loss sum: 17.
@@ -509,24 +511,34 @@ class FacetDenoiser:
         if rotate:
             _lib.check(L.fgc_rotate_rows(_p(B["gt"]), _p(B["gtr"]), n0, 1, _p(B["R"]), st), "rotate gt")
             gt = B["gtr"]
-        samp = B["sample_ind_local"] if self.sharded else B["sample_ind"]
-        ns_samp = samp.numel()
-        if ns_samp:
-            _lib.check(L.fgc_angular_loss_fwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, _p(B["loss"]), st), "loss")
-        else:
-            B["loss"].zero_()
+
+        def loss_rows():
+            stl = self._st()
+            samp = B["sample_ind_local"] if self.sharded else B["sample_ind"]
+            ns_samp = samp.numel()
+            if ns_samp:
+                _lib.check(L.fgc_angular_loss_fwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, _p(B["loss"]), stl), "loss")
+            else:
+                B["loss"].zero_()
+            if self.sharded:
+                # loss = sum over ranks of (sum of angles) / (real rows among ALL samples).  The count is known to every
+                # rank (flags of the whole mesh were kept at bind time), so the backward pass can start at once; the sum
+                # of angles rides in the tail of the gradient all-reduce at the end of the step
+                ext = self.params.grad_ext
+                ext[-4:-3] = torch.nan_to_num(B["loss"][0:1] * B["loss"][1:2])
+                B["loss"][1:2] = B["real_flag"][B["sample_ind"].long()].sum().reshape(1)
+            if ns_samp:
+                _lib.check(L.fgc_angular_loss_bwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, n0, _p(B["loss"]), 1.0,
+                                                  _p(B["g_nconv"]), stl), "loss bwd")
+            else:
+                B["g_nconv"].zero_()
+
         if self.sharded:
-            # loss = sum over ranks of (sum of angles) / (real rows among ALL samples).  The count is known to every
-            # rank (flags of the whole mesh were kept at bind time), so the backward pass can start at once; the sum of
-            # angles rides in the tail of the gradient all-reduce at the end of the step
-            ext = self.params.grad_ext
-            ext[-4:-3] = torch.nan_to_num(B["loss"][0:1] * B["loss"][1:2])
-            B["loss"][1:2] = B["real_flag"][B["sample_ind"].long()].sum().reshape(1)
-        if ns_samp:
-            _lib.check(L.fgc_angular_loss_bwd(_p(B["nconv"]), _p(gt), _p(samp), ns_samp, n0, _p(B["loss"]), 1.0,
-                                              _p(B["g_nconv"]), st), "loss bwd")
+            # a rank's own samples are a list of another length (and another tensor) every step: these few launches are
+            # a request of their own, served by an eager call also when the schedule is replayed from hipGraphs
+            yield ("call", loss_rows)
         else:
-            B["g_nconv"].zero_()
+            loss_rows()
         if not self.sharded:
             _lib.check(L.fgc_normalize_bwd(_p(B["y0"]), _p(B["g_nconv"]), n0, _p(B["g_y0"]), _p(B["norm_scratch"]),
                                            st), "normalize bwd")
@@ -660,20 +672,51 @@ class FacetDenoiser:
             return (send, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
         raise ValueError(item[0])
 
+    def _serve(self, req, pending):
+        """One request of a schedule through self.comm (exchange now / begin / await, or an all-reduce)."""
+        if req[0] == "wait":
+            self.comm.finish(pending.pop(req[1]))
+        elif req[0] == "call":
+            req[1]()
+        elif req[0] == "sum":
+            self.comm.all_reduce_sum(req[1])
+        else:
+            mats = [self._materialise(it) for it in req[1]]
+            if req[2] is None:
+                self.comm.exchange(mats)
+            else:
+                pending[req[2]] = self.comm.exchange_begin(mats)
+
     def _drain(self, gen):
         """Run a schedule on this rank: no-op exchanges when unsharded, collectives through self.comm otherwise."""
         pending = {}
         for req in gen:
-            if req[0] == "wait":
-                self.comm.finish(pending.pop(req[1]))
-            elif req[0] == "sum":
-                self.comm.all_reduce_sum(req[1])
-            else:
-                mats = [self._materialise(it) for it in req[1]]
-                if req[2] is None:
-                    self.comm.exchange(mats)
-                else:
-                    pending[req[2]] = self.comm.exchange_begin(mats)
+            self._serve(req, pending)
+
+    def _capture_segments(self, make_gen):
+        """A facet-sharded schedule as a list of (hipGraph, request): the launches between two exchanges are captured
+        into one graph each; the exchanges themselves (row gather + grouped point-to-point, all-reduces) stay eager
+        calls between the replays - a collective is not a graph node here.  The schedule is static (same buffers, same
+        tile lists, same message sizes every step), so the requests recorded with the graphs are replayed as they are."""
+        gen = make_gen()
+        segs = []
+        while True:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                try:
+                    req = next(gen)
+                except StopIteration:
+                    req = None
+            segs.append((g, req))
+            if req is None:
+                return segs
+
+    def _replay_segments(self, segs):
+        pending = {}
+        for g, req in segs:
+            g.replay()
+            if req is not None:
+                self._serve(req, pending)
 
     def _enqueue_forward(self, rotate):
         self._drain(self._forward_gen(rotate))
@@ -810,6 +853,22 @@ class FacetDenoiser:
         if capture:
             from . import require_graph_replay_safe
             require_graph_replay_safe()
+            if self.sharded:
+                # one hipGraph per stretch of launches between two exchanges (17 collectives -> ~25 graphs per step
+                # instead of ~110 launches); the first call runs one step eagerly (lazy one-time set-up inside the
+                # library must not happen under capture), every later one replays
+                if self._graph_fb is None:
+                    self._enqueue_forward(rotate)
+                    self._enqueue_loss_backward(rotate)
+                    torch.cuda.synchronize()
+                    self._graph_fb = ((self._capture_segments(lambda: self._forward_gen(rotate)),
+                                       self._capture_segments(lambda: self._loss_backward_gen(rotate))), rotate)
+                    return self._mesh["B"]["loss"]
+                if self._graph_fb[1] != rotate:
+                    raise RuntimeError("the captured schedule was recorded with rotate=%s" % self._graph_fb[1])
+                for segs in self._graph_fb[0]:
+                    self._replay_segments(segs)
+                return self._mesh["B"]["loss"]
             if self._graph_fb is None:
                 # warm up on a side stream, then capture the whole enqueue sequence into one hipGraph
                 s = torch.cuda.Stream()

@@ -327,6 +327,10 @@ def sim_run(nets, make_gen):
         assert len({r[0] for r in reqs}) == 1, "shards disagree on the exchange schedule"
         if reqs[0][0] == "wait":       # the exchange already happened when it was begun
             continue
+        if reqs[0][0] == "call":       # launches a shard makes outside its captured graphs (see net._loss_backward_gen)
+            for r in reqs:
+                r[1]()
+            continue
         if reqs[0][0] == "sum":
             tot = reqs[0][1].clone()
             for r in reqs[1:]:

@@ -26,6 +26,15 @@ net.forward_backward(rotate=True)
 torch.cuda.synchronize()
 loss = net.buffers["loss"][0].item()
 gn = net.params.grad.norm().item()
+# the same schedule replayed from hipGraphs (one per stretch of launches between two exchanges): bit-identical
+g_eager = net.params.grad.clone()
+for it in range(3):       # first call: eager warm-up + capture; then two replays
+    net.forward_backward(rotate=True, capture=True)
+torch.cuda.synchronize()
+assert net.buffers["loss"][0].item() == loss and torch.equal(net.params.grad, g_eager), "graph replay differs from eager"
+nseg = sum(len(s) for s in net._graph_fb[0])
+if rank == 0:
+    print("captured schedule: %d graphs per step" % nseg)
 if rank == 0:
     ref = FacetDenoiser("cuda:0", seed=0).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0])
     ref.set_samples(samp); ref.set_rotation(np.eye(3)); ref.forward_backward(rotate=True); torch.cuda.synchronize()
