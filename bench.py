@@ -68,11 +68,13 @@ def parse_args(argv=None):
     ap.add_argument("--nv", type=int, default=0)
     ap.add_argument("--multi-scale", action="store_true", help="three-head network, step = multi-scale denoising forward")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="replay the forward+backward enqueue as one hipGraph (1 %% faster than eager here: the step is "
-                         "GPU-bound).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
-                         "the runtime's pre-built graph packets a replay after a stream synchronise computes garbage on "
-                         "this ROCm stack (DESIGN.md section 6), so the timed default stays on eager launches")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: replay the step from hipGraphs, 0: eager launches, -1 (default): eager on one GPU (the step "
+                         "is GPU-bound, replay is 1 %% faster), hipGraph segments between the exchanges on a facet-sharded "
+                         "run (there the ~110 launches + 17 collective calls of a step are close to its GPU time on the "
+                         "host; falls back to eager if capture fails).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which "
+                         "the package sets at import: with the runtime's pre-built graph packets a replay after a stream "
+                         "synchronise computes garbage on this ROCm stack (DESIGN.md section 6)")
     ap.add_argument("--repeats", type=int, default=5, help="untimed-extra repeats of the K-step block (min / median)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -344,7 +346,10 @@ def main(argv=None):
     S_loc = [net.local_samples_device(s) for s in samp_host] if (shard and train) else None
     torch.cuda.synchronize()
     counter = [0]
-    graph_mode = [False]      # sharded extra: replay the schedule from per-segment hipGraphs
+    auto_graph = args.graph < 0
+    args.graph = 0 if auto_graph else args.graph
+    # a facet-sharded training run replays the stretches between its exchanges from hipGraphs unless told otherwise
+    graph_mode = [bool(shard and train and auto_graph)]
 
     def step():
         k = counter[0] % nsteps_total
@@ -384,6 +389,15 @@ def main(argv=None):
             dt = t.item()
         return dt
 
+    if graph_mode[0]:
+        try:
+            step()                           # eager warm-up step + capture of the schedule's segments
+            step()
+        except Exception as e:               # noqa: BLE001 - any capture problem: the eager schedule is the same arithmetic
+            print("bench: hipGraph segments unavailable (%s: %s), timing eager launches" % (type(e).__name__, e), file=sys.stderr)
+            graph_mode[0] = False
+            net._graph_fb = None
+    launch_mode = "hipGraph segments between the exchanges" if graph_mode[0] else "eager launches"
     for _ in range(args.warmup):
         step()
     dt = timed_block()                       # THE timed region: exactly K steps, max over ranks
@@ -416,15 +430,15 @@ def main(argv=None):
         tg, loss_g = walk(net_g, True)
         hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": loss_g, "matches_eager": loss_g == loss_e}
         del net_g, net_e
-    elif shard and train and not args.graph:
-        # sharded: the launches between two exchanges replayed as one hipGraph each, the exchanges eager in between
-        graph_mode[0] = True
-        step()                                # eager warm-up + capture
-        step()
-        tg = timed_block()
+    elif shard and train and graph_mode[0]:
+        # sharded: the timed region replayed one hipGraph per stretch of launches between two exchanges (the exchanges
+        # eager in between); the same K steps with eager launches beside it
         graph_mode[0] = False
-        hipgraph = {"ms_per_step": tg / args.steps * 1e3, "loss_deg": net.buffers["loss"][0].item(),
-                    "graphs_per_step": sum(len(sg) for sg in net._graph_fb[0]), "matches_eager": None}
+        te = timed_block()
+        graph_mode[0] = True
+        hipgraph = {"ms_per_step": dt / args.steps * 1e3, "eager_ms_per_step": te / args.steps * 1e3,
+                    "graphs_per_step": sum(len(sg) for sg in net._graph_fb[0]), "matches_eager": None,
+                    "timed_region": "hipgraph"}
 
     # forward-only rate (BASELINE config 2 wording), untimed extra
     torch.cuda.synchronize()
@@ -579,10 +593,10 @@ def main(argv=None):
                        "parallelism": ("single GPU" if world == 1 else
                                        ("one %d-facet mesh facet-sharded over %d GPUs (%s world size %d), halo all-to-all per "
                                         "conv + flat-gradient all-reduce; halo/owned rows per level on rank 0: %s; %d "
-                                        "collectives per step, %.3f ms per step when exchanged blocking" %
+                                        "collectives per step, %.3f ms per step when exchanged blocking; %s" %
                                         (F_total, world, "RCCL" if backend == "nccl" else backend, dist.get_world_size(),
                                          ", ".join("%.3f" % h for h in halo_frac), exchange["collectives_per_step"],
-                                         exchange["blocking_ms_per_step"])) if shard else
+                                         exchange["blocking_ms_per_step"], launch_mode)) if shard else
                                        "1 mesh per GPU, flat-gradient all-reduce (%s world size %d)" % (
                                            "RCCL" if backend == "nccl" else backend, dist.get_world_size()))},
             "loss_deg": loss,

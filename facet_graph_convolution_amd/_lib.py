@@ -33,6 +33,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class RowJob(C.Structure):
+    """struct fgc_row_job (include/fgc.h): one row copy of fgc_copy_rows_jobs."""
+    _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("width", C.c_int32)]
+
+
 class ConvBwdIO(C.Structure):
     _fields_ = [
         ("trowptr", C.c_void_p), ("tcol", C.c_void_p), ("tedge", C.c_void_p), ("max_in_deg", C.c_int32), ("stages", C.c_int32),
@@ -141,6 +146,7 @@ _SIGS = {
                                 C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "fgc_infer_epilogue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "fgc_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "fgc_copy_rows_jobs": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "fgc_scatter_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 

@@ -310,6 +310,28 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __r
         dst[i] = src[(int64_t)idx[r] * c + i % c];
     }
 }
+// several row copies in one launch (fgc_copy_rows_jobs): workgroup -> job through the table's block prefix
+struct RowJobs {
+    fgc_row_job job[FGC_ROW_JOBS_MAX];
+    int block0[FGC_ROW_JOBS_MAX + 1];
+    int njobs;
+};
+constexpr int ROWJOB_ELEMS = 2048;      // dwords per workgroup
+__global__ __launch_bounds__(EW_THREADS) void copy_rows_jobs_kernel(RowJobs J) {
+    int j = 0;
+#pragma unroll 1
+    for (int t = 1; t < J.njobs; ++t)
+        if ((int)blockIdx.x >= J.block0[t]) j = t;
+    const fgc_row_job job = J.job[j];
+    const int64_t total = (int64_t)job.rows * job.width;
+    const int64_t e0 = (int64_t)(blockIdx.x - J.block0[j]) * ROWJOB_ELEMS;
+    for (int64_t e = e0 + threadIdx.x; e < min(e0 + ROWJOB_ELEMS, total); e += EW_THREADS) {
+        const int64_t r = e / job.width;
+        const int c = (int)(e - r * job.width);
+        const int64_t sr = job.idx ? (int64_t)job.idx[r] : r;
+        job.dst[e] = job.src[sr * job.width + c];
+    }
+}
 __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int64_t count,
                                         int c, float* __restrict__ dst) {
     // idx must be duplicate-free (each halo row has one owner): plain read-modify-write, deterministic
@@ -486,6 +508,28 @@ extern "C" int fgc_gather_rows(const float* src, const int32_t* idx, int32_t cou
     const int64_t cnt = (int64_t)count * c;
     FGC_LAUNCH("gather_rows_kernel", ST, gather_rows_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, src, idx, cnt, c, dst);
     FGC_CHECK_LAUNCH("fgc_gather_rows");
+    return FGC_OK;
+}
+extern "C" int fgc_copy_rows_jobs(const fgc_row_job* jobs, int32_t njobs, void* stream) {
+    FGC_CHECK_ARG(njobs >= 0 && njobs <= FGC_ROW_JOBS_MAX && (jobs || !njobs), "fgc_copy_rows_jobs: 0 <= njobs <= %d",
+                  FGC_ROW_JOBS_MAX);
+    RowJobs J;
+    J.njobs = 0;
+    int blocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const fgc_row_job& q = jobs[j];
+        FGC_CHECK_ARG(q.rows >= 0 && q.width > 0, "fgc_copy_rows_jobs: job %d: rows %d, width %d", j, q.rows, q.width);
+        if (!q.rows) continue;
+        FGC_CHECK_ARG(q.src && q.dst, "fgc_copy_rows_jobs: job %d: null pointer", j);
+        J.job[J.njobs] = q;
+        J.block0[J.njobs] = blocks;
+        blocks += (int)(((int64_t)q.rows * q.width + ROWJOB_ELEMS - 1) / ROWJOB_ELEMS);
+        ++J.njobs;
+    }
+    J.block0[J.njobs] = blocks;
+    if (!blocks) return FGC_OK;
+    FGC_LAUNCH("copy_rows_jobs_kernel", ST, copy_rows_jobs_kernel, dim3(blocks), dim3(EW_THREADS), 0, J);
+    FGC_CHECK_LAUNCH("fgc_copy_rows_jobs");
     return FGC_OK;
 }
 extern "C" int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst,

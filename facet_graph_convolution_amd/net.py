@@ -650,27 +650,36 @@ class FacetDenoiser:
             B["loss"][0:1] = self.params.grad_ext[-4:-3] / B["loss"][1:2]
 
     # ---- exchange items -> (send buffer, send counts, receive view, receive counts) ------------------------
-    def _materialise(self, item):
-        from . import ops
+    def _block(self, item):
+        """One block of a grouped exchange (shard.PackedExchange): (src rows, send index, send counts, halo tail, recv
+        counts)."""
         M = self._mesh
         g = M["graphs"][item[1]]
         if item[0] == "rows":
             t, parent = item[2], item[3]
             if t.dtype == torch.bfloat16:
-                # a row of C bf16 channels travels as C / 2 dwords (every exchanged width is even): the row gather and the
-                # point-to-point messages only move bytes
+                # a row of C bf16 channels travels as C / 2 dwords (every exchanged width is even): the copies and the
+                # collective only move bytes
                 t = t.view(torch.float32)
             tail = t.shape[0] - g.n_halo
             idx = g.send_parent_rows if parent else g.send_rows
-            nsend = sum(g.send_counts)
-            send = ops.gather_rows(t, idx[:nsend]) if nsend else t[:0]
-            return (send, g.send_counts, t[tail:], g.recv_counts)
+            return (t, idx, g.send_counts, t[tail:], g.recv_counts)
         if item[0] == "edges":
             dl = M["B"]["dl"][:(g.nnz + g.n_cross_in) * DL_LD].view(-1, DL_LD)
-            nsend = sum(g.cross_send_counts)
-            send = ops.gather_rows(dl, g.send_edges[:nsend]) if nsend else dl[:0]
-            return (send, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
+            return (dl, g.send_edges, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
         raise ValueError(item[0])
+
+    def _packed(self, req):
+        """The PackedExchange of an ("xchg", items, key) request; built at its first use, the same every step."""
+        from .shard import PackedExchange
+        cache = self._mesh.setdefault("packed", {})
+        key = tuple((it[0], it[1]) + ((it[2].data_ptr(), tuple(it[2].shape), bool(it[3])) if it[0] == "rows" else ())
+                    for it in req[1])
+        px = cache.get(key)
+        if px is None:
+            world = len(self._mesh["graphs"][0].send_counts)
+            px = cache[key] = PackedExchange([self._block(it) for it in req[1]], world)
+        return px
 
     def _serve(self, req, pending):
         """One request of a schedule through self.comm (exchange now / begin / await, or an all-reduce)."""
@@ -681,11 +690,11 @@ class FacetDenoiser:
         elif req[0] == "sum":
             self.comm.all_reduce_sum(req[1])
         else:
-            mats = [self._materialise(it) for it in req[1]]
+            px = self._packed(req)
             if req[2] is None:
-                self.comm.exchange(mats)
+                self.comm.exchange(px)
             else:
-                pending[req[2]] = self.comm.exchange_begin(mats)
+                pending[req[2]] = self.comm.exchange_begin(px)
 
     def _drain(self, gen):
         """Run a schedule on this rank: no-op exchanges when unsharded, collectives through self.comm otherwise."""
@@ -702,7 +711,8 @@ class FacetDenoiser:
         segs = []
         while True:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread_local: the collective back end's watchdog thread may query its events while this thread captures)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 try:
                     req = next(gen)
                 except StopIteration:
@@ -823,11 +833,11 @@ class FacetDenoiser:
                 stats["n"] += 1
                 stats["bytes"] += nbytes
 
-            def exchange(self, mats):
-                self._t(lambda: comm.exchange(mats), sum(m[0].numel() * m[0].element_size() for m in mats))
+            def exchange(self, px):
+                self._t(lambda: comm.exchange(px), px.send_buf.numel() * 4)
 
-            def exchange_begin(self, mats):
-                self.exchange(mats)
+            def exchange_begin(self, px):
+                self.exchange(px)
                 return None
 
             def finish(self, h):

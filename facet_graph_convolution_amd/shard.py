@@ -197,6 +197,80 @@ class LocalGraph:
 
 
 # ---------------------------------------------------------------------------------------------------
+# one grouped exchange = one all-to-all
+# ---------------------------------------------------------------------------------------------------
+class PackedExchange:
+    """The static plan of ONE grouped halo exchange: the rows of several tensors ("blocks") for every peer, packed
+    peer-major into one send buffer, moved by a single all-to-all, and copied from the receive buffer into the halo
+    tails of the tensors.  A block is (src [rows, width], idx, send_counts, recv [halo rows, width], recv_counts): rows
+    idx[...] of src go out (idx sorted by peer, send_counts[q] of them to peer q); recv is the tail view the incoming
+    rows land in, peer after peer.  Rows are float32 views (a bf16 row of C channels is C / 2 dwords).  Buffers, split
+    sizes and the two copy-job lists are built once; every step then costs one pack launch, one collective call and one
+    unpack launch (fgc_copy_rows_jobs), whatever the number of tensors and peers."""
+
+    def __init__(self, blocks, world):
+        dev = blocks[0][0].device
+        w = [int(b[0].shape[1]) for b in blocks]
+        self.send_splits = [int(sum(b[2][q] * w[i] for i, b in enumerate(blocks))) for q in range(world)]
+        self.recv_splits = [int(sum(b[4][q] * w[i] for i, b in enumerate(blocks))) for q in range(world)]
+        self.send_buf = torch.empty(sum(self.send_splits), dtype=torch.float32, device=dev)
+        self.recv_buf = torch.empty(sum(self.recv_splits), dtype=torch.float32, device=dev)
+        s_off = [np.cumsum([0] + list(b[2])) for b in blocks]
+        r_off = [np.cumsum([0] + list(b[4])) for b in blocks]
+        # pack job: rows idx[idx_off : idx_off + rows] of src -> send_buf[dst_off ...]; unpack job: recv_buf[src_off ...]
+        # (rows consecutive) -> rows dst_row ... of the tail view
+        self.pack_jobs, self.unpack_jobs = [], []
+        so = ro = 0
+        for q in range(world):
+            for i, (src, idx, sc, recv, rc) in enumerate(blocks):
+                if sc[q]:
+                    self.pack_jobs.append(dict(src=src, idx=idx, idx_off=int(s_off[i][q]), dst=self.send_buf, dst_off=so,
+                                               rows=int(sc[q]), width=w[i]))
+                    so += int(sc[q]) * w[i]
+                if rc[q]:
+                    self.unpack_jobs.append(dict(src=self.recv_buf, src_off=ro, dst=recv, dst_row=int(r_off[i][q]),
+                                                 rows=int(rc[q]), width=w[i]))
+                    ro += int(rc[q]) * w[i]
+        self._tables = None
+
+    def _row_jobs(self):
+        """The ctypes job tables of fgc_copy_rows_jobs (pointers are static: built once), in chunks of <= 32 jobs."""
+        if self._tables is None:
+            from . import _lib
+            import ctypes as C
+
+            def table(jobs, pack):
+                chunks = []
+                for c0 in range(0, len(jobs), 32):
+                    part = jobs[c0:c0 + 32]
+                    arr = (_lib.RowJob * len(part))()
+                    for k, j in enumerate(part):
+                        if pack:
+                            arr[k].src, arr[k].idx = j["src"].data_ptr(), j["idx"].data_ptr() + 4 * j["idx_off"]
+                            arr[k].dst = j["dst"].data_ptr() + 4 * j["dst_off"]
+                        else:
+                            arr[k].src, arr[k].idx = j["src"].data_ptr() + 4 * j["src_off"], None
+                            arr[k].dst = j["dst"].data_ptr() + 4 * j["dst_row"] * j["width"]
+                        arr[k].rows, arr[k].width = j["rows"], j["width"]
+                    chunks.append((arr, len(part)))
+                return chunks
+            self._tables = (table(self.pack_jobs, True), table(self.unpack_jobs, False))
+        return self._tables
+
+    def _run(self, chunks, what):
+        from . import _lib
+        st = torch.cuda.current_stream().cuda_stream
+        for arr, n in chunks:
+            _lib.check(_lib.lib().fgc_copy_rows_jobs(arr, n, st), what)
+
+    def pack(self):
+        self._run(self._row_jobs()[0], "halo pack")
+
+    def unpack(self):
+        self._run(self._row_jobs()[1], "halo unpack")
+
+
+# ---------------------------------------------------------------------------------------------------
 # exchange back ends
 # ---------------------------------------------------------------------------------------------------
 class DistComm:
@@ -209,55 +283,39 @@ class DistComm:
         self.rank = dist.get_rank(group)
         self.host_staged = dist.get_backend(group) == "gloo"
 
-    def all_to_all_rows(self, send, send_counts, recv, recv_counts):
-        """send [sum(send_counts), C] -> recv [sum(recv_counts), C] (views into larger tensors are fine)."""
+    # ---- grouped exchanges: the rows of several tensors with every peer in ONE all-to-all (PackedExchange) ----------
+    def all_to_all_flat(self, send, send_splits, recv, recv_splits, async_op=False):
+        """1-D buffers, split sizes in elements per peer.  RCCL: one all_to_all_single (a group of sends and receives,
+        every peer pair on its own xGMI link); returns the work handle when async_op.  gloo: staged through the host."""
         if self.host_staged:
-            s = send.cpu()
             r = torch.empty(recv.shape, dtype=recv.dtype)
-            self._gloo_a2a(r, s, recv_counts, send_counts)
+            self._gloo_a2a(r, send.cpu(), recv_splits, send_splits)
             recv.copy_(r)
-        else:
-            self.dist.all_to_all_single(recv, send, list(recv_counts), list(send_counts), group=self.group)
-
-    # ---- grouped exchanges: several (send, send_counts, recv, recv_counts) blocks with every peer at once ----------
-    def _p2p_ops(self, mats):
-        """One isend / irecv per (block, peer) with rows to move.  RCCL runs the whole list as ONE group: every peer
-        pair uses its own xGMI link, nothing is packed or unpacked beyond the row gather the caller did - the rows land
-        in the halo tail of their tensor.  Both sides post the blocks in the same order, so the messages of a peer pair
-        match up."""
-        d = self.dist
-        ops = []
-        for send, sc, recv, rc in mats:
-            so, ro = np.cumsum([0] + list(sc)), np.cumsum([0] + list(rc))
-            for q in range(self.world):
-                if q == self.rank:
-                    continue
-                if sc[q]:
-                    ops.append(d.P2POp(d.isend, send[so[q]:so[q + 1]], q, self.group))
-                if rc[q]:
-                    ops.append(d.P2POp(d.irecv, recv[ro[q]:ro[q + 1]], q, self.group))
-        return ops
-
-    def exchange_begin(self, mats):
-        """Start ONE grouped exchange of all blocks and return a handle for `finish`: on RCCL it runs on the
-        communicator's own stream, so kernels enqueued between begin and finish overlap it.  The receive views must
-        not be read, nor the send buffers reused, before `finish`.  The host-staged gloo path exchanges synchronously."""
-        if self.host_staged:
-            for m in mats:
-                self.all_to_all_rows(*m)
             return None
-        ops = self._p2p_ops(mats)
-        if not ops:
+        if send.numel() == 0 and recv.numel() == 0:
             return None
-        return (self.dist.batch_isend_irecv(ops), mats)     # keeps the buffers alive until the wait
+        return self.dist.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=self.group,
+                                           async_op=async_op)
 
-    def exchange(self, mats):
-        self.finish(self.exchange_begin(mats))
+    def exchange_begin(self, px):
+        """Start the exchange `px` (PackedExchange) and return a handle for `finish`: pack (one launch), then ONE
+        collective call - on RCCL on the communicator's own stream, so kernels enqueued between begin and finish overlap
+        it.  The halo tails must not be read before `finish`.  (A step has 14 of these; issued as point-to-point pairs
+        per tensor and peer they were 230 isend / irecv calls per step on 8 ranks - more host time than the step has GPU
+        time.)  The host-staged gloo path exchanges synchronously."""
+        px.pack()
+        work = self.all_to_all_flat(px.send_buf, px.send_splits, px.recv_buf, px.recv_splits, async_op=True)
+        return (work, px)
+
+    def exchange(self, px):
+        self.finish(self.exchange_begin(px))
 
     def finish(self, handle):
         if handle is not None:
-            for w in handle[0]:
-                w.wait()                # the current stream waits for the group; the host does not block
+            work, px = handle
+            if work is not None:
+                work.wait()             # the current stream waits for the collective; the host does not block
+            px.unpack()
 
     def _gloo_a2a(self, r, s, recv_counts, send_counts):
         # gloo has no all_to_all_single on every build: P2P rounds instead
@@ -338,20 +396,19 @@ def sim_run(nets, make_gen):
             for r in reqs:
                 r[1].copy_(tot)
             continue
-        nitems = len(reqs[0][1])
-        assert all(len(r[1]) == nitems for r in reqs), "shards disagree on the exchange schedule"
-        for k in range(nitems):
-            mats = [n._materialise(r[1][k]) for n, r in zip(nets, reqs)]
-            for dst, md in enumerate(mats):
-                recv, recv_counts = md[2], md[3]
-                ro = np.cumsum([0] + list(recv_counts))
-                for src, ms in enumerate(mats):
-                    if src == dst or not recv_counts[src]:
-                        continue
-                    send, send_counts = ms[0], ms[1]
-                    so = np.cumsum([0] + list(send_counts))
-                    assert send_counts[dst] == recv_counts[src], (src, dst, send_counts[dst], recv_counts[src])
-                    recv[ro[src]:ro[src + 1]].copy_(send[so[dst]:so[dst + 1]])
+        pxs = [n._packed(r) for n, r in zip(nets, reqs)]
+        for px in pxs:
+            px.pack()
+        for dst, pd in enumerate(pxs):
+            ro = np.cumsum([0] + pd.recv_splits)
+            for src, ps in enumerate(pxs):
+                if src == dst or not pd.recv_splits[src]:
+                    continue
+                so = np.cumsum([0] + ps.send_splits)
+                assert ps.send_splits[dst] == pd.recv_splits[src], (src, dst)
+                pd.recv_buf[ro[src]:ro[src + 1]].copy_(ps.send_buf[so[dst]:so[dst + 1]])
+        for px in pxs:
+            px.unpack()
 
 
 def sim_forward_backward(nets, rotate=True):

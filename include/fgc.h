@@ -372,6 +372,21 @@ int fgc_infer_epilogue(const float* n_conv, const int32_t* perm, int32_t num_fac
 int fgc_gather_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst, void* stream);
 int fgc_scatter_add_rows(const float* src, const int32_t* idx, int32_t count, int32_t c, float* dst, void* stream);
 
+/* Several row copies in ONE launch: the pack and the unpack side of a grouped halo exchange.  A sharded
+ * step sends the halo rows of up to three tensors to every peer at once; packing them per (tensor, peer) into the send
+ * buffer of one all-to-all, and copying what arrives into the halo tails of the tensors, is one call each instead of a
+ * launch per piece.  Job j:  dst_j[i, 0..width) = src_j[(idx_j ? idx_j[i] : i), 0..width)  for i < rows.
+ * Rows are `width` dwords (a bf16 row of C channels is C / 2 dwords).  At most FGC_ROW_JOBS_MAX jobs; `jobs` is a host
+ * array read before the call returns.  Jobs must not overlap each other's destinations. */
+#define FGC_ROW_JOBS_MAX 32
+typedef struct fgc_row_job {
+    const float* src;
+    const int32_t* idx;       /* device, or NULL: rows are consecutive in src */
+    float* dst;
+    int32_t rows, width;
+} fgc_row_job;
+int fgc_copy_rows_jobs(const fgc_row_job* jobs, int32_t njobs, void* stream);
+
 /* Vertex update from denoised normals = update_position2 (train.py:1467-1557; called with 60 iterations and
  * lambda = 1/18 by inferNetOld, train.py:129-139).  Jacobi iterations
  *   x_i <- x_i + lambda * sum_{edges e = (i,j,f1,f2) of i} sum_{f in {f1,f2}} n_f (n_f . (x_j - x_i))

@@ -45,7 +45,10 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert j["exchange"]["collectives_per_step"] > 0 and j["exchange"]["bytes_sent_per_step"] > 0
     assert 0 < j["loss_deg"] < 180
     # the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
-    assert j["hipgraph_replay"]["graphs_per_step"] > 17 and j["hipgraph_replay"]["ms_per_step"] > 0
+    assert j["hipgraph_replay"]["graphs_per_step"] > 17 and j["hipgraph_replay"]["eager_ms_per_step"] > 0
+    assert j["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in j["config"]["parallelism"]
+    e = _bench(["--gpus", "2", "--graph", "0"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
+    assert "eager launches" in e["config"]["parallelism"] and e["hipgraph_replay"] is None
     # weak scaling: the mesh has twice the facets of the single-GPU run
     assert "%d facets" % (2 * 48 * 40 * 2) in j["config"]["workload"]
 

@@ -80,33 +80,34 @@ def _worker(rank, world, port, golden_dir, out):
         plan = ShardPlan(gh, rank, world)
         comm = DistComm()
         ok = True
-        for l in range(3):
-            P = plan.levels[l]
-            ids = plan.local_rows(l)
-            # a "feature" that encodes the global row id: after the exchange the halo rows must hold their own ids
-            t = torch.zeros(len(ids), 3)
-            t[:P.n_own, 0] = torch.arange(P.lo, P.hi, dtype=torch.float32)
-            t[:P.n_own, 1] = 7.0
-            send = t[torch.from_numpy(np.concatenate(P.send_rows)).long()]
-            comm.all_to_all_rows(send, P.send_counts, t[P.n_own:], P.recv_counts)
-            ok &= bool(torch.equal(t[:, 0], torch.from_numpy(ids).float()))
-            ok &= bool((t[:, 1] == 7.0).all())
-        # the grouped form a multi-GPU step uses: two levels' rows with every peer in ONE batch of point-to-point
-        # operations (on RCCL one group; here gloo moves CPU tensors through the same isend / irecv list)
-        comm.host_staged = False
-        ts, mats = [], []
-        for l in (0, 1):
+        # the grouped form a step uses: the rows of two tensors (two levels, different widths) for every peer packed into
+        # ONE all-to-all (shard.PackedExchange).  The product runs the pack / unpack job lists through
+        # fgc_copy_rows_jobs on the GPU; here a torch restatement of the same lists moves CPU tensors, so that layout,
+        # split sizes and the gloo transport are checked without a GPU.  A "feature" encodes the global row id: after
+        # the exchange every halo row must hold its own id.
+        from facet_graph_convolution_amd.shard import PackedExchange
+        ts, blocks = [], []
+        for l in (0, 1, 2):
             P = plan.levels[l]
             ids = plan.local_rows(l)
             t = torch.zeros(len(ids), 2 + l)
             t[:P.n_own, 0] = torch.arange(P.lo, P.hi, dtype=torch.float32)
-            send = t[torch.from_numpy(np.concatenate(P.send_rows)).long()].contiguous()
-            mats.append((send, P.send_counts, t[P.n_own:], P.recv_counts))
+            t[:P.n_own, 1] = 7.0
+            idx = torch.from_numpy(np.concatenate(P.send_rows).astype(np.int32))
+            blocks.append((t, idx, P.send_counts, t[P.n_own:], P.recv_counts))
             ts.append((t, ids))
-        h = comm.exchange_begin(mats)
-        comm.finish(h)
+        px = PackedExchange(blocks, world)
+        assert sum(px.send_splits) == sum(sum(b[2]) * b[0].shape[1] for b in blocks)
+        for j in px.pack_jobs:
+            rows = j["src"][j["idx"][j["idx_off"]:j["idx_off"] + j["rows"]].long()]
+            j["dst"][j["dst_off"]:j["dst_off"] + j["rows"] * j["width"]] = rows.reshape(-1)
+        comm.all_to_all_flat(px.send_buf, px.send_splits, px.recv_buf, px.recv_splits)
+        for j in px.unpack_jobs:
+            j["dst"][j["dst_row"]:j["dst_row"] + j["rows"]] = \
+                j["src"][j["src_off"]:j["src_off"] + j["rows"] * j["width"]].view(j["rows"], j["width"])
         for t, ids in ts:
             ok &= bool(torch.equal(t[:, 0], torch.from_numpy(ids).float()))
+            ok &= bool((t[:, 1] == 7.0).all())
         comm.host_staged = True
         s = torch.tensor([float(rank + 1)])
         comm.all_reduce_sum(s)
