@@ -93,6 +93,10 @@ def main():
     out["method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes of tools/pmc_steps.py %d "
                      "(torus 250x200, 100000 facets, forward+backward+Adam); values of the last step; hbm = 2 x FETCH_SIZE "
                      "(gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; counter values are KB" % steps)
+    if len(sys.argv) > 5:
+        out["commit"] = sys.argv[5]
+    if len(sys.argv) > 6:
+        out["command"] = sys.argv[6]
     json.dump(out, open(outp, "w"), indent=1)
     ws = whole[-1]
     print("whole step: FETCH %.1f MB x2 + WRITE %.1f MB = %.1f MB over %d launches" % (
