@@ -67,7 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--nu", type=int, default=0, help="torus quads around the large circle (default: from --config)")
     ap.add_argument("--nv", type=int, default=0)
     ap.add_argument("--multi-scale", action="store_true", help="three-head network, step = multi-scale denoising forward")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
+                    help="storage of the activations: f32 (default, the headline) or bf16 (default of --config c3)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the step from hipGraphs, 0: eager launches, -1 (default): eager on one GPU (the step "
                          "is GPU-bound, replay is 1 %% faster), hipGraph segments between the exchanges on a facet-sharded "
@@ -87,6 +88,7 @@ def parse_args(argv=None):
     args.nv = args.nv or nv
     args.multi_scale = args.multi_scale or ms
     args.scaling = args.scaling or scaling
+    args.dtype = args.dtype or ("bf16" if args.config == "c3" else "f32")      # BASELINE config 3 is the bf16 train step
     args.what = "denoise" if args.multi_scale else what
     return args
 

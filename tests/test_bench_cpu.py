@@ -12,8 +12,9 @@ def test_config_presets_follow_the_survey():
     import bench
     a = bench.parse_args([])
     assert (a.gpus, a.nu, a.nv, a.multi_scale, a.scaling, a.what, a.dtype) == (1, 250, 200, False, "weak", "train", "f32")
-    a = bench.parse_args(["--config", "c3", "--dtype", "bf16"])
-    assert (a.nu, a.nv, a.what, a.dtype) == (250, 100, "train", "bf16")          # 50 000 facets
+    a = bench.parse_args(["--config", "c3"])
+    assert (a.nu, a.nv, a.what, a.dtype) == (250, 100, "train", "bf16")          # 50 000 facets, bf16 storage
+    assert bench.parse_args(["--config", "c3", "--dtype", "f32"]).dtype == "f32"
     a = bench.parse_args(["--config", "c4", "--gpus", "8"])
     assert (a.nu * a.nv * 2, a.scaling, a.what) == (1000000, "strong", "train")   # ONE 1M-facet mesh over the ranks
     a = bench.parse_args(["--config", "c5", "--gpus", "8"])
