@@ -2,7 +2,10 @@
 // /root/reference/Code/model.py:763-769,937-941).  The [n, hidden] activation never leaves the CU:
 // each wave produces 16-column slabs of it with f32 MFMA, applies bias + leaky ReLU in the
 // accumulator layout and folds them straight into the tiny second layer on the VALU.
+#include <algorithm>
+
 #include "fgc_reduce.h"
+#include "fgc_mlp_split.h"
 
 namespace fgc {
 
@@ -508,7 +511,7 @@ extern "C" size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t c
     // packed W1 + backward slabs (sized for the worst case n-independent parts; dx slabs are sized by the caller's n
     // through fgc_mlp_bwd_workspace_bytes below)
     (void)cout;
-    return align_up((size_t)mlp_kpad(cin) * hidden * sizeof(float), 256);
+    return std::max(align_up((size_t)mlp_kpad(cin) * hidden * sizeof(float), 256), mlp_split_pack_bytes(cin, hidden));
 }
 
 extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout) {
@@ -536,6 +539,10 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
                   "fgc_mlp_fwd: workspace too small");
     FGC_CHECK_ARG(alpha >= 0.f && alpha <= 1.f, "fgc_mlp_fwd: alpha=%g outside [0,1] (the reference uses 0.1, model.py:846)", alpha);
     hipStream_t st = (hipStream_t)stream;
+    // the two 1024-wide products on the bf16 matrix pipe with three-term operand splits (fgc_mlp_bf16.hip) where the shape
+    // allows: fp32-equivalent results, the matrix time a sixth of the fp32 MFMA's
+    if (mlp_fwd_split_ok(x, cin, hidden, cout) && (uintptr_t)workspace % 16 == 0)
+        return launch_mlp_fwd_split(x, n, cin, hidden, cout, W1, b1, W2, b2, alpha, y, abs_partial, workspace, st);
     const int kpad = mlp_kpad(cin);
     float* Wp = (float*)workspace;
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);

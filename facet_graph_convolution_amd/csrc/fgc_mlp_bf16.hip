@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "fgc_reduce.h"
+#include "fgc_mlp_split.h"
 
 namespace fgc {
 
@@ -107,6 +108,177 @@ __global__ __launch_bounds__(MB_THREADS, 4) void mlp_fwd_bf16_kernel(const unsig
             for (int t = 0; t < 4; ++t) {
                 float v = h[r][t];
                 v = lrelu01(v, alpha);    // leaky ReLU for 0 <= alpha <= 1 (checked by the host)
+#pragma unroll
+                for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
+            }
+    }
+    // reduce over the 16 column lanes, then over the four waves (fixed order)
+#pragma unroll
+    for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                float v = yp[r][t][o];
+                FGC_ROW16_SUM(v);
+                yp[r][t][o] = v;
+            }
+    if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int o = 0; o < CO; ++o) ypart[(wave * MB_FWD_T + r * 16 + lq * 4 + t) * 4 + o] = yp[r][t][o];
+    }
+    __syncthreads();
+    float asum = 0.f;
+    for (int t = threadIdx.x; t < MB_FWD_T * cout; t += MB_THREADS) {
+        const int r = t / cout, o = t % cout;
+        const int row = row0 + r;
+        if (row < n) {
+            float v = b2[o];
+            v += ypart[(0 * MB_FWD_T + r) * 4 + o];
+            v += ypart[(1 * MB_FWD_T + r) * 4 + o];
+            v += ypart[(2 * MB_FWD_T + r) * 4 + o];
+            v += ypart[(3 * MB_FWD_T + r) * 4 + o];
+            y[(size_t)row * cout + o] = v;
+            asum += fabsf(v);
+        }
+    }
+    if (abs_partial) {
+        for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off);
+        if (lane == 0) red[wave] = asum;
+        __syncthreads();
+        if (threadIdx.x == 0) abs_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 operands on the bf16 matrix pipe (the fp32 network's MLP).  v_mfma_f32_16x16x4_f32 runs at the vector FMA rate and
+// shares the SIMD with the vector ALU; the bf16 pipe is 16 times faster and runs beside it.  An
+// fp32 value is split into three bf16 terms v = v0 + v1 + v2 (v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1): 3 x 8
+// significand bits >= the 24 of fp32, same exponent range), and a product a b is the six bf16 MFMAs a0 b2 + a2 b0 + a1 b1 +
+// a0 b1 + a1 b0 + a0 b0 accumulated in fp32, smallest terms first.  Each bf16 x bf16 product is exact in fp32; the three
+// terms left out (a1 b2, a2 b1, a2 b2) are below 2^-25 of the product: the result differs from the fp32-MFMA kernel's by
+// summation order only (tests/test_gpu_ops.py compares the two).  FGC_NO_MLP_SPLIT=1 keeps the fp32 MFMA kernels.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(const f32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
+    p0 = f4_to_bf4(v);
+    const f32x4 r1 = v - bf4_to_f4(p0);
+    p1 = f4_to_bf4(r1);
+    const f32x4 r2 = r1 - bf4_to_f4(p1);
+    p2 = f4_to_bf4(r2);
+}
+
+// W1 [cin, hidden] fp32 -> three planes of B fragments [plane][k-step][column tile][lane][8] bf16
+__global__ void mlp_pack_split_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
+    const int nct = hidden >> 4;
+    const size_t total = (size_t)(cin >> 5) * nct * 512;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int ct = rest % nct, ks = (int)(rest / nct);
+        const int c = ks * 32 + 8 * (lane >> 4) + j;
+        const float w = W1[(size_t)c * hidden + ct * 16 + (lane & 15)];
+        const unsigned short w0 = f_to_bf(w);
+        const float r1 = w - bf_to_f(w0);
+        const unsigned short w1 = f_to_bf(r1);
+        const unsigned short w2 = f_to_bf(r1 - bf_to_f(w1));
+        Wp[idx] = w0;
+        Wp[total + idx] = w1;
+        Wp[2 * total + idx] = w2;
+    }
+}
+
+// six MFMAs of one split product, smallest terms first
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
+#define FGC_M16(A_, B_) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), acc, 0, 0, 0)
+    FGC_M16(a[0], b[2]);
+    FGC_M16(a[2], b[0]);
+    FGC_M16(a[1], b[1]);
+    FGC_M16(a[0], b[1]);
+    FGC_M16(a[1], b[0]);
+    FGC_M16(a[0], b[0]);
+#undef FGC_M16
+    return acc;
+}
+
+// forward: the bf16 kernel's structure (a workgroup = 64 rows, wave w walks the hidden column tiles w, w + 4, ...); x is
+// fp32 and is split once per workgroup, the weights come split from mlp_pack_split_kernel.
+template <int KS, int CO>
+__global__ __launch_bounds__(MB_THREADS, 2) void mlp_fwd_split_kernel(const float* __restrict__ x, int n, int hidden, int cout,
+                                                                      const u32x4* __restrict__ Wp16,
+                                                                      const float* __restrict__ b1,
+                                                                      const float* __restrict__ W2,
+                                                                      const float* __restrict__ b2, float alpha,
+                                                                      float* __restrict__ y, float* __restrict__ abs_partial) {
+    __shared__ float ypart[4 * MB_FWD_T * 4];
+    __shared__ float red[4];
+    constexpr int CIN = KS * 32;
+    const int row0 = blockIdx.x * MB_FWD_T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int nct = hidden >> 4;
+    const size_t plane = (size_t)KS * nct * 64;            // u32x4 per plane
+    u32x4 a[MB_FWD_RT][KS][3];
+#pragma unroll
+    for (int r = 0; r < MB_FWD_RT; ++r) {
+        const int row = min(row0 + r * 16 + lr, n - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)row * CIN + ks * 32 + 8 * lq);
+            u32x2 lo[3], hi[3];
+            split3(src[0], lo[0], lo[1], lo[2]);
+            split3(src[1], hi[0], hi[1], hi[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[r][ks][p] = u32x4{lo[p][0], lo[p][1], hi[p][0], hi[p][1]};
+        }
+    }
+    float yp[MB_FWD_RT][4][CO];
+#pragma unroll
+    for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) yp[r][t][o] = 0.f;
+
+    u32x4 bnext[KS][3];
+    float bbn = 0.f, w2n[CO];
+    auto fetch_weights = [&](int ct) {   // (clamped: always a valid load)
+        ct = min(ct, nct - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bnext[ks][p] = Wp16[p * plane + ((size_t)ks * nct + ct) * 64 + lane];
+        bbn = b1[ct * 16 + lr];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) w2n[o] = W2[(size_t)(ct * 16 + lr) * cout + min(o, cout - 1)];
+    };
+    fetch_weights(wave);
+    for (int ct = wave; ct < nct; ct += 4) {
+        u32x4 bcur[KS][3];
+        float w2[CO];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bcur[ks][p] = bnext[ks][p];
+        const float bb = bbn;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) w2[o] = o < cout ? w2n[o] : 0.f;
+        fetch_weights(ct + 4);
+        f32x4 h[MB_FWD_RT];
+#pragma unroll
+        for (int r = 0; r < MB_FWD_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int r = 0; r < MB_FWD_RT; ++r) h[r] = mfma_split(a[r][ks], bcur[ks], h[r]);
+#pragma unroll
+        for (int r = 0; r < MB_FWD_RT; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = h[r][t] + bb;      // (the bias is added last: riding in the accumulator it would swallow the small terms)
+                v = lrelu01(v, alpha);
 #pragma unroll
                 for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
             }
@@ -478,6 +650,39 @@ static int mb_gx(int n) {
     const int wg = cdiv(ntiles, 4);
     return (wg < 32 ? wg : 32) * 4;
 }
+
+namespace fgc {
+// ---- the fp32 network's MLP through split operands (called by fgc_mlp_fwd in fgc_mlp.hip) ----------------
+bool mlp_split_enabled() {
+    static const bool on = !(getenv("FGC_NO_MLP_SPLIT") && getenv("FGC_NO_MLP_SPLIT")[0] == '1');
+    return on;
+}
+size_t mlp_split_pack_bytes(int cin, int hidden) { return align_up((size_t)3 * cin * hidden * 2, 256); }
+bool mlp_fwd_split_ok(const float* x, int cin, int hidden, int cout) {
+    return mlp_split_enabled() && (cin == 32 || cin == 64) && hidden % 256 == 0 && cout <= 4 && (uintptr_t)x % 16 == 0;
+}
+int launch_mlp_fwd_split(const float* x, int n, int cin, int hidden, int cout, const float* W1, const float* b1, const float* W2,
+                         const float* b2, float alpha, float* y, float* abs_partial, void* workspace, hipStream_t st) {
+    unsigned short* Wp = (unsigned short*)workspace;
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_split_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
+    const u32x4* Wp16 = (const u32x4*)Wp;
+    const dim3 grid(cdiv(n, MB_FWD_T));
+#define FGC_MS_FWD(KS)                                                                                                       \
+    do {                                                                                                                     \
+        if (cout <= 3)                                                                                                       \
+            FGC_LAUNCH("mlp_fwd_kernel", st, (mlp_fwd_split_kernel<KS, 3>), grid, dim3(MB_THREADS), 0, x, n, hidden, cout, Wp16, b1, \
+                       W2, b2, alpha, y, abs_partial);                                                                       \
+        else                                                                                                                 \
+            FGC_LAUNCH("mlp_fwd_kernel", st, (mlp_fwd_split_kernel<KS, 4>), grid, dim3(MB_THREADS), 0, x, n, hidden, cout, Wp16, b1, \
+                       W2, b2, alpha, y, abs_partial);                                                                       \
+    } while (0)
+    if (cin == 32) FGC_MS_FWD(1);
+    else FGC_MS_FWD(2);
+#undef FGC_MS_FWD
+    FGC_CHECK_LAUNCH("fgc_mlp_fwd (split operands)");
+    return FGC_OK;
+}
+}  // namespace fgc
 
 extern "C" size_t fgc_mlp_bf16_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout) {
     (void)cout;

@@ -1,4 +1,6 @@
 """GPU parity of the MLP and the element-wise / reduction ops against the oracle (torch fp32/fp64 on CPU)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -23,6 +25,35 @@ def test_mlp_forward(n, cin):
     y, part = ops.mlp_fwd(x.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), 0.1, want_abs_partial=True)
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=3e-6)
     assert abs(part.sum().item() - ref.abs().sum().item()) < 1e-4 * ref.abs().sum().item()
+
+
+def test_mlp_forward_split_operands_are_as_accurate_as_the_fp32_mfma():
+    """fgc_mlp_fwd runs its 1024-wide product on the bf16 matrix pipe with three-term operand splits (six bf16 MFMAs
+    per product, fp32 accumulation; fgc_mlp_bf16.hip) and keeps the fp32-MFMA kernel behind FGC_NO_MLP_SPLIT=1.  Both
+    against a float64 reference on the same inputs: the split form must be as close as the fp32 MFMA is."""
+    import subprocess, sys, textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import numpy as np, torch
+        from facet_graph_convolution_amd import ops
+        rs = np.random.RandomState(5)
+        x = torch.from_numpy(rs.normal(size=(4096, 32)).astype(np.float32))
+        W1 = torch.from_numpy(rs.normal(0, 0.05, (32, 1024)).astype(np.float32)); b1 = torch.from_numpy(rs.normal(0, 0.01, 1024).astype(np.float32))
+        W2 = torch.from_numpy(rs.normal(0, 0.05, (1024, 3)).astype(np.float32)); b2 = torch.from_numpy(rs.normal(0, 0.01, 3).astype(np.float32))
+        h = x.double() @ W1.double() + b1.double()
+        ref = torch.where(h > 0, h, 0.1 * h) @ W2.double() + b2.double()
+        y = ops.mlp_fwd(x.cuda(), W1.cuda(), b1.cuda(), W2.cuda(), b2.cuda(), 0.1)
+        y = y[0] if isinstance(y, tuple) else y
+        print("ERR %.6e" % (y.cpu().double() - ref).abs().max().item())
+    """)
+    errs = {}
+    for tag, env in (("split", {}), ("fp32", {"FGC_NO_MLP_SPLIT": "1"})):
+        out = subprocess.run([sys.executable, "-c", code], cwd=repo, env=dict(os.environ, **env), capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        errs[tag] = float([l for l in out.stdout.splitlines() if l.startswith("ERR")][0].split()[1])
+    assert errs["fp32"] < 3e-6 and errs["split"] < 3e-6
+    assert errs["split"] < 2.0 * errs["fp32"] + 2e-7, errs
 
 
 @pytest.mark.parametrize("n,cin", [(1000, 32), (77, 32), (5000, 32), (6, 32), (900, 64), (333, 128), (70, 48)])
