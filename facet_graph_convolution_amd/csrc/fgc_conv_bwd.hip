@@ -110,6 +110,12 @@ struct LogitParams {
 };
 
 constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> ceil(18/4)
+// developer knock-outs of the deep d-logits kernel for phase timing (results are wrong with any bit set; never set in the
+// shipped build): 1 = no dz-GEMM MFMAs, 2 = no packed-weight loads, 4 = no dz tile stores, 8 = no per-node product MFMAs,
+// 16 = no neighbour-row gathers, 32 = no softmax backward / dl stores
+#ifndef FGC_KO1
+#define FGC_KO1 0
+#endif
 
 template <int LPN, bool VEC4>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_kernel(CoreParams p, LogitParams lp) {
@@ -637,6 +643,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
                 for (int nn = 0; nn < H; ++nn) {
                     const unsigned off = __umul24((unsigned)rowid[n0 + nn], rowbytes) + laneoff;
+                    if (FGC_KO1 & 16) { bx[nn][0] = bx[nn][1] = f32x4{__uint_as_float(off), 1.f, 2.f, 3.f}; continue; }
                     bx[nn][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                     bx[nn][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64u, 0, 0));
                 }
@@ -657,6 +664,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c) {
                         const int ct = min(wave + c * 4, nct - 1);
+                        if (FGC_KO1 & 2) { b[c] = f32x4{(float)ct, (float)soff, 1.f, 2.f}; continue; }
                         b[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                              wq_rs, (unsigned)((lq * KPASS + ct * 16 + lr) * 16), soff, 0));
                     }
@@ -679,8 +687,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
-                            for (int r = 0; r < RT; ++r)
-                                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+                            for (int r = 0; r < RT; ++r) {
+                                if (FGC_KO1 & 1) asm volatile("" ::"v"(a[r][t]), "v"(b[c][t]));
+                                else acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+                            }
                     }
                 };
                 if constexpr (OKG >= 4) {
@@ -708,6 +718,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 for (int c = 0; c < K1_CTW; ++c) {
                     const int ct = wave + c * 4;
                     if (ct >= nct) continue;
+                    if (FGC_KO1 & 4) { if (acc[0][c][0] == 123.f) s.ztile[tid] = acc[1][c][3]; continue; }
 #pragma unroll
                     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -727,6 +738,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                     f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {  // two independent accumulation chains
+                        if (FGC_KO1 & 8) { t0[t] += a0[t] * bx[nn][0][t]; t1[t] += a1[t] * bx[nn][1][t]; continue; }
                         t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], bx[nn][0][t], t0, 0, 0, 0);
                         t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], bx[nn][1][t], t1, 0, 0, 0);
                     }
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
             }
             const int e0 = s.deg[TILE + 4 + node];     // first edge id, left in LDS by the softmax phase
             f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int ntile = (LONG && d > 16) ? 2 : 1;
+            const int ntile = (FGC_KO1 & 32) ? 0 : ((LONG && d > 16) ? 2 : 1);
             for (int et = 0; et < ntile; ++et) {
                 const int edge = ebase + 16 * et + lr;
                 const bool ok = edge < d;
