@@ -24,12 +24,12 @@ def _oracle_inputs(x, adjs, gt):
             torch.tensor(gt.astype(np.float32)))
 
 
-def _train_step_vs_oracle(x, adjs, gt):
+def _train_step_vs_oracle(x, adjs, gt, dtype="f32", tol=(2e-5, 1e-4, 2e-3)):
     from facet_graph_convolution_amd.net import FacetDenoiser
     from facet_graph_convolution_amd.utils import rand_rotation_matrix
     from oracle import model_ref as R
     torch.set_num_threads(min(len(__import__("os").sched_getaffinity(0)), 32))
-    net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+    net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
     samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
     Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
     net.set_samples(samp)
@@ -41,16 +41,25 @@ def _train_step_vs_oracle(x, adjs, gt):
     ref_loss, n_conv = R.train_loss(xt, adjt, gtt, params, samp, torch.tensor(Rm.astype(np.float32)))
     ref_loss.backward()
     err_n = (net.buffers["nconv"].cpu() - n_conv[0].detach()).abs().max().item()
-    assert err_n < 2e-5, err_n
-    assert abs(loss[0].item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
-    worst = 0.0
+    assert err_n < tol[0], err_n
+    assert abs(loss[0].item() - ref_loss.item()) < tol[1] * abs(ref_loss.item())
+    worst, worst_of = 0.0, None
     for i, (g, p) in enumerate(zip(net.params.grads, params)):
         scale = max(p.grad.abs().max().item(), 1e-3)
         err = (g.cpu() - p.grad).abs().max().item() / scale
-        worst = max(worst, err)
-        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
-    print("N0 = %d: |normals - oracle| %.2e, worst rel grad err %.2e" % (x.shape[1], err_n, worst))
+        if err > worst:
+            worst, worst_of = err, net.params.spec[i]
+        assert err < tol[2], "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
+    print("N0 = %d: |normals - oracle| %.2e, worst rel grad err %.2e (%s)" % (x.shape[1], err_n, worst, worst_of))
     return net
+
+
+def test_39k_facet_bf16_storage_train_step_within_its_stated_tolerance_of_the_oracle():
+    """The bf16-storage network (BASELINE config 3) at the same scale against the fp32 oracle: unit normals 5e-3 abs and
+    loss 1e-2 rel as tests/test_gpu_bf16.py states them; gradients within 8e-2 of each tensor's largest entry (measured:
+    normals 1.4e-3, worst gradient 5.4e-2 - a 64-entry conv bias, i.e. column sums of bf16-stored rows over 12 000 nodes)."""
+    x, adjs, gt = _mesh(140, 140)
+    _train_step_vs_oracle(x, adjs, gt, dtype="bf16", tol=(5e-3, 1e-2, 8e-2))
 
 
 def test_39k_facet_train_step_matches_oracle():
