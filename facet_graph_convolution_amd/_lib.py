@@ -47,7 +47,7 @@ class ConvBwdIO(C.Structure):
         ("accumulate0", C.c_int32), ("accumulate1", C.c_int32),
         ("dW0", C.c_void_p), ("db", C.c_void_p), ("du", C.c_void_p), ("dc", C.c_void_p), ("dv", C.c_void_p),
         ("data_tile_list", C.c_void_p), ("n_data_tiles", C.c_int32), ("flags", C.c_int32),
-        ("z_saved", C.c_void_p),
+        ("z_saved", C.c_void_p), ("pool_y", C.c_void_p), ("pool_dy", C.c_void_p),
     ]
 
 

@@ -35,6 +35,19 @@ __global__ void pack_weight_kernel(const float* __restrict__ W0, float* __restri
 
 __device__ __forceinline__ float slope_from_y(float y, float alpha) { return y > 0.f ? 1.f : (y < 0.f ? alpha : 0.f); }
 
+// What the 4:1 max pooling sends back to row r, column col of its input y: the pooled gradient split evenly over the rows
+// of the group that equal the maximum (tf.reduce_max's gradient; fgc_pool4_bwd as a term of fgc_conv_bwd_io.pool_dy).
+__device__ __forceinline__ float pool4_grad_term(const float* __restrict__ y, const float* __restrict__ pool_y,
+                                                 const float* __restrict__ pool_dy, int r, int col, int cout, int bf16) {
+    const size_t pi = (size_t)(r >> 2) * cout + col;
+    const float m = ld_act(pool_y, pi, bf16);
+    const size_t b = (size_t)(r & ~3) * cout + col;
+    float ne = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ne += ld_act(y, b + (size_t)k * cout, bf16) == m ? 1.f : 0.f;
+    return ld_act(y, (size_t)r * cout + col, bf16) == m ? ld_act(pool_dy, pi, bf16) / ne : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // s = dy * lrelu'(y) / deg ; db partial column sums of dy * lrelu'(y) over rows that got the bias
 // ---------------------------------------------------------------------------------------------
@@ -44,7 +57,8 @@ __global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy
                                                     const int* __restrict__ rowptr, int n, int cout, int cp2, int act,
                                                     float alpha, int bias_mask, int rows_per_block,
                                                     float* __restrict__ ds, float* __restrict__ db_part, int in_bf16,
-                                                    int out_bf16) {
+                                                    int out_bf16, const float* __restrict__ pool_y,
+                                                    const float* __restrict__ pool_dy) {
     __shared__ float part[256];
     const int col = threadIdx.x % cp2, rl = threadIdx.x / cp2, nrl = 256 / cp2;
     const int r0 = blockIdx.x * rows_per_block;
@@ -54,6 +68,7 @@ __global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy
         for (int r = r0 + rl; r < r1; r += nrl) {
             const int d = rowptr[r + 1] - rowptr[r];
             float g = ld_act(dy, (size_t)r * cout + col, in_bf16);
+            if (pool_dy) g += pool4_grad_term(y, pool_y, pool_dy, r, col, cout, in_bf16);
             if (act) g *= slope_from_y(ld_act(y, (size_t)r * cout + col, in_bf16), alpha);
             if (!bias_mask || d > 0) acc += g;
             st_act(ds, (size_t)r * cout + col, d > 0 ? g / (float)d : 0.f, out_bf16);
@@ -107,6 +122,8 @@ struct LogitParams {
     float* db_part;      // [cdiv(n, TILE), cout]
     int a_global;        // LONG form, cout % 16 == 0: the dz GEMM reads its ds operand from global memory (the tile is
                          // L1-resident) instead of an LDS copy, which keeps two workgroups per CU for wide layers
+    const float* pool_y;   // fused prologue only: fgc_conv_bwd_io.pool_y / pool_dy (NULL = no pooled gradient to fold in)
+    const float* pool_dy;
 };
 
 constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> ceil(18/4)
@@ -538,8 +555,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 const int t = min(tid + k * NTHREADS, vmax);
                 const int i = tile0 + t / (OKG * 4);
                 gy[k] = dy4[t];
-                if (lp.act) yy[k] = y4[t];
+                if (lp.act || lp.pool_dy) yy[k] = y4[t];
                 dg[k] = p.rowptr[i + 1] - p.rowptr[i];
+            }
+            if (lp.pool_dy) {
+                // the gradient of the 4:1 max pooling of this layer's output, folded in here instead of a pass of its own
+                // over dy: the four rows of a pooling group sit in the same tile (tile0 is a multiple of 32)
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int t = min(tid + k * NTHREADS, vmax);
+                    const int rl = t / (OKG * 4), c4 = t % (OKG * 4);
+                    const size_t pi = (size_t)((tile0 + rl) >> 2) * (OKG * 4) + c4;
+                    const f32x4 m = reinterpret_cast<const f32x4*>(lp.pool_y)[pi];
+                    const f32x4 gp = reinterpret_cast<const f32x4*>(lp.pool_dy)[pi];
+                    f32x4 ne = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int tq = min(((rl & ~3) + q) * (OKG * 4) + c4, vmax);
+                        const f32x4 yq = y4[tq];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ne[c] += yq[c] == m[c] ? 1.f : 0.f;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gy[k][c] += yy[k][c] == m[c] ? gp[c] / ne[c] : 0.f;
+                }
             }
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -1712,10 +1751,13 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     FGC_CHECK_ARG(!bf16 || narrow_path || (deep_ok && cout % 32 == 0),
                   "fgc_conv_bwd: FGC_CONV_BF16 needs widths that are multiples of 32, 16-byte aligned tensors and degrees <= %d "
                   "(cin=%d cout=%d max_deg=%d)", KMAX, cin, cout, d->max_deg);
+    FGC_CHECK_ARG(!io->pool_dy || (io->pool_y && io->y && d->n % 4 == 0),
+                  "fgc_conv_bwd: pool_dy needs pool_y, y and a row count that is a multiple of 4 (n=%d)", d->n);
     const bool fuse_ds = !bf16 && (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, TILE) &&
                          !(d->max_deg > 16 && cout > 32) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
+                         (!io->pool_dy || (((uintptr_t)io->y | (uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % 16) == 0) &&
                          !(getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1');
     // s = dy*lrelu'(y)/deg, db partials
     if ((stages & 1) && !fuse_ds) {
@@ -1723,7 +1765,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         while (cp2 < cout) cp2 <<= 1;
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
                    d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part, bf16 ? 1 : 0,
-                   (bf16 && !narrow_path) ? 1 : 0);
+                   (bf16 && !narrow_path) ? 1 : 0, io->pool_dy ? io->pool_y : nullptr, io->pool_dy);
         FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");   // db partials are summed with the other parameter gradients (stage 8)
     }
     // first layer over a narrow input (no input gradient wanted): vector-ALU path, no transposed graph, no r buffer
@@ -1772,6 +1814,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             lp.alpha = d->alpha;
             lp.ds_out = io->ds;
             lp.db_part = w.db_part;
+            lp.pool_y = io->pool_dy ? io->pool_y : nullptr;
+            lp.pool_dy = io->pool_dy;
         }
         size_t smem = smem_core_bytes(g1.zstride) + (size_t)(TILE * ostride + 48) * 4;
         const bool vec4 = conv_vec4_ok(d);

@@ -145,6 +145,8 @@ class FacetDenoiser:
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
         self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
+        # the gradient of the 4:1 max pooling behind conv1 / conv2 is a term of those layers' backward stage 1
+        self.fused_pool = os.environ.get("FGC_NO_FUSED_POOL", "0") != "1"
         # parameter slots
         k = 0
         self.slot = {}
@@ -328,6 +330,9 @@ class FacetDenoiser:
             io.accumulate0, io.accumulate1 = 0, 0
         ios["conv1"].dx0 = None
         ios["conv1"].dx1 = None
+        if self.fused_pool and gt is not None:
+            ios["conv1"].pool_y, ios["conv1"].pool_dy = B["p1"].data_ptr(), B["g_p1"].data_ptr()
+            ios["conv2"].pool_y, ios["conv2"].pool_dy = B["p2"].data_ptr(), B["g_p2"].data_ptr()
         if self.multi_scale and gt is not None and plan is None:
             # training the three heads: the coarse heads write their input gradients into g_d3 / g_d2 first, the
             # up-convolutions then add theirs
@@ -589,10 +594,12 @@ class FacetDenoiser:
                                  _p(grads[s + 2]), _p(grads[s + 3]), _p(ws), ws.numel(), st), "head0 bwd")
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
             self._tag("bwd:" + name)
-            if name == "conv2":   # g_h2 += d pool2
+            # (g_h2 += d pool2 and g_h1 += d pool1 are folded into stage 1 of conv2 / conv1: fgc_conv_bwd_io.pool_y / pool_dy;
+            #  FGC_NO_FUSED_POOL=1: by launches of their own)
+            if name == "conv2" and not self.fused_pool:
                 _lib.check(self._pool4_bwd(_p(B["h2"]), _p(B["p2"]), _p(B["g_p2"]), _p(B["g_h2"]), ns[2], 64, 1, st),
                            "pool2 bwd")
-            if name == "conv1":   # g_h1 += d pool1
+            if name == "conv1" and not self.fused_pool:
                 _lib.check(self._pool4_bwd(_p(B["h1"]), _p(B["p1"]), _p(B["g_p1"]), _p(B["g_h1"]), ns[1], 32, 1, st),
                            "pool1 bwd")
             d, io = M["descs"][name], M["ios"][name]

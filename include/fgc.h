@@ -252,6 +252,13 @@ typedef struct fgc_conv_bwd_io {
     int32_t flags;                 /* FGC_CONV_PACKED: the operands are already packed (an earlier stage call, or
                                     * fgc_conv_pack); FGC_CONV_DEFER_REDUCE: see fgc_conv_bwd_reduce */
     const float* z_saved;          /* optional: the workspace of the forward call made with FGC_CONV_SAVE_Z */
+    /* optional: the layer's output also went through the 4:1 max pooling (custom_binary_tree_pooling, model.py:779-788)
+     * and the pooled tensor's gradient is still to be folded in: stage 1 then uses
+     *   dy_i + [y_i == pool_y_(i/4)] * pool_dy_(i/4) / #{rows of the group equal to the maximum}
+     * instead of dy_i (tf.reduce_max's gradient, as fgc_pool4_bwd computes it) - no separate pass over dy.
+     * pool_y, pool_dy: [n / 4, cout], the pooled output and its gradient (bf16 with FGC_CONV_BF16). */
+    const float* pool_y;
+    const float* pool_dy;
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);

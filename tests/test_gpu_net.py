@@ -325,6 +325,31 @@ def test_whole_network_pack_and_reduce_match_the_per_layer_path():
         assert torch.equal(a, b)
 
 
+def test_pool_gradient_folded_into_the_conv_backward_equals_the_separate_pass():
+    """fgc_conv_bwd_io.pool_y / pool_dy: the gradient of the 4:1 max pooling behind conv1 and conv2 is added to dy inside
+    stage 1 of those layers (the d-logits kernel's prologue for conv2, ds_db_kernel for the narrow first layer) instead of
+    two fgc_pool4_bwd launches: same additions in the same order, so every gradient is bit-identical."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = icosphere(3)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    out = []
+    for fused in (True, False):
+        net = FacetDenoiser("cuda:0", seed=0)
+        net.fused_pool = fused
+        net.bind_mesh(x, adjs, gt=gt)
+        losses = [net.train_step(sample_ind=samp, R=Rm)[0].item() for _ in range(3)]
+        out.append((losses, net.params.grad.clone(), net.params.theta.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
 def test_graph_replay_survives_a_device_synchronise():
     """forward_backward(capture=True) replays one hipGraph per step.  With ROCm's pre-built graph packets a replay
     enqueued after a hipDeviceSynchronize went wrong (loss 88 deg instead of 33); the package turns that runtime
