@@ -82,14 +82,14 @@ struct Smem {
 };
 
 // qslots: edge slots per node the kernel keeps (KMAX, or 16 where the host guarantees max_deg <= 16: 12 KB less LDS)
-__device__ __forceinline__ Smem carve(char* base, int zstride, int qslots = KMAX) {
+__device__ __forceinline__ Smem carve(char* base, int zstride, int qslots = KMAX, int nodes = TILE) {
     Smem s;
     s.ztile = reinterpret_cast<float*>(base);
-    size_t off = (size_t)TILE * zstride * 4;
+    size_t off = (size_t)nodes * zstride * 4;
     s.qbuf = reinterpret_cast<float*>(base + off);
-    off += (size_t)TILE * qnode_stride(qslots) * 4;
+    off += (size_t)nodes * qnode_stride(qslots) * 4;
     s.deg = reinterpret_cast<int*>(base + off);
-    off += (2 * TILE + 4) * 4;
+    off += (2 * nodes + 4) * 4;
     s.extra = reinterpret_cast<float*>(base + off);
     return s;
 }

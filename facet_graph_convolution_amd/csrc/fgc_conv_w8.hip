@@ -113,28 +113,38 @@ __device__ __forceinline__ void wave_lds_sync() {
 // BF: bf16 storage (FGC_CONV_BF16).  The gathered rows, y / y_pool (forward), r and dx (data gradient) are bf16; the
 // aggregate tile is kept in LDS as bf16 and the tile product runs on v_mfma_f32_16x16x32_bf16 (fp32 accumulators).  The
 // soft assignment, the aggregation FMAs and every epilogue stay fp32.  FAST shapes only.
-template <bool DATA, bool FAST, int QS, bool BF = false>
-__global__ __launch_bounds__(W8_THREADS, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+// NT: nodes per workgroup, 32 (eight waves) or 16 (four waves: a half tile each; twice the workgroups, four instead of two
+// resident per CU at the same 16 waves, and twice the packed-weight traffic per node).  NT = 16 needs npad <= 64.
+template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32>
+__global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     static_assert(!BF || FAST, "the bf16 form exists for the fast shapes only");
+    static_assert(NT == 32 || (NT == 16 && FAST && QS == 16), "half tiles: the pipelined 16-slot form only");
+    constexpr int TILE = NT, RT = NT / 16, NW = NT / 4, LW = NT == 32 ? 3 : 2, W8_THREADS = NT * 16;   // (shadow the 32-node constants)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS);
+    const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS, NT);
     constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
     constexpr bool PIPE = FAST && QS == 16;            // rows requested one phase ahead (gather_rows / fma_rows)
     float* dagt = s.extra;  // DATA: [TILE][24]
-    const int tile0 = block_tile0(p);
+    int tile0;
+    if constexpr (NT == 32) {
+        tile0 = block_tile0(p);
+    } else {   // half tiles: workgroup h of 2 * tiles; the XCD map runs over half tiles
+        const int h = xcd_tile(blockIdx.x, gridDim.x);
+        tile0 = (p.tile_list ? p.tile_list[h >> 1] : (h >> 1)) * 32 + (h & 1) * 16;
+    }
     const int tid = threadIdx.x;
     const int node = tid >> 4, kl = tid & 15;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     // ---------------- MFMA tiling: wave w owns column tile (w % nct) and k-part (w / nct)
     const int nct = p.npad >> 4;              // 1, 2, 4 or 8
     const int nsh = 31 - __builtin_clz(nct);
-    const int kparts = 8 >> nsh;
+    const int kparts = NW >> nsh;
     const int ct = __builtin_amdgcn_readfirstlane(wave & (nct - 1));
     const int kpart = __builtin_amdgcn_readfirstlane(wave >> nsh);
     // units of the reduction index per pass: 16-deep k-groups (fp32, four MFMAs deep) or 32-deep k-steps (bf16)
     constexpr int UPP = BF ? KPASS / 32 : KPASS / 16;
-    const int u0 = __builtin_amdgcn_readfirstlane((UPP * kpart) >> (3 - nsh));
-    const int u1 = __builtin_amdgcn_readfirstlane((UPP * (kpart + 1)) >> (3 - nsh));
+    const int u0 = __builtin_amdgcn_readfirstlane((UPP * kpart) >> (LW - nsh));
+    const int u1 = __builtin_amdgcn_readfirstlane((UPP * (kpart + 1)) >> (LW - nsh));
     // packed weights through a buffer descriptor: the lane's part of the offset is computed once, the unit's part is
     // scalar (the plain indexed form spent two 64-bit multiplies per fragment load on the vector ALU)
     //   fp32: [unit][4 rows of float4: lq][npad columns]     bf16: [unit][column tile][lane] x 8 bf16
@@ -591,6 +601,17 @@ static bool w8_fast(const CoreParams& p) {
     return p.cg % 32 == 0 && (p.c1 == 0 || p.c0 % 32 == 0) && (size_t)p.n * 4 * 128 < 0xFFFFFFFFull;
 }
 
+// Half tiles (16 nodes, four waves per workgroup, four workgroups per CU): the forward kernel of layers up to 64 outputs
+// wide.  Measured on the 100k-facet mesh: level-0 forward 98.8 -> 85.6 us (four independently phased workgroups per CU
+// overlap their gather, aggregate and matrix phases better than two, and that outweighs reading the packed weights twice
+// as often), 64-wide level-1 forward 62.1 -> 60.5; the data-gradient kernel 126.4 -> 129.6 (its epilogue and its r / dl
+// traffic dominate), so it keeps 32-node tiles.  FGC_W8_NT16 = 0: never, 2: the data kernel too (developer switch).
+template <bool DATA>
+static bool w8_half_tiles(const CoreParams& p) {
+    static const int mode = getenv("FGC_W8_NT16") ? atoi(getenv("FGC_W8_NT16")) : 1;
+    return (DATA ? mode >= 2 : mode >= 1) && (p.npad >> 4) <= 4;
+}
+
 template <bool DATA, bool FAST, int QS, bool BF = false>
 static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
     static bool attr = false;
@@ -598,6 +619,17 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
         hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST, QS, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr = true;
+    }
+    if constexpr (FAST && QS == 16) {
+        if (w8_half_tiles<DATA>(p)) {
+            constexpr int NT = 16;
+            const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
+            const size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + (DATA ? (size_t)NT * 24 * 4 : 0) + 64;
+            FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT>),
+                       dim3(2 * core_grid(p)), dim3(NT * 16), smem16, p, fe, de);
+            FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles)");
+            return FGC_OK;
+        }
     }
     smem -= (size_t)TILE * (qnode_stride(KMAX) - qnode_stride(QS)) * 4;     // the caller sized the tile for KMAX slots
     if (BF) smem -= (size_t)TILE * (ZSTRIDE * 4 - ZSTRIDE_BF * 2);   // ... and for the fp32 aggregate tile
