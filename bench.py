@@ -61,8 +61,8 @@ CONFIGS = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--nu", type=int, default=0, help="torus quads around the large circle (default: from --config)")
     ap.add_argument("--nv", type=int, default=0)
