@@ -518,11 +518,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 // on demand.  Without it such tiles took the two-sweep path below, i.e. the dz GEMM twice.
 // OKG = cout / 16 for cout = 32 and 64 (strides of the ds tile become compile-time, its load one coalesced dwordx4
 // stream issued up front), 0 = any cout (measured faster than OKG = 8 for the 128-wide layers of the coarsest level)
-template <bool LONG, int OKG>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
+// NT_ nodes per workgroup, NPW_ nodes per wave.  (32, 8): the form described above, four waves, 68 KB of LDS, 188 registers:
+// two workgroups = two waves per SIMD per CU.  (16, 4), regular graphs only: four waves on HALF a tile - half the per-wave
+// state (gathers of 4 nodes instead of 8), 34 KB of LDS: four workgroups per CU if the registers stay under 128.
+template <bool LONG, int OKG, int NT_ = 32, int NPW_ = 8>
+__global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
+    static_assert((NT_ == 32 && NPW_ == 8) || (NT_ == 16 && NPW_ == 4 && !LONG), "tile shapes");
+    // (shadow the 32-node constants of the file)
+    constexpr int TILE = NT_, NPW = NPW_, NWV = NT_ / NPW_, NTHREADS = NWV * 64, RT = NT_ / 16, LPN = NTHREADS / NT_;
+    static_assert(NWV == 4, "four waves either way: the column-tile split and the dc sums below assume it");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int QS = LONG ? KMAX : 16;        // the host sends graphs with a degree above 16 to the LONG form
-    const Smem s = carve(smem_raw, ZSTRIDE, QS);
+    const Smem s = carve(smem_raw, ZSTRIDE, QS, NT_);
     const int opad = OKG ? OKG * 16 : lp.opad;
     const int ostride = OKG ? OKG * 16 + 8 : lp.ostride;
     float* dst = s.extra;                       // ds tile [TILE][ostride]
@@ -536,9 +543,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
         // no LDS copy of the ds tile
     } else if constexpr (OKG > 0) {
         // rows tile0 .. tile0+31 of ds are one contiguous run of 32 * cout floats (cout == opad)
-        constexpr int V4 = TILE * OKG * 16 / 4;          // float4s in the tile: 128 * OKG
+        constexpr int V4 = TILE * OKG * 16 / 4;          // float4s in the tile: 128 * OKG (half tiles: 64 * OKG)
         constexpr int PER = (V4 + NTHREADS - 1) / NTHREADS;
-        static_assert(V4 % NTHREADS == 0, "whole float4s per thread");
+        static_assert(V4 % NTHREADS == 0 || V4 < NTHREADS, "whole float4s per thread, or fewer float4s than threads");
         const f32x4* src = reinterpret_cast<const f32x4*>(lp.ds + (size_t)tile0 * (OKG * 16));
         const int vmax = (min(p.n - tile0, TILE) * OKG * 16) / 4 - 1;     // last valid float4 (n > tile0)
         f32x4 v[PER];
@@ -596,7 +603,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
                 if (ok) out4[t] = sv;
                 const bool counts = ok && (!lp.bias_mask || dg[k] > 0);
                 const int r = t / (OKG * 4), o4 = t % (OKG * 4);
-                *reinterpret_cast<f32x4*>(dst + r * ostride + o4 * 4) = counts ? g : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (V4 % NTHREADS == 0 || t < V4)
+                    *reinterpret_cast<f32x4*>(dst + r * ostride + o4 * 4) = counts ? g : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
             {
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_deep_kernel(CoreP
             dst[r * ostride + o] = (i < p.n && o < lp.cout) ? lp.ds[(size_t)i * lp.cout + o] : 0.f;
         }
     }
-    const int dmine = softmax_phase<false, QS>(p, s, tile0, 0, nullptr, nullptr);
+    const int dmine = softmax_phase<false, QS, NT_, LPN>(p, s, tile0, 0, nullptr, nullptr);
     // edges 0..15 of every node in sweep 0; a second sweep (block-uniform, rare) for nodes with 17..24 edges.  The
     // per-edge work is independent across edges, so a sweep is the whole computation for its 16 edge slots.
     (void)dmine;
@@ -1608,6 +1616,22 @@ static int tn_splits(int P, int Q, int rows) {
     return tn_balanced_splits(8 * std::max(1, 128 / tiles), cdiv(rows, 128), rows);
 }
 
+// Nodes per workgroup of the deep d-logits kernel: half tiles (16 nodes, four workgroups per CU) for the fp32 network on
+// regular graphs.  A function of the descriptor alone: the partial-sum slots (dc per workgroup, db per tile of the fused
+// prologue and of ds_db_kernel) are counted in these units by the workspace plan, the launches and the reductions.
+// FGC_K1_NT16=0: 32-node tiles everywhere.
+static int k1_nodes(const fgc_conv_desc* d) {
+    static const bool on = !(getenv("FGC_K1_NT16") && getenv("FGC_K1_NT16")[0] == '0');
+    static const bool k1m = !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1');
+    static const bool k1deep = !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+    if (!on || !k1m || !k1deep || (d->flags & FGC_CONV_BF16)) return TILE;
+    const int cin = d->c0 + d->c1;
+    const ConvGeom g1 = conv_geom(cin, d->cout);
+    const bool deep = g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= 16 && conv_vec4_ok(d) && cin % 32 == 0 &&
+                      (d->c1 == 0 || d->c0 % 32 == 0) && (size_t)d->n * 4 * 128 < 0xFFFFFFFFull;
+    return deep ? 16 : TILE;
+}
+
 struct BwdWorkspace {
     float* Wq;        // logits operand
     float* Wpt;       // data-gradient operand
@@ -1635,11 +1659,12 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     };
     w.Wq = take((size_t)g1.passes * opad * g1.kpass);
     w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
-    w.nb_db = d->n < 4096 * 32 ? cdiv(d->n, 32) : 4096;   // >= 16 workgroups per CU: the kernel is a latency-bound stream
+    const int k1n = k1_nodes(d);
+    w.nb_db = d->n < 4096 * 32 ? cdiv(d->n, k1n) : 4096;   // >= 16 workgroups per CU: the kernel is a latency-bound stream
     w.rows_per_db = cdiv(d->n, w.nb_db);
     w.nb_db = cdiv(d->n, w.rows_per_db);
     w.db_part = take((size_t)w.nb_db * d->cout);
-    w.dc_part = take((size_t)cdiv(d->n, TILE) * 12);
+    w.dc_part = take((size_t)cdiv(d->n, k1n) * 12);
     w.splitW = tn_splits(FGC_M * d->cout + 24, cin, d->n);
     if ((d->flags & FGC_CONV_BF16) && tn_bf16_ok(FGC_M * d->cout + 24, d->c0, d->c1)) {
         // the bf16 kernel's workgroups own up to 320 x 64 of the product: one or two per CU in all
@@ -1649,7 +1674,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     }
     w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
     w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
-                  reduce_tmp_floats(cdiv(d->n, TILE), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
+                  reduce_tmp_floats(cdiv(d->n, k1n), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
     w.narrow = narrow_supported(d) ? take(narrow_bwd_floats(d)) : nullptr;
     w.bytes = off;
     return w;
@@ -1665,7 +1690,7 @@ static void conv_param_jobs(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, c
     jobs[1] = RedJob{w.slab + (size_t)P * cin, sst, ns, FGC_M * cin, cin, cin, io->du};
     jobs[2] = RedJob{w.slab + (size_t)(P + 12) * cin, sst, ns, FGC_M * cin, cin, cin, io->dv};
     jobs[3] = RedJob{w.db_part, (size_t)cout, w.nb_db, cout, cout, cout, io->db};
-    jobs[4] = RedJob{w.dc_part, (size_t)12, cdiv(d->n, TILE), 12, 12, FGC_M, io->dc};
+    jobs[4] = RedJob{w.dc_part, (size_t)12, cdiv(d->n, k1_nodes(d)), 12, 12, FGC_M, io->dc};
 }
 
 }  // namespace fgc
@@ -1753,7 +1778,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                   "(cin=%d cout=%d max_deg=%d)", KMAX, cin, cout, d->max_deg);
     FGC_CHECK_ARG(!io->pool_dy || (io->pool_y && io->y && d->n % 4 == 0),
                   "fgc_conv_bwd: pool_dy needs pool_y, y and a row count that is a multiple of 4 (n=%d)", d->n);
-    const bool fuse_ds = !bf16 && (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, TILE) &&
+    const bool fuse_ds = !bf16 && (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, k1_nodes(d)) &&
                          !(d->max_deg > 16 && cout > 32) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
@@ -1859,6 +1884,23 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     } while (0)
                 const bool lng = d->max_deg > 16;
                 if (!lng) smem = smem_core_bytes(g1.zstride, 16) + (size_t)(TILE * ostride + 48) * 4;
+                if (k1_nodes(d) == 16) {      // half tiles (implies !lng)
+                    constexpr int NT = 16;
+                    const size_t smem16 = (size_t)NT * g1.zstride * 4 + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 +
+                                          (size_t)(NT * ostride + 48) * 4;
+#define FGC_DEEP_HALF(OKG_)                                                                                          \
+    do {                                                                                                             \
+        hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<false, OKG_, NT, 4>,                            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);                                \
+        FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, (conv_bwd_logits_deep_kernel<false, OKG_, NT, 4>),             \
+                   dim3(cdiv(d->n, NT)), dim3(256), smem16, p, lp);                                                  \
+    } while (0)
+                    const bool al = ((uintptr_t)io->ds % 16) == 0;
+                    if (cout == 32 && al) FGC_DEEP_HALF(2);
+                    else if (cout == 64 && al) FGC_DEEP_HALF(4);
+                    else FGC_DEEP_HALF(0);
+#undef FGC_DEEP_HALF
+                } else {
                 // 24 edge slots + the ds tile of a 64- or 128-wide layer do not fit twice into a CU's LDS
                 if (lng && cout > 32 && cout % 16 == 0 && ((uintptr_t)io->ds % 16) == 0) {
                     lp.a_global = 1;
@@ -1868,6 +1910,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                 if (cout == 32 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 2); else FGC_DEEP_LAUNCH(false, 2); }
                 else if (cout == 64 && al16) { if (lng) FGC_DEEP_LAUNCH(true, 4); else FGC_DEEP_LAUNCH(false, 4); }
                 else { if (lng) FGC_DEEP_LAUNCH(true, 0); else FGC_DEEP_LAUNCH(false, 0); }
+                }
 #undef FGC_DEEP_LAUNCH
             } else if (vec4)
                 FGC_LAUNCH("conv_bwd_logits_mfma_kernel", st, (conv_bwd_logits_mfma_kernel<true>),

@@ -102,11 +102,12 @@ static inline size_t smem_core_bytes(int zstride, int qslots = KMAX) {
 // Edges [kbase, kbase+KMAX) of every node of the tile are processed per call (one call covers
 // every node whose degree is <= KMAX = 24, i.e. every reference K-list; longer in-edge lists of
 // asymmetric graphs take several chunks).  Returns this thread's node degree.
-template <bool WITH_DL, int QS = KMAX>
+// NT nodes of the tile (s carved for NT nodes), LPN lanes per node (a power of two): NT * LPN threads
+template <bool WITH_DL, int QS = KMAX, int NT = TILE, int LPN = 8>
 __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s, int tile0, int kbase,
                                              const float* dl, float* dgsum /* [9] += sum of dl over my edges */) {
     const int tid = threadIdx.x;
-    const int node = tid >> 3, kl = tid & 7;
+    const int node = tid / LPN, kl = tid % LPN;
     const int i = tile0 + node;
     int d = 0, e0 = 0;
     float ctr[FGC_M];
@@ -126,18 +127,18 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
     }
     if (kl == 0) {
         s.deg[node] = d;
-        s.deg[TILE + 4 + node] = e0;
+        s.deg[NT + 4 + node] = e0;
     }
     const int kend = min(d, kbase + KMAX);
     // all neighbour ids first, then all their logit rows: two memory round trips for the (up to 3) edges of this
     // thread instead of two per edge
-    constexpr int EPT = QS / 8;  // edges per thread (QS < KMAX: the caller guarantees degrees <= QS)
+    constexpr int EPT = (QS + LPN - 1) / LPN;  // edges per thread (QS < KMAX: the caller guarantees degrees <= QS)
     int jj[EPT];
     f32x4 g0[EPT], g1[EPT];
     float g8[EPT];
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-        const int kk = kbase + kl + 8 * t;
+        const int kk = kbase + kl + LPN * t;
         // (unconditional, clamped into the node's list: no exec-masked load)
         const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(e0 + min(kk, max(kend - 1, 0))) * 4u, 0, 0);
         jj[t] = kk < kend ? jv : 0;
@@ -151,7 +152,7 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
     }
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-        const int kk = kbase + kl + 8 * t;
+        const int kk = kbase + kl + LPN * t;
         if (kk >= kend) continue;
         const int e = e0 + kk;
         const int k = kk - kbase;
