@@ -891,11 +891,15 @@ __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd
 //       one MFMA per node and pass; its B fragment is ONE 16-byte load per lane from the neighbour's bf16 row
 // s = dy * lrelu'(y) / deg comes from ds_db_kernel (bf16), the soft assignment and its backward stay fp32.
 // ---------------------------------------------------------------------------------------------
-template <bool LONG>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreParams p, LogitParams lp) {
+// NT_ / NPW_: nodes per workgroup / per wave, (32, 8) or - regular graphs - the half tile (16, 4) of
+// conv_bwd_logits_deep_kernel: half the per-wave state and half the LDS, more workgroups resident per CU.
+template <bool LONG, int NT_ = 32, int NPW_ = 8>
+__global__ __launch_bounds__(256, NT_ == 32 ? 2 : 4) void conv_bwd_logits_bf16_kernel(CoreParams p, LogitParams lp) {
+    static_assert((NT_ == 32 && NPW_ == 8) || (NT_ == 16 && NPW_ == 4 && !LONG), "tile shapes");
+    constexpr int TILE = NT_, NPW = NPW_, NTHREADS = 256, RT = NT_ / 16, LPN = NTHREADS / NT_;   // (shadow the 32-node constants)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int QS = LONG ? KMAX : 16;
-    const Smem s = carve(smem_raw, ZSTRIDE_BF / 2, QS);
+    const Smem s = carve(smem_raw, ZSTRIDE_BF / 2, QS, NT_);
     const int cout = lp.cout;                       // a multiple of 32
     const int obytes = cout * 2 + 32;               // LDS row stride of the s tile (== 32 mod 64)
     char* dst = reinterpret_cast<char*>(s.extra);   // s tile [TILE][obytes]
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_bwd_logits_bf16_kernel(CoreP
             *reinterpret_cast<u32x4*>(dst + r * obytes + c8 * 16) = t <= vmax ? v : u32x4{0u, 0u, 0u, 0u};
         }
     }
-    softmax_phase<false, QS>(p, s, tile0, 0, nullptr, nullptr);
+    softmax_phase<false, QS, NT_, LPN>(p, s, tile0, 0, nullptr, nullptr);
     __syncthreads();
 
     constexpr int nct = KPASS >> 4;   // 18
@@ -1624,9 +1628,10 @@ static int k1_nodes(const fgc_conv_desc* d) {
     static const bool on = !(getenv("FGC_K1_NT16") && getenv("FGC_K1_NT16")[0] == '0');
     static const bool k1m = !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1');
     static const bool k1deep = !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
-    if (!on || !k1m || !k1deep || (d->flags & FGC_CONV_BF16)) return TILE;
+    if (!on || !k1m || !k1deep) return TILE;
     const int cin = d->c0 + d->c1;
     const ConvGeom g1 = conv_geom(cin, d->cout);
+    if ((d->flags & FGC_CONV_BF16) && d->cout % 32 != 0) return TILE;
     const bool deep = g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= 16 && conv_vec4_ok(d) && cin % 32 == 0 &&
                       (d->c1 == 0 || d->c0 % 32 == 0) && (size_t)d->n * 4 * 128 < 0xFFFFFFFFull;
     return deep ? 16 : TILE;
@@ -1852,6 +1857,14 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                                     (int)smem);
                 FGC_LAUNCH("conv_bwd_logits_bf16_kernel", st, (conv_bwd_logits_bf16_kernel<true>), dim3(cdiv(d->n, TILE)),
                            dim3(NTHREADS), smem, p, lp);
+            } else if (k1_nodes(d) == 16) {
+                constexpr int NT = 16;
+                const size_t smem16 = (size_t)NT * (ZSTRIDE_BF / 2) * 4 + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 +
+                                      (size_t)NT * (cout * 2 + 32) + 48 * 4;
+                hipFuncSetAttribute((const void*)conv_bwd_logits_bf16_kernel<false, NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem16);
+                FGC_LAUNCH("conv_bwd_logits_bf16_kernel", st, (conv_bwd_logits_bf16_kernel<false, NT, 4>), dim3(cdiv(d->n, NT)),
+                           dim3(256), smem16, p, lp);
             } else {
                 hipFuncSetAttribute((const void*)conv_bwd_logits_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem);
