@@ -124,7 +124,9 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
     const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS, NT);
     constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
     constexpr bool PIPE = FAST && QS == 16;            // rows requested one phase ahead (gather_rows / fma_rows)
-    float* dagt = s.extra;  // DATA: [TILE][24]
+    // DATA: the node's da | dg rows for the epilogue live in the two spare floats of the node's first nine edge slots
+    // (qbuf[node][m][10] = da[m], [11] = dg[m]): no LDS of their own, which is what lets a fifth half-tile workgroup fit
+    auto dag_slot = [&](int nd, int m) { return s.qbuf + (size_t)nd * qnode_stride(QS) + m * QLD + 10; };
     int tile0;
     if constexpr (NT == 32) {
         tile0 = block_tile0(p);
@@ -301,14 +303,10 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                 dgsum[m] = v;
             }
             if (kl == 0) {
-                float* t = dagt + node * 24;
                 if (i < p.n) {
                     const float da[FGC_M] = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3], da8};
 #pragma unroll
-                    for (int m = 0; m < FGC_M; ++m) {
-                        t[m] = da[m];
-                        t[12 + m] = dgsum[m];
-                    }
+                    for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(dag_slot(node, m)) = f32x2{da[m], dgsum[m]};
                     float* o = de.dag + (size_t)i * FGC_AG_LD + 12;
                     *reinterpret_cast<f32x4*>(o) = f32x4{dgsum[0], dgsum[1], dgsum[2], dgsum[3]};
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
@@ -332,10 +330,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                     *reinterpret_cast<f32x4*>(rt + 16) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                     *reinterpret_cast<f32x4*>(rt + 20) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
                     }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < 24; ++m) t[m] = 0.f;
-                }
+                }   // (rows past n are skipped by the epilogue)
             }
         }
     }
@@ -564,11 +559,11 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                 any = true;
                 float g = 0.f;
                 for (int kp = 0; kp < kparts; ++kp) g += otile[((size_t)kp * TILE + row) * oldd + c];
-                const float* dg = dagt + row * 24;
 #pragma unroll
                 for (int m = 0; m < FGC_M; ++m) {
-                    g = fmaf(dg[m], uc[m], g);
-                    g = fmaf(dg[12 + m], vc[m], g);
+                    const f32x2 dd = *reinterpret_cast<const f32x2*>(dag_slot(row, m));
+                    g = fmaf(dd[0], uc[m], g);
+                    g = fmaf(dd[1], vc[m], g);
                 }
                 val += g;
             }
@@ -601,15 +596,21 @@ static bool w8_fast(const CoreParams& p) {
     return p.cg % 32 == 0 && (p.c1 == 0 || p.c0 % 32 == 0) && (size_t)p.n * 4 * 128 < 0xFFFFFFFFull;
 }
 
-// Half tiles (16 nodes, four waves per workgroup, four workgroups per CU): the forward kernel of layers up to 64 outputs
-// wide.  Measured on the 100k-facet mesh: level-0 forward 98.8 -> 85.6 us (four independently phased workgroups per CU
-// overlap their gather, aggregate and matrix phases better than two, and that outweighs reading the packed weights twice
-// as often), 64-wide level-1 forward 62.1 -> 60.5; the data-gradient kernel 126.4 -> 129.6 (its epilogue and its r / dl
-// traffic dominate), so it keeps 32-node tiles.  FGC_W8_NT16 = 0: never, 2: the data kernel too (developer switch).
+// Half tiles (16 nodes, four waves per workgroup, five workgroups per CU at 31 KB of LDS each): the forward kernel of
+// layers up to 64 outputs wide, and the data-gradient kernel of such layers on big levels.  Measured on the 100k-facet
+// mesh: level-0 forward 98.8 -> 85.6 us (independently phased small workgroups overlap their gather, aggregate and matrix
+// phases better than two big ones, and that outweighs reading the packed weights twice as often), 64-wide level-1 forward
+// 62.1 -> 60.5.  The data-gradient kernel lost at four workgroups per CU (126.4 -> 129.6: its da | dg rows cost 1.5 KB
+// of LDS, one workgroup fewer than the forward kernel); with those rows moved into spare floats of the edge table it
+// runs five as well: level 0 128.6 / 112.5 -> 121.5 / 103.4 us, but the small coarse levels (a few hundred workgroups)
+// got slower (level 2: 29.6 -> 32.3), so it switches at FGC_W8_DATA16_MIN_N nodes (default 81920 = four rounds of
+// workgroups).  FGC_W8_NT16 = 0: never, 2: the data kernel always (developer switch).
 template <bool DATA>
 static bool w8_half_tiles(const CoreParams& p) {
     static const int mode = getenv("FGC_W8_NT16") ? atoi(getenv("FGC_W8_NT16")) : 1;
-    return (DATA ? mode >= 2 : mode >= 1) && (p.npad >> 4) <= 4;
+    static const int min_n = getenv("FGC_W8_DATA16_MIN_N") ? atoi(getenv("FGC_W8_DATA16_MIN_N")) : 81920;
+    if ((p.npad >> 4) > 4 || mode < 1) return false;
+    return !DATA || mode >= 2 || p.n >= min_n;
 }
 
 template <bool DATA, bool FAST, int QS, bool BF = false>
@@ -624,7 +625,7 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
         if (w8_half_tiles<DATA>(p)) {
             constexpr int NT = 16;
             const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
-            const size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + (DATA ? (size_t)NT * 24 * 4 : 0) + 64;
+            const size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
             FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT>),
                        dim3(2 * core_grid(p)), dim3(NT * 16), smem16, p, fe, de);
             FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles)");
