@@ -83,6 +83,88 @@ __global__ __launch_bounds__(256) void ds_db_kernel(const float* __restrict__ dy
     }
 }
 
+// Vector form for 16-byte aligned tensors whose width is a multiple of 8 (bf16 input) or 4 (fp32 input) and divides
+// 256 chunks evenly: a thread owns one 16-byte chunk of dy per row (8 or 4 columns), so a row of the pooling term costs
+// seven 16-byte loads instead of seven scalar ones per column (the scalar kernel: 23 us fp32 / 35 us bf16 on the first
+// layer's 122k x 32 tensor, far above its 55 MB of traffic).  Same operations per element, so the same s bit for bit;
+// the bias-gradient partials group their rows differently (256 / chunks-per-row row lanes).
+template <bool BF_IN, bool BF_OUT>
+__global__ __launch_bounds__(256) void ds_db_vec_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const int* __restrict__ rowptr, int n, int cout, int act,
+                                                        float alpha, int bias_mask, int rows_per_block,
+                                                        float* __restrict__ ds, float* __restrict__ db_part,
+                                                        const float* __restrict__ pool_y, const float* __restrict__ pool_dy) {
+    constexpr int V = BF_IN ? 8 : 4;
+    __shared__ float part[256 * V];
+    const int cpr = cout / V, c = threadIdx.x % cpr, rl = threadIdx.x / cpr, nrl = 256 / cpr;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    auto ld = [&](const float* base, size_t chunk, float (&o)[V]) {
+        if constexpr (BF_IN) {
+            const u32x4 w = reinterpret_cast<const u32x4*>(base)[chunk];
+            const f32x4 a = bf4_to_f4(u32x2{w[0], w[1]}), b = bf4_to_f4(u32x2{w[2], w[3]});
+            o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+        } else {
+            const f32x4 a = reinterpret_cast<const f32x4*>(base)[chunk];
+            o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+        }
+    };
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int r = r0 + rl; r < r1; r += nrl) {
+        const int d = rowptr[r + 1] - rowptr[r];
+        float g[V], yv[V];
+        ld(dy, (size_t)r * cpr + c, g);
+        if (act || pool_dy) ld(y, (size_t)r * cpr + c, yv);
+        if (pool_dy) {
+            float m[V], gp[V], ne[V];
+            const size_t pi = (size_t)(r >> 2) * cpr + c;
+            ld(pool_y, pi, m);
+            ld(pool_dy, pi, gp);
+#pragma unroll
+            for (int k = 0; k < V; ++k) ne[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float yq[V];
+                ld(y, (size_t)((r & ~3) + q) * cpr + c, yq);
+#pragma unroll
+                for (int k = 0; k < V; ++k) ne[k] += yq[k] == m[k] ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] += yv[k] == m[k] ? gp[k] / ne[k] : 0.f;
+        }
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] *= slope_from_y(yv[k], alpha);
+        }
+        if (!bias_mask || d > 0) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += g[k];
+        }
+        float sv[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) sv[k] = d > 0 ? g[k] / (float)d : 0.f;
+        if constexpr (BF_OUT) {
+            static_assert(!BF_OUT || BF_IN, "bf16 output comes with bf16 input");
+            const u32x2 b0 = f4_to_bf4(f32x4{sv[0], sv[1], sv[2], sv[3]}), b1 = f4_to_bf4(f32x4{sv[4 % V], sv[5 % V], sv[6 % V], sv[7 % V]});
+            reinterpret_cast<u32x4*>(ds)[(size_t)r * cpr + c] = u32x4{b0[0], b0[1], b1[0], b1[1]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; k += 4)
+                reinterpret_cast<f32x4*>(ds)[((size_t)r * cout + c * V + k) >> 2] = f32x4{sv[k], sv[k + 1], sv[k + 2], sv[k + 3]};
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) part[(rl * cpr + c) * V + k] = acc[k];   // = part[rl][column]
+    __syncthreads();
+    if ((int)threadIdx.x < cout) {
+        float v = 0.f;
+        for (int t = 0; t < nrl; ++t) v += part[t * cout + threadIdx.x];
+        db_part[(size_t)blockIdx.x * cout + threadIdx.x] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1 operand: Wq[pass][o/4][kk][o%4] = W0[m][o][pass*kc+cl], kk = m*kc+cl  (K = cout, N = kpass)
 // ---------------------------------------------------------------------------------------------
@@ -910,12 +992,94 @@ __global__ __launch_bounds__(256, NT_ == 32 ? 2 : 4) void conv_bwd_logits_bf16_k
     {
         // rows tile0 .. tile0+31 of s are one contiguous run of 32 * cout bf16
         const int cpr = cout >> 3;                   // 16-byte chunks per row
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(lp.ds) + (size_t)tile0 * cout);
         const int vmax = min(p.n - tile0, TILE) * cpr - 1;
-        for (int t = tid; t < TILE * cpr; t += NTHREADS) {
-            const int r = t / cpr, c8 = t % cpr;
-            const u32x4 v = src[min(t, vmax)];
-            *reinterpret_cast<u32x4*>(dst + r * obytes + c8 * 16) = t <= vmax ? v : u32x4{0u, 0u, 0u, 0u};
+        if (lp.dy) {
+            // s = dy * lrelu'(y) / deg computed here instead of by ds_db_kernel (same operations in the same order on the
+            // same bf16 inputs: the same s, bit for bit): the tile goes to LDS and to ds (the data kernel gathers it), the
+            // fp32 values that count for the bias gradient to a staging tile in the (still unused) dz tile for the column sums
+            const u32x4* dy8 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(lp.dy) + (size_t)tile0 * cout);
+            const u32x4* y8 = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(lp.y) + (size_t)tile0 * cout);
+            u32x4* out8 = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(lp.ds_out) + (size_t)tile0 * cout);
+            float* gst = s.ztile;                    // [TILE][cout + 8] fp32
+            const int gs = cout + 8;
+            for (int t = tid; t < TILE * cpr; t += NTHREADS) {
+                const int tt = min(t, vmax);
+                const int r = tt / cpr, c8 = tt % cpr;
+                const int i = tile0 + r;
+                const u32x4 gy = dy8[tt];
+                u32x4 yy = u32x4{0u, 0u, 0u, 0u};
+                if (lp.act || lp.pool_dy) yy = y8[tt];
+                const int dg = p.rowptr[i + 1] - p.rowptr[i];
+                f32x4 g0 = bf4_to_f4(u32x2{gy[0], gy[1]}), g1 = bf4_to_f4(u32x2{gy[2], gy[3]});
+                const f32x4 y0 = bf4_to_f4(u32x2{yy[0], yy[1]}), y1 = bf4_to_f4(u32x2{yy[2], yy[3]});
+                if (lp.pool_dy) {
+                    // the gradient of the 4:1 max pooling of this layer's output (the four rows of a pooling group sit in
+                    // the same tile: tile0 is a multiple of 16)
+                    const size_t pi = (size_t)(i >> 2) * cpr + c8;
+                    const u32x4 mm = reinterpret_cast<const u32x4*>(lp.pool_y)[pi];
+                    const u32x4 gp = reinterpret_cast<const u32x4*>(lp.pool_dy)[pi];
+                    const f32x4 m0 = bf4_to_f4(u32x2{mm[0], mm[1]}), m1 = bf4_to_f4(u32x2{mm[2], mm[3]});
+                    const f32x4 p0 = bf4_to_f4(u32x2{gp[0], gp[1]}), p1 = bf4_to_f4(u32x2{gp[2], gp[3]});
+                    f32x4 n0 = f32x4{0.f, 0.f, 0.f, 0.f}, n1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32x4 yq = y8[min(((r & ~3) + q) * cpr + c8, vmax)];
+                        const f32x4 q0 = bf4_to_f4(u32x2{yq[0], yq[1]}), q1 = bf4_to_f4(u32x2{yq[2], yq[3]});
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            n0[c] += q0[c] == m0[c] ? 1.f : 0.f;
+                            n1[c] += q1[c] == m1[c] ? 1.f : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        g0[c] += y0[c] == m0[c] ? p0[c] / n0[c] : 0.f;
+                        g1[c] += y1[c] == m1[c] ? p1[c] / n1[c] : 0.f;
+                    }
+                }
+                if (lp.act) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        g0[c] *= slope_from_y(y0[c], lp.alpha);
+                        g1[c] *= slope_from_y(y1[c], lp.alpha);
+                    }
+                }
+                const bool ok = t <= vmax;
+                const bool counts = ok && (!lp.bias_mask || dg > 0);
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int rr = t / cpr, cc = t % cpr;
+                *reinterpret_cast<f32x4*>(gst + rr * gs + cc * 8) = counts ? g0 : z4;
+                *reinterpret_cast<f32x4*>(gst + rr * gs + cc * 8 + 4) = counts ? g1 : z4;
+                f32x4 s0, s1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = (ok && dg > 0) ? g0[c] / (float)dg : 0.f;
+                    s1[c] = (ok && dg > 0) ? g1[c] / (float)dg : 0.f;
+                }
+                const u32x2 b0 = f4_to_bf4(s0), b1 = f4_to_bf4(s1);
+                const u32x4 sv = u32x4{b0[0], b0[1], b1[0], b1[1]};
+                if (ok) out8[t] = sv;
+                *reinterpret_cast<u32x4*>(dst + rr * obytes + cc * 16) = sv;
+            }
+            __syncthreads();
+            // column sums of the staging tile with all threads: P = 256 / cout adjacent lanes share a column and add up on
+            // the DPP crossbar in a fixed order
+            const int P = NTHREADS / cout;           // 8, 4 or 2
+            const int col = tid / P, part = tid % P;
+            float acc = 0.f;
+            for (int j = part; j < TILE; j += P) acc += gst[j * gs + col];
+            acc += fgc_dpp_c<0xB1>(acc);
+            if (P >= 4) acc += fgc_dpp_c<0x4E>(acc);
+            if (P == 8) acc += fgc_dpp_c<0x141>(acc);
+            if (part == 0) lp.db_part[(size_t)(tile0 / TILE) * cout + col] = acc;
+            // (the barrier behind the softmax phase orders these reads before the first dz tile store)
+        } else {
+            const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(lp.ds) + (size_t)tile0 * cout);
+            for (int t = tid; t < TILE * cpr; t += NTHREADS) {
+                const int r = t / cpr, c8 = t % cpr;
+                const u32x4 v = src[min(t, vmax)];
+                *reinterpret_cast<u32x4*>(dst + r * obytes + c8 * 16) = t <= vmax ? v : u32x4{0u, 0u, 0u, 0u};
+            }
         }
     }
     softmax_phase<false, QS, NT_, LPN>(p, s, tile0, 0, nullptr, nullptr);
@@ -1783,8 +1947,12 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                   "(cin=%d cout=%d max_deg=%d)", KMAX, cin, cout, d->max_deg);
     FGC_CHECK_ARG(!io->pool_dy || (io->pool_y && io->y && d->n % 4 == 0),
                   "fgc_conv_bwd: pool_dy needs pool_y, y and a row count that is a multiple of 4 (n=%d)", d->n);
-    const bool fuse_ds = !bf16 && (stages & 3) == 3 && deep_ok && (cout == 32 || cout == 64) && w.nb_db == cdiv(d->n, k1_nodes(d)) &&
-                         !(d->max_deg > 16 && cout > 32) &&   // that form keeps no LDS copy of the tile (a_global)
+    // (the bf16 kernel: any width it supports - 32, 64, 128 - and both degree forms keep the LDS copy)
+    const bool fuse_ds = (stages & 3) == 3 && deep_ok && w.nb_db == cdiv(d->n, k1_nodes(d)) &&
+                         (bf16 ? (!narrow_path && (cout == 32 || cout == 64 || cout == 128) &&
+                                  !(getenv("FGC_NO_FUSED_DS_BF16") && getenv("FGC_NO_FUSED_DS_BF16")[0] == '1'))
+                               : ((cout == 32 || cout == 64) &&
+                                  !(d->max_deg > 16 && cout > 32))) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
                          (!io->pool_dy || (((uintptr_t)io->y | (uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % 16) == 0) &&
@@ -1793,9 +1961,23 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     if ((stages & 1) && !fuse_ds) {
         int cp2 = 1;
         while (cp2 < cout) cp2 <<= 1;
+        const int vw = bf16 ? 8 : 4;
+        const float* yy = io->y ? io->y : io->dy;
+        const bool vec = cout % vw == 0 && 256 % (cout / vw) == 0 && cout <= 256 &&
+                         (((uintptr_t)io->dy | (uintptr_t)yy | (uintptr_t)io->ds) % 16) == 0 &&
+                         (!io->pool_dy || (((uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % 16) == 0) &&
+                         !(getenv("FGC_NO_DS_VEC") && getenv("FGC_NO_DS_VEC")[0] == '1');
+#define FGC_DS_VEC(BI, BO)                                                                                                  \
+    FGC_LAUNCH("ds_db_kernel", st, (ds_db_vec_kernel<BI, BO>), dim3(w.nb_db), dim3(256), 0, io->dy, yy, d->rowptr, d->n, cout,   \
+               d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part, io->pool_dy ? io->pool_y : nullptr, io->pool_dy)
+        if (vec && bf16 && !narrow_path) FGC_DS_VEC(true, true);
+        else if (vec && bf16) FGC_DS_VEC(true, false);
+        else if (vec) FGC_DS_VEC(false, false);
+        else
         FGC_LAUNCH("ds_db_kernel", st, ds_db_kernel, dim3(w.nb_db), dim3(256), 0, io->dy, io->y, d->rowptr, d->n, cout, cp2,
                    d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part, bf16 ? 1 : 0,
                    (bf16 && !narrow_path) ? 1 : 0, io->pool_dy ? io->pool_y : nullptr, io->pool_dy);
+#undef FGC_DS_VEC
         FGC_CHECK_LAUNCH("fgc_conv_bwd/ds");   // db partials are summed with the other parameter gradients (stage 8)
     }
     // first layer over a narrow input (no input gradient wanted): vector-ALU path, no transposed graph, no r buffer

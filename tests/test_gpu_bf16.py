@@ -49,6 +49,31 @@ def test_bf16_train_step_within_stated_tolerance_of_the_reference(golden_dir, na
     print("bf16 vs reference fp32: normals %.2e, worst rel grad err %.2e" % (err_n, worst))
 
 
+@pytest.mark.parametrize("tag,seed", [("ico3", 0), ("torus640", 1)])
+def test_bf16_fused_ds_prologue_matches_the_separate_launch(golden_dir, tag, seed, monkeypatch):
+    """The bf16 d-logits kernel computes s = dy * lrelu'(y) / deg (and folds the pooling gradient in) in its prologue;
+    FGC_NO_FUSED_DS_BF16=1 runs ds_db_kernel instead.  Same operations on the same inputs: every tensor that does not
+    pass through the bias-gradient partial sums is identical bit for bit, the bias gradients agree to fp32 rounding."""
+    z = np.load(os.path.join(golden_dir, ("net_%s" % tag) + ".npz"))
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FGC_NO_FUSED_DS_BF16", mode)
+        net, _ = _bind(golden_dir, tag, seed, "bf16")
+        net.set_rotation(z["R"])
+        net.set_samples(z["sample_ind"])
+        net.forward_backward(rotate=True)
+        torch.cuda.synchronize()
+        grads[mode] = [g.clone() for g in net.params.grads]
+    nbias = 0
+    for i, (a, b) in enumerate(zip(grads["0"], grads["1"])):
+        if net.params.spec[i][0] == "bias":
+            nbias += 1
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-6), (i, net.params.spec[i])
+        else:
+            assert torch.equal(a, b), (i, net.params.spec[i])
+    assert nbias >= 8
+
+
 def test_bf16_irregular_mesh_matches_the_fp32_network():
     """Facet degrees up to 23: the 24-slot conv kernels and the LONG d-logits form in bf16."""
     from facet_graph_convolution_amd.net import FacetDenoiser
