@@ -1829,7 +1829,9 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.Wq = take((size_t)g1.passes * opad * g1.kpass);
     w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
     const int k1n = k1_nodes(d);
-    w.nb_db = d->n < 4096 * 32 ? cdiv(d->n, k1n) : 4096;   // >= 16 workgroups per CU: the kernel is a latency-bound stream
+    // one bias-gradient partial per d-logits tile at every size: the fused prologue of the d-logits kernel (which needs
+    // exactly that) then also serves meshes beyond 131k nodes (it used to stop there: 4096 partials, ds_db launches)
+    w.nb_db = cdiv(d->n, k1n);
     w.rows_per_db = cdiv(d->n, w.nb_db);
     w.nb_db = cdiv(d->n, w.rows_per_db);
     w.db_part = take((size_t)w.nb_db * d->cout);
