@@ -48,7 +48,7 @@ def main():
         lines.append("  (upconv1 forward, same grid: avg %.2f us over %d)" % (avg(u1), len(u1)))
         lines.append("  hipEvents, no profiler, default arguments (profiles/%s_bench.json)        avg %.2f us"
                      % (tag, dflt["roofline"]["avg_kernel_us"]))
-    kern = {k["name"]: k for k in prof.get("kernels", [])}
+    kern = prof.get("kernels", {})
     other = []
     for sub, label, key in (("mlp_bwd_kernel", "mlp_bwd_kernel", "bwd:mlp/mlp_bwd_kernel"),
                             ("mlp_fwd_split_kernel", "mlp_fwd_split_kernel", "fwd:mlp/mlp_fwd_kernel")):
