@@ -3,8 +3,11 @@
 //
 // x (and dx in backward) are bf16 tensors; W1, b1, W2, b2 and every gradient of them stay fp32 (master weights).  The
 // matrix products with the 1024-wide hidden layer run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; bias, leaky
-// ReLU, the 1024 -> 3 layer and every sum over nodes stay fp32 on the vector ALU / in the accumulators.  The hidden
-// activation is never stored (recomputed in backward), exactly as in the fp32 kernels.
+// ReLU, the forward 1024 -> 3 layer and every sum over nodes stay fp32 on the vector ALU / in the accumulators.  In the
+// backward pass the two K = 3 / N = 3 products of that layer ride on the matrix pipe too (g = dy W2^T with hi + lo
+// operand pairs, dW2 = hact^T dy with hact rounded to bf16 and dy as a hi + lo pair): they were a third of the vector
+// work of kernels that the vector ALU bounds.  The hidden activation is never stored (recomputed in backward), exactly
+// as in the fp32 kernels.
 //
 // Fragment layouts of v_mfma_f32_16x16x32_bf16 (MI355X guide): lane l = (lr = l & 15, lq = l >> 4) holds
 //   A[row lr][k = 8*lq + j],  B[k = 8*lq + j][col lr],  j = 0..7  (16 bytes each);  C/D: col = lr, row = 4*lq + reg.
@@ -37,6 +40,39 @@ __global__ void mlp_pack_bf16_kernel(const float* __restrict__ W1, unsigned shor
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t count4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x)
         reinterpret_cast<u32x2*>(dst)[i] = f4_to_bf4(reinterpret_cast<const f32x4*>(src)[i]);
+}
+
+// The 1024 -> 3 layer of the backward pass on the matrix pipe.  g[row][col] = sum_o dy[row][o] W2[col][o] has K = 3: on the
+// vector ALU it cost three FMAs per hidden element, a third of the kernel's vector work.  One bf16 MFMA has 32 k slots:
+// slots 0-2 carry dy_hi x W2_hi, 3-5 dy_lo x W2_hi, 8-10 dy_hi x W2_lo (v_hi = bf16(v), v_lo = bf16(v - v_hi): 16
+// significand bits per operand; g is rounded to bf16 right afterwards for the products that consume it).
+//   A (per 16 rows):  lane (lr = row, lq):  lq 0: {hi0 hi1 hi2 lo0 lo1 lo2 0 0}   lq 1: {hi0 hi1 hi2 0 ...}   else 0
+//   B (per 16 hidden columns, packed once per launch): lq 0: {Whi0-2 Whi0-2 0 0}   lq 1: {Wlo0-2 0 ...}   else 0
+__global__ void mlp_pack_w2_bf16_kernel(const float* __restrict__ W2, u32x4* __restrict__ W2p, int hidden, int cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (hidden >> 4) * 64) return;
+    const int lane = idx & 63, ct = idx >> 6, lr = lane & 15, lq = lane >> 4;
+    unsigned short hi[3], lo[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float w = o < cout ? W2[(size_t)(ct * 16 + lr) * cout + o] : 0.f;
+        hi[o] = f_to_bf(w);
+        lo[o] = f_to_bf(w - bf_to_f(hi[o]));
+    }
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (lq == 0) v = u32x4{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[0] << 16), hi[1] | ((unsigned)hi[2] << 16), 0u};
+    if (lq == 1) v = u32x4{lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2], 0u, 0u};
+    W2p[idx] = v;
+}
+// A fragment of that product from a lane's dy row (o = 0..2)
+__device__ __forceinline__ u32x4 mb_dy_frag(float d0, float d1, float d2, int lq) {
+    const unsigned h01 = f2_to_bf2(d0, d1), h2x = f2_to_bf2(d2, 0.f);
+    const f32x2c f01 = bf2_to_f2(h01), f2x = bf2_to_f2(h2x);
+    const unsigned l01 = f2_to_bf2(d0 - f01[0], d1 - f01[1]), l2x = f2_to_bf2(d2 - f2x[0], 0.f);
+    // lq 0: {hi0 hi1 | hi2 lo0 | lo1 lo2 | 0}    lq 1: {hi0 hi1 | hi2 0 | 0 | 0}
+    const unsigned w1 = lq == 0 ? ((h2x & 0xFFFFu) | (l01 << 16)) : (h2x & 0xFFFFu);
+    const unsigned w2 = lq == 0 ? ((l01 >> 16) | (l2x << 16)) : 0u;
+    return lq < 2 ? u32x4{h01, w1, w2, 0u} : u32x4{0u, 0u, 0u, 0u};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -372,27 +408,35 @@ template <int MT>
 __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
     const u32x4* __restrict__ Wp16, const unsigned short* __restrict__ W1h /* [cin][hidden] bf16 */,
-    const float* __restrict__ b1, const float* __restrict__ W2, float alpha, unsigned short* __restrict__ dx) {
+    const float* __restrict__ b1, const u32x4* __restrict__ W2p /* mlp_pack_w2_bf16_kernel */, float alpha,
+    unsigned short* __restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int CIN = MT * 16;
     constexpr int KS = CIN / 32;
     constexpr int DHS = 32 * 2 + 32;          // bytes per row (= node) of a wave's dh tile
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    char* dhw = smem_raw + wave * (MB_T * DHS + MB_T * 16);
-    float* dyw = reinterpret_cast<float*>(dhw + MB_T * DHS);
+    char* dhw = smem_raw + wave * (MB_T * DHS);
     unsigned short* d16 = reinterpret_cast<unsigned short*>(dhw);
     const int nct = hidden >> 4;
     const int tile = blockIdx.x * MBB_WAVES + wave;
     const int row0 = tile * MB_T;
     if (row0 >= n) return;                    // (whole wave; nothing below is shared between waves)
-    u32x4 ax[MB_RT * KS];
-    mb_load_rows(x, dy, n, cout, row0, CIN, lane, ax, KS, dyw);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    f32x4 dyr[MB_RT][4];
+    u32x4 ax[MB_RT * KS], gA[MB_RT];
 #pragma unroll
-    for (int r = 0; r < MB_RT; ++r)
+    for (int r = 0; r < MB_RT; ++r) {
+        const int row = row0 + r * 16 + lr;
+        const size_t rc = (size_t)min(row, n - 1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dyr[r][t] = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lq * 4 + t) * 4);
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + rc * CIN + ks * 32 + 8 * lq);
+            ax[r * KS + ks] = row < n ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+        // this lane's dy row as the A fragment of g = dy W2^T (rows past n: zero, so their dh is zero)
+        float d[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) d[o] = (row < n && o < cout) ? dy[rc * cout + min(o, cout - 1)] : 0.f;
+        gA[r] = mb_dy_frag(d[0], d[1], d[2], lq);
+    }
     f32x4 dxacc[MB_RT][MT];
 #pragma unroll
     for (int r = 0; r < MB_RT; ++r)
@@ -404,7 +448,7 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
     struct PairW {
         u32x4 bw[2][KS];
         float bb[2];
-        float w2[2][3];
+        u32x4 bg[2];
         u32x4 bt[MT];
     };
     auto fetch = [&](int pp, PairW& w) {
@@ -415,8 +459,7 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) w.bw[c2][ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
             w.bb[c2] = b1[ct * 16 + lr];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) w.w2[c2][o] = W2[(size_t)(ct * 16 + lr) * cout + min(o, cout - 1)];
+            w.bg[c2] = W2p[ct * 64 + lane];
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -434,17 +477,16 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
                 for (int r = 0; r < MB_RT; ++r)
                     h[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[r * KS + ks]),
                                                                   __builtin_bit_cast(bf16x8, w.bw[c2][ks]), h[r], 0, 0, 0);
+            f32x4 g[MB_RT];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+                g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gA[r]), __builtin_bit_cast(bf16x8, w.bg[c2]),
+                                                              f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float pre = h[r][t];
-                    const float slope = lrelu01_slope(pre, alpha);
-                    float g = dyr[r][t][0] * w.w2[c2][0];
-                    if (cout > 1) g = fmaf(dyr[r][t][1], w.w2[c2][1], g);
-                    if (cout > 2) g = fmaf(dyr[r][t][2], w.w2[c2][2], g);
-                    d16[((r * 16 + lq * 4 + t) * DHS) / 2 + c2 * 16 + lr] = f_to_bf(g * slope);
-                }
+                for (int t = 0; t < 4; ++t)
+                    d16[((r * 16 + lq * 4 + t) * DHS) / 2 + c2 * 16 + lr] = f_to_bf(g[r][t] * lrelu01_slope(h[r][t], alpha));
         }
         // same wave wrote and reads: LDS ops of one wave are ordered; the compiler inserts the lgkmcnt wait
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
 template <int MT, int CO>
 __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
-    const u32x4* __restrict__ Wp16, const float* __restrict__ b1, const float* __restrict__ W2, float alpha,
+    const u32x4* __restrict__ Wp16, const float* __restrict__ b1, const u32x4* __restrict__ W2p, float alpha,
     float* __restrict__ dW1_slab /* [walkers][cin][hidden] */, float* __restrict__ db1_slab /* [walkers][hidden] */,
     float* __restrict__ dW2_slab /* [walkers][hidden][4] */, float* __restrict__ db2_slab /* [walkers][4] */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -502,29 +544,27 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
     const int ntiles = (n + MB_T - 1) / MB_T;
     const int walker = blockIdx.x * MBB_WAVES + wave, nwalkers = gridDim.x * MBB_WAVES;
 
-    u32x4 bw[MBW_CT][KS];
-    float bb[MBW_CT], w2[MBW_CT][CO];
+    u32x4 bw[MBW_CT][KS], bg[MBW_CT];
+    float bb[MBW_CT];
 #pragma unroll
     for (int c = 0; c < MBW_CT; ++c) {
         const int ct = (hc0 >> 4) + c;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bw[c][ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
         bb[c] = b1[ct * 16 + lr];
-#pragma unroll
-        for (int o = 0; o < CO; ++o) w2[c][o] = o < cout ? W2[(size_t)(ct * 16 + lr) * cout + o] : 0.f;
+        bg[c] = W2p[ct * 64 + lane];
     }
-    f32x4 dW1acc[MBW_CT][MT];
-    float dW2acc[MBW_CT][CO], db1acc[MBW_CT], db2acc[CO];
+    // dW1acc: C layout of x^T dh (column = hidden column lr, row = input channel 4*lq + t of tile m)
+    // dW2acc: C layout of hact^T dy (column = output o = lr, row = hidden column 4*lq + t of tile c): lanes lr < cout count
+    f32x4 dW1acc[MBW_CT][MT], dW2acc[MBW_CT];
+    float db1acc[MBW_CT], db2acc = 0.f;
 #pragma unroll
     for (int c = 0; c < MBW_CT; ++c) {
         db1acc[c] = 0.f;
-#pragma unroll
-        for (int o = 0; o < CO; ++o) dW2acc[c][o] = 0.f;
+        dW2acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int o = 0; o < CO; ++o) db2acc[o] = 0.f;
 
 #pragma unroll 1
     for (int tile = walker; tile < ntiles; tile += nwalkers) {
@@ -543,18 +583,33 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
                     xT16[((c + 1) * XTS) / 2 + r * 16 + lr] = (unsigned short)(ax[r * KS + ks][e] >> 16);
                 }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        f32x4 dyr[MB_RT][4];
+        // dy of the tile in the two operand layouts it is needed in:
+        //   gA[r]    A of g = dy W2^T: this lane's row r*16 + lr (mb_dy_frag)
+        //   dyh/dyl  B of dW2 += hact^T dy: lane (o = lr, lq), k slot j <-> row (j >> 2) * 16 + 4*lq + (j & 3) - the row
+        //            order in which a lane holds its hidden column in the C layout - as bf16 hi and lo parts
+        u32x4 gA[MB_RT], dyh, dyl;
 #pragma unroll
-        for (int r = 0; r < MB_RT; ++r)
+        for (int r = 0; r < MB_RT; ++r) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lr) * 4);
+            gA[r] = mb_dy_frag(d[0], d[1], d[2], lq);
+        }
+        {
+            float v[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dyr[r][t] = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lq * 4 + t) * 4);
-        if (blockIdx.y == 0 && lr == 0) {     // db2 = column sums of dy (hidden slice 0 only): one lane per row
+            for (int j = 0; j < 8; ++j) {
+                const float d = dyw[((j >> 2) * 16 + 4 * lq + (j & 3)) * 4 + (lr & 3)];
+                v[j] = lr < CO ? d : 0.f;
+            }
+            if (blockIdx.y == 0) db2acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            unsigned hh[4], ll[4];
 #pragma unroll
-            for (int r = 0; r < MB_RT; ++r)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int o = 0; o < CO; ++o) db2acc[o] += dyr[r][t][o];
+            for (int q = 0; q < 4; ++q) {
+                hh[q] = f2_to_bf2(v[2 * q], v[2 * q + 1]);
+                const f32x2c f = bf2_to_f2(hh[q]);
+                ll[q] = f2_to_bf2(v[2 * q] - f[0], v[2 * q + 1] - f[1]);
+            }
+            dyh = u32x4{hh[0], hh[1], hh[2], hh[3]};
+            dyl = u32x4{ll[0], ll[1], ll[2], ll[3]};
         }
         u32x4 af[MT];
 #pragma unroll
@@ -567,7 +622,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
 #pragma unroll
         for (int c = 0; c < MBW_CT; ++c) {
             __builtin_amdgcn_sched_barrier(0);    // one column tile at a time
-            f32x4 h[MB_RT], dh[MB_RT];
+            f32x4 h[MB_RT], g[MB_RT];
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{bb[c], bb[c], bb[c], bb[c]};
 #pragma unroll
@@ -578,42 +633,42 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
                                                                   __builtin_bit_cast(bf16x8, bw[c][ks]), h[r], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
+                g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gA[r]), __builtin_bit_cast(bf16x8, bg[c]),
+                                                              f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            // lrelu(pre) = pre * lrelu'(pre): one multiply instead of a multiply and a max
+            f32x4 ha[MB_RT];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float pre = h[r][t];
-                    const float hact = lrelu01(pre, alpha);
-                    const float slope = lrelu01_slope(pre, alpha);
-                    float g = 0.f;
-#pragma unroll
-                    for (int o = 0; o < CO; ++o) {
-                        g = fmaf(dyr[r][t][o], w2[c][o], g);
-                        dW2acc[c][o] = fmaf(hact, dyr[r][t][o], dW2acc[c][o]);
-                    }
-                    g *= slope;
-                    dh[r][t] = g;
-                    db1acc[c] += g;
+                    const float slope = lrelu01_slope(h[r][t], alpha);
+                    ha[r][t] = h[r][t] * slope;
+                    g[r][t] *= slope;
+                    db1acc[c] += g[r][t];
                 }
-            // k = r*16 + 4*lq + t: element j of both fragments is (r = j >> 2, t = j & 3)
-            const u32x4 bf = u32x4{f2_to_bf2(dh[0][0], dh[0][1]), f2_to_bf2(dh[0][2], dh[0][3]), f2_to_bf2(dh[1][0], dh[1][1]),
-                                   f2_to_bf2(dh[1][2], dh[1][3])};
+            // k = r*16 + 4*lq + t: element j of the fragments is (r = j >> 2, t = j & 3)
+            const u32x4 bf = u32x4{f2_to_bf2(g[0][0], g[0][1]), f2_to_bf2(g[0][2], g[0][3]), f2_to_bf2(g[1][0], g[1][1]),
+                                   f2_to_bf2(g[1][2], g[1][3])};
+            const u32x4 hf = u32x4{f2_to_bf2(ha[0][0], ha[0][1]), f2_to_bf2(ha[0][2], ha[0][3]), f2_to_bf2(ha[1][0], ha[1][1]),
+                                   f2_to_bf2(ha[1][2], ha[1][3])};
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 dW1acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[m]), __builtin_bit_cast(bf16x8, bf),
                                                                       dW1acc[c][m], 0, 0, 0);
+            // dW2 += hact^T dy (smaller term first)
+            dW2acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hf), __builtin_bit_cast(bf16x8, dyl),
+                                                               dW2acc[c], 0, 0, 0);
+            dW2acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hf), __builtin_bit_cast(bf16x8, dyh),
+                                                               dW2acc[c], 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile overwrites the LDS tiles
     }
     // parameter-gradient slabs of this wave (slab index = its walker id)
-    if (blockIdx.y == 0) {
-#pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            float v = db2acc[o];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (lane == 0) db2_slab[walker * 4 + o] = v;
-        }
-        if (lane == 0)
-            for (int o = CO; o < 4; ++o) db2_slab[walker * 4 + o] = 0.f;
+    if (blockIdx.y == 0) {   // db2[o]: lanes (lr = o, lq) hold the sums of their rows
+        float v = db2acc;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0 && lr < 4) db2_slab[walker * 4 + lr] = lr < CO ? v : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < MBW_CT; ++c) {
@@ -628,15 +683,12 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         if (lq == 0) db1_slab[(size_t)walker * hidden + col] = v;
+        // dW2acc C layout: column = lr (output o), row = 4*lq + t (hidden column within tile c)
+        if (lr < 4) {
 #pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            float w = dW2acc[c][o];
-            w += __shfl_xor(w, 16);
-            w += __shfl_xor(w, 32);
-            if (lq == 0) dW2_slab[((size_t)walker * hidden + col) * 4 + o] = w;
+            for (int t = 0; t < 4; ++t)
+                dW2_slab[((size_t)walker * hidden + hc0 + c * 16 + lq * 4 + t) * 4 + lr] = lr < CO ? dW2acc[c][t] : 0.f;
         }
-        if (lq == 0)
-            for (int o = CO; o < 4; ++o) dW2_slab[((size_t)walker * hidden + col) * 4 + o] = 0.f;
     }
 }
 
@@ -697,6 +749,7 @@ extern "C" size_t fgc_mlp_bwd_bf16_workspace_bytes(int32_t n, int32_t cin, int32
     b += align_up(gx * (size_t)hidden * 4, 256);               // db1 slabs
     b += align_up(gx * (size_t)hidden * 4 * 4, 256);           // dW2 slabs
     b += align_up((size_t)1024 * 4 * 4, 256);                  // db2 partials
+    b += align_up((size_t)(hidden >> 4) * 64 * 16, 256);       // W2 as fragments of the g product
     b += align_up((reduce_tmp_floats(1024, 4) + reduce_tmp_floats((int)gx, (size_t)cin * hidden) +
                    reduce_tmp_floats((int)gx, (size_t)hidden * 5)) * 4 + 256, 256);
     return b;
@@ -774,8 +827,11 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
     w += align_up((size_t)gx * hidden * 4 * 4, 256);
     float* db2_part = (float*)w;
     w += align_up((size_t)1024 * 4 * 4, 256);
+    u32x4* W2p = (u32x4*)w;
+    w += align_up((size_t)(hidden >> 4) * 64 * 16, 256);
     float* rtmp = (float*)w;
 
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_w2_bf16_kernel, dim3(cdiv((hidden >> 4) * 64, 256)), dim3(256), 0, W2, W2p, hidden, cout);
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
     FGC_LAUNCH("mlp_pack_kernel", st, cast_f32_bf16_kernel, dim3(cdiv(cin * hidden / 4, 256)), dim3(256), 0, W1, W1h,
                (int64_t)cin * hidden / 4);
@@ -785,12 +841,12 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
 #define FGC_MB_BWD(MT)                                                                                                      \
     do {                                                                                                                    \
         constexpr int CIN_ = MT * 16;                                                                                       \
-        const size_t smem_dx = (size_t)MBB_WAVES * (MB_T * 96 + MB_T * 16);                                                 \
+        const size_t smem_dx = (size_t)MBB_WAVES * (MB_T * 96);                                                             \
         FGC_LAUNCH("mlp_bwd_kernel<dx>", st, (mlp_bwd_dx_bf16_kernel<MT>), dim3(cdiv(tiles, MBB_WAVES)), dim3(MBB_THREADS),  \
-                   smem_dx, x16, dy, n, hidden, cout, Wp16, W1h, b1, W2, alpha, (unsigned short*)dx);                       \
+                   smem_dx, x16, dy, n, hidden, cout, Wp16, W1h, b1, W2p, alpha, (unsigned short*)dx);                      \
         const size_t smem_w = (size_t)MBB_WAVES * ((size_t)CIN_ * (MB_T * 2 + 8) + MB_T * 16);                              \
         FGC_LAUNCH("mlp_bwd_kernel<w>", st, (mlp_bwd_w_bf16_kernel<MT, 3>), dim3(gx / 4, gy), dim3(MBB_THREADS), smem_w, x16, \
-                   dy, n, hidden, cout, Wp16, b1, W2, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);                       \
+                   dy, n, hidden, cout, Wp16, b1, W2p, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);                      \
     } while (0)
     if (cin == 32) FGC_MB_BWD(2);
     else FGC_MB_BWD(4);

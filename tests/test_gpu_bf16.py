@@ -105,8 +105,9 @@ def test_bf16_irregular_mesh_matches_the_fp32_network():
 
 def test_bf16_mlp_kernels_against_torch(golden_dir):
     """fgc_mlp_fwd_bf16 / fgc_mlp_bwd_bf16 through the C ABI against a float64 torch MLP fed the SAME bf16-rounded x
-    and weights: what is left is the fp32 accumulation order and the bf16 rounding of dh inside the two
-    K = nodes / K = hidden products."""
+    and weights: what is left is the fp32 accumulation order and the bf16 rounding of dh (dx, dW1, db1) and of the hidden
+    activation (dW2: the K = nodes product hact^T dy runs on the bf16 matrix pipe, dy as a hi + lo pair; 1.6e-3 at 1000
+    rows, the rounding errors are unbiased and average out over the rows)."""
     import ctypes as C
     from facet_graph_convolution_amd import _lib
     L = _lib.lib()
@@ -139,7 +140,7 @@ def test_bf16_mlp_kernels_against_torch(golden_dir):
         Y.backward(dy.double())
         assert (y.cpu().double() - Y.detach()).abs().max().item() < 1e-5
         for got, ref, tol in ((dx.float(), X.grad, 1.5e-2), (dW1, P[0].grad, 1.5e-2), (db1, P[1].grad, 1.5e-2),
-                              (dW2, P[2].grad, 1e-4), (db2, P[3].grad, 1e-5)):
+                              (dW2, P[2].grad, 4e-3), (db2, P[3].grad, 1e-5)):
             err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
             assert err < tol, (n, cin, tuple(ref.shape), err)
 
