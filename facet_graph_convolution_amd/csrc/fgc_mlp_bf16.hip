@@ -50,8 +50,8 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned sho
 //   B (per 16 hidden columns, packed once per launch): lq 0: {Whi0-2 Whi0-2 0 0}   lq 1: {Wlo0-2 0 ...}   else 0
 __global__ void mlp_pack_w2_bf16_kernel(const float* __restrict__ W2, u32x4* __restrict__ W2p, int hidden, int cout) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (hidden >> 4) * 64) return;
-    const int lane = idx & 63, ct = idx >> 6, lr = lane & 15, lq = lane >> 4;
+    if (idx >= (hidden >> 4) * 32) return;       // lanes 0..31 of a fragment (lq 0 and 1); lanes 32..63 are zero, not stored
+    const int lane = idx & 31, ct = idx >> 5, lr = lane & 15, lq = lane >> 4;
     unsigned short hi[3], lo[3];
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
@@ -59,10 +59,25 @@ __global__ void mlp_pack_w2_bf16_kernel(const float* __restrict__ W2, u32x4* __r
         hi[o] = f_to_bf(w);
         lo[o] = f_to_bf(w - bf_to_f(hi[o]));
     }
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (lq == 0) v = u32x4{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[0] << 16), hi[1] | ((unsigned)hi[2] << 16), 0u};
-    if (lq == 1) v = u32x4{lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2], 0u, 0u};
-    W2p[idx] = v;
+    W2p[idx] = lq == 0 ? u32x4{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[0] << 16), hi[1] | ((unsigned)hi[2] << 16), 0u}
+                       : u32x4{lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2], 0u, 0u};
+}
+__device__ __forceinline__ u32x4 mb_w2_frag(const u32x4* __restrict__ W2p, int ct, int lane) {
+    const u32x4 v = W2p[ct * 32 + (lane & 31)];
+    return lane < 32 ? v : u32x4{0u, 0u, 0u, 0u};
+}
+// W1 [cin, hidden] fp32 -> B fragments of dx += dh W1^T in the k order of the dx kernel's transposed dh (pair pp of column
+// tiles, input-channel tile m, lane (lr = channel, lq)): element j = c2*4 + t is W1[m*16 + lr][pp*32 + c2*16 + 4*lq + t]
+__global__ void mlp_pack_w1dx_bf16_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wd, int cin, int hidden) {
+    const size_t total = (size_t)cin * hidden;
+    const int mt = cin >> 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int m = rest % mt, pp = (int)(rest / mt);
+        const int ch = m * 16 + (lane & 15), col = pp * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
+        Wd[idx] = f_to_bf(W1[(size_t)ch * hidden + col]);
+    }
 }
 // A fragment of that product from a lane's dy row (o = 0..2)
 __device__ __forceinline__ u32x4 mb_dy_frag(float d0, float d1, float d2, int lq) {
@@ -366,8 +381,9 @@ __global__ __launch_bounds__(MB_THREADS, 2) void mlp_fwd_split_kernel(const floa
 // the hidden layer nearly free (a fused kernel with the fp32 kernel's structure kept ~200 registers of partial sums
 // alive and spilled; giving the waves of a workgroup the same rows cost three barriers per 32-row tile):
 //   mlp_bwd_dx_bf16_kernel   row major: a wave owns 32 rows and walks ALL hidden columns, 32 at a time:
-//        h = x W1 + b1 (MFMA), dh = (dy W2^T) * lrelu'(h) (vector ALU, fp32), dx += dh W1^T (MFMA; dh through a
-//        wave-private bf16 LDS tile into the A layout).  dx leaves as bf16, complete: no partial slabs.
+//        h^T = W1^T x^T + b1 and g^T = W2 dy^T (MFMA, operands swapped), dh = g * lrelu'(h) (vector ALU, fp32),
+//        dx += dh W1^T (MFMA; the transposed C layout of dh IS the A layout, no LDS).  dx leaves as bf16, complete: no
+//        partial slabs.
 //   mlp_bwd_w_bf16_kernel    column major: a wave owns 64 hidden columns (blockIdx.y) and walks its share of the
 //        32-row tiles with dW1 / db1 / dW2 partial sums in registers:
 //        dW1 += x^T dh: K = the 32 rows of the tile, ONE MFMA per (16 input channels, 16 hidden columns); B = dh
@@ -407,16 +423,12 @@ __device__ __forceinline__ void mb_load_rows(const unsigned short* __restrict__ 
 template <int MT>
 __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
-    const u32x4* __restrict__ Wp16, const unsigned short* __restrict__ W1h /* [cin][hidden] bf16 */,
+    const u32x4* __restrict__ Wp16, const u32x4* __restrict__ W1d /* mlp_pack_w1dx_bf16_kernel */,
     const float* __restrict__ b1, const u32x4* __restrict__ W2p /* mlp_pack_w2_bf16_kernel */, float alpha,
     unsigned short* __restrict__ dx) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int CIN = MT * 16;
     constexpr int KS = CIN / 32;
-    constexpr int DHS = 32 * 2 + 32;          // bytes per row (= node) of a wave's dh tile
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    char* dhw = smem_raw + wave * (MB_T * DHS);
-    unsigned short* d16 = reinterpret_cast<unsigned short*>(dhw);
     const int nct = hidden >> 4;
     const int tile = blockIdx.x * MBB_WAVES + wave;
     const int row0 = tile * MB_T;
@@ -443,11 +455,15 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
 #pragma unroll
         for (int m = 0; m < MT; ++m) dxacc[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weights of one pair of column tiles (W1 fragments, b1, W2 rows, W1 rows for the dx product): clamped, so that the
-    // pair after the last is a valid (unused) load; fetched one pair ahead
+    // weights of one pair of column tiles (W1 fragments, b1, W2 fragments, W1 rows for the dx product): clamped, so that the
+    // pair after the last is a valid (unused) load; fetched one pair ahead.
+    // The two products that make dh are computed TRANSPOSED (operands swapped: h^T = W1^T x^T, g^T = W2 dy^T): in the C
+    // layout a lane then holds ONE row (its lr) and the hidden columns 4*lq + t of a tile - with the two tiles of a pair,
+    // eight k values of the A operand of dx += dh W1^T, straight out of the registers.  k slot j = c2*4 + t of lane group
+    // lq stands for hidden column c2*16 + 4*lq + t; the W1 rows (B operand) are loaded in that same order.  No LDS.
     struct PairW {
         u32x4 bw[2][KS];
-        float bb[2];
+        f32x4 bb[2];
         u32x4 bg[2];
         u32x4 bt[MT];
     };
@@ -458,59 +474,62 @@ __global__ __launch_bounds__(MBB_THREADS, MT <= 2 ? 3 : 2) void mlp_bwd_dx_bf16_
             const int ct = pp * 2 + c2;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) w.bw[c2][ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
-            w.bb[c2] = b1[ct * 16 + lr];
-            w.bg[c2] = W2p[ct * 64 + lane];
+            w.bb[c2] = *reinterpret_cast<const f32x4*>(b1 + ct * 16 + 4 * lq);
+            w.bg[c2] = mb_w2_frag(W2p, ct, lane);
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            w.bt[m] = *reinterpret_cast<const u32x4*>(W1h + (size_t)(m * 16 + lr) * hidden + pp * 32 + 8 * lq);
+        for (int m = 0; m < MT; ++m) w.bt[m] = W1d[((size_t)pp * MT + m) * 64 + lane];
     };
     auto pair = [&](const PairW& w) {
+        f32x4 d[2][MB_RT];
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
-            f32x4 h[MB_RT];
+            f32x4 h[MB_RT], g[MB_RT];
 #pragma unroll
-            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{w.bb[c2], w.bb[c2], w.bb[c2], w.bb[c2]};
+            for (int r = 0; r < MB_RT; ++r) h[r] = w.bb[c2];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int r = 0; r < MB_RT; ++r)
-                    h[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[r * KS + ks]),
-                                                                  __builtin_bit_cast(bf16x8, w.bw[c2][ks]), h[r], 0, 0, 0);
-            f32x4 g[MB_RT];
+                    h[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w.bw[c2][ks]),
+                                                                  __builtin_bit_cast(bf16x8, ax[r * KS + ks]), h[r], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
-                g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gA[r]), __builtin_bit_cast(bf16x8, w.bg[c2]),
+                g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w.bg[c2]), __builtin_bit_cast(bf16x8, gA[r]),
                                                               f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    d16[((r * 16 + lq * 4 + t) * DHS) / 2 + c2 * 16 + lr] = f_to_bf(g[r][t] * lrelu01_slope(h[r][t], alpha));
+                for (int t = 0; t < 4; ++t) d[c2][r][t] = g[r][t] * lrelu01_slope(h[r][t], alpha);
         }
-        // same wave wrote and reads: LDS ops of one wave are ordered; the compiler inserts the lgkmcnt wait
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        u32x4 ad[MB_RT];
 #pragma unroll
-        for (int r = 0; r < MB_RT; ++r) ad[r] = *reinterpret_cast<const u32x4*>(dhw + (r * 16 + lr) * DHS + lq * 16);
+        for (int r = 0; r < MB_RT; ++r) {
+            const u32x4 ad = u32x4{f2_to_bf2(d[0][r][0], d[0][r][1]), f2_to_bf2(d[0][r][2], d[0][r][3]),
+                                   f2_to_bf2(d[1][r][0], d[1][r][1]), f2_to_bf2(d[1][r][2], d[1][r][3])};
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < MB_RT; ++r)
-                dxacc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ad[r]),
-                                                                     __builtin_bit_cast(bf16x8, w.bt[m]), dxacc[r][m], 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next pair overwrites the dh tile
+            for (int m = 0; m < MT; ++m)
+                dxacc[r][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ad), __builtin_bit_cast(bf16x8, w.bt[m]),
+                                                                     dxacc[r][m], 0, 0, 0);
+        }
     };
     // cout > 3 (a fourth output column) is folded in by a second sweep below: the network's heads have three
     PairW wa, wb;
     const int npairs = nct >> 1;
     fetch(0, wa);
+    // sched_barrier: keep the program order "request the next pair, then work on this one" (left alone the scheduler sinks
+    // every request to the end of the iteration and waits for all of them at the top of the next: no load ever overlaps
+    // a product)
 #pragma unroll 1
     for (int pp = 0; pp < npairs; pp += 2) {
         fetch(pp + 1, wb);
+        __builtin_amdgcn_sched_barrier(0);
         pair(wa);
+        __builtin_amdgcn_sched_barrier(0);
         fetch(pp + 2, wa);
-        if (pp + 1 < npairs) pair(wb);
+        __builtin_amdgcn_sched_barrier(0);
+        pair(wb);                 // (hidden % 256 == 0: the pair count is even; a conditional here lets the compiler sink
+                                  //  the loads of wb into the branch, next to their use)
+        __builtin_amdgcn_sched_barrier(0);
     }
     // C layout: column = input channel lr of tile m, rows 4*lq + t
 #pragma unroll
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bw[c][ks] = Wp16[((size_t)ks * nct + ct) * 64 + lane];
         bb[c] = b1[ct * 16 + lr];
-        bg[c] = W2p[ct * 64 + lane];
+        bg[c] = mb_w2_frag(W2p, ct, lane);
     }
     // dW1acc: C layout of x^T dh (column = hidden column lr, row = input channel 4*lq + t of tile m)
     // dW2acc: C layout of hact^T dy (column = output o = lr, row = hidden column 4*lq + t of tile c): lanes lr < cout count
@@ -831,19 +850,17 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
     w += align_up((size_t)(hidden >> 4) * 64 * 16, 256);
     float* rtmp = (float*)w;
 
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_w2_bf16_kernel, dim3(cdiv((hidden >> 4) * 64, 256)), dim3(256), 0, W2, W2p, hidden, cout);
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_w2_bf16_kernel, dim3(cdiv((hidden >> 4) * 32, 256)), dim3(256), 0, W2, W2p, hidden, cout);
     FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
-    FGC_LAUNCH("mlp_pack_kernel", st, cast_f32_bf16_kernel, dim3(cdiv(cin * hidden / 4, 256)), dim3(256), 0, W1, W1h,
-               (int64_t)cin * hidden / 4);
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_w1dx_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, W1h, cin, hidden);
     const unsigned short* x16 = (const unsigned short*)x;
     const u32x4* Wp16 = (const u32x4*)Wp;
     const int tiles = cdiv(n, MB_T);
 #define FGC_MB_BWD(MT)                                                                                                      \
     do {                                                                                                                    \
         constexpr int CIN_ = MT * 16;                                                                                       \
-        const size_t smem_dx = (size_t)MBB_WAVES * (MB_T * 96);                                                             \
         FGC_LAUNCH("mlp_bwd_kernel<dx>", st, (mlp_bwd_dx_bf16_kernel<MT>), dim3(cdiv(tiles, MBB_WAVES)), dim3(MBB_THREADS),  \
-                   smem_dx, x16, dy, n, hidden, cout, Wp16, W1h, b1, W2p, alpha, (unsigned short*)dx);                      \
+                   0, x16, dy, n, hidden, cout, Wp16, (const u32x4*)W1h, b1, W2p, alpha, (unsigned short*)dx);        \
         const size_t smem_w = (size_t)MBB_WAVES * ((size_t)CIN_ * (MB_T * 2 + 8) + MB_T * 16);                              \
         FGC_LAUNCH("mlp_bwd_kernel<w>", st, (mlp_bwd_w_bf16_kernel<MT, 3>), dim3(gx / 4, gy), dim3(MBB_THREADS), smem_w, x16, \
                    dy, n, hidden, cout, Wp16, b1, W2p, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);                      \
