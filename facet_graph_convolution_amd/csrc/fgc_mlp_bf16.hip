@@ -25,10 +25,11 @@ constexpr int MB_T = 32;           // rows per backward tile
 constexpr int MB_RT = MB_T / 16;
 
 // W1 [cin, hidden] fp32 -> B fragments [k-step][column tile][lane][8] bf16 (k = input channel, 32 per step)
-__global__ void mlp_pack_bf16_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
+__device__ __forceinline__ void mlp_pack_bf16_body(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden,
+                                                   int bid, int nb) {
     const int nct = hidden >> 4;
     const size_t total = (size_t)(cin >> 5) * nct * 512;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63;
         const size_t rest = idx >> 9;
         const int ct = rest % nct, ks = (int)(rest / nct);
@@ -36,10 +37,8 @@ __global__ void mlp_pack_bf16_kernel(const float* __restrict__ W1, unsigned shor
         Wp[idx] = f_to_bf(W1[(size_t)c * hidden + ct * 16 + (lane & 15)]);
     }
 }
-
-__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t count4) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (int64_t)gridDim.x * blockDim.x)
-        reinterpret_cast<u32x2*>(dst)[i] = f4_to_bf4(reinterpret_cast<const f32x4*>(src)[i]);
+__global__ void mlp_pack_bf16_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
+    mlp_pack_bf16_body(W1, Wp, cin, hidden, blockIdx.x, gridDim.x);
 }
 
 // The 1024 -> 3 layer of the backward pass on the matrix pipe.  g[row][col] = sum_o dy[row][o] W2[col][o] has K = 3: on the
@@ -48,8 +47,9 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, unsigned sho
 // significand bits per operand; g is rounded to bf16 right afterwards for the products that consume it).
 //   A (per 16 rows):  lane (lr = row, lq):  lq 0: {hi0 hi1 hi2 lo0 lo1 lo2 0 0}   lq 1: {hi0 hi1 hi2 0 ...}   else 0
 //   B (per 16 hidden columns, packed once per launch): lq 0: {Whi0-2 Whi0-2 0 0}   lq 1: {Wlo0-2 0 ...}   else 0
-__global__ void mlp_pack_w2_bf16_kernel(const float* __restrict__ W2, u32x4* __restrict__ W2p, int hidden, int cout) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void mlp_pack_w2_bf16_body(const float* __restrict__ W2, u32x4* __restrict__ W2p, int hidden, int cout,
+                                                      int bid) {
+    const int idx = bid * blockDim.x + threadIdx.x;
     if (idx >= (hidden >> 4) * 32) return;       // lanes 0..31 of a fragment (lq 0 and 1); lanes 32..63 are zero, not stored
     const int lane = idx & 31, ct = idx >> 5, lr = lane & 15, lq = lane >> 4;
     unsigned short hi[3], lo[3];
@@ -68,16 +68,26 @@ __device__ __forceinline__ u32x4 mb_w2_frag(const u32x4* __restrict__ W2p, int c
 }
 // W1 [cin, hidden] fp32 -> B fragments of dx += dh W1^T in the k order of the dx kernel's transposed dh (pair pp of column
 // tiles, input-channel tile m, lane (lr = channel, lq)): element j = c2*4 + t is W1[m*16 + lr][pp*32 + c2*16 + 4*lq + t]
-__global__ void mlp_pack_w1dx_bf16_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wd, int cin, int hidden) {
+__device__ __forceinline__ void mlp_pack_w1dx_bf16_body(const float* __restrict__ W1, unsigned short* __restrict__ Wd, int cin,
+                                                        int hidden, int bid, int nb) {
     const size_t total = (size_t)cin * hidden;
     const int mt = cin >> 4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63;
         const size_t rest = idx >> 9;
         const int m = rest % mt, pp = (int)(rest / mt);
         const int ch = m * 16 + (lane & 15), col = pp * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
         Wd[idx] = f_to_bf(W1[(size_t)ch * hidden + col]);
     }
+}
+// the three operand packs of the backward pass in one launch: blocks [0, nb) W1 fragments, [nb, 2 nb) W1 in dx order, the rest W2
+__global__ void mlp_pack_bwd_bf16_kernel(const float* __restrict__ W1, const float* __restrict__ W2, unsigned short* __restrict__ Wp,
+                                         unsigned short* __restrict__ Wd, u32x4* __restrict__ W2p, int cin, int hidden, int cout,
+                                         int nb) {
+    const int b = blockIdx.x;
+    if (b < nb) mlp_pack_bf16_body(W1, Wp, cin, hidden, b, nb);
+    else if (b < 2 * nb) mlp_pack_w1dx_bf16_body(W1, Wd, cin, hidden, b - nb, nb);
+    else mlp_pack_w2_bf16_body(W2, W2p, hidden, cout, b - 2 * nb);
 }
 // A fragment of that product from a lane's dy row (o = 0..2)
 __device__ __forceinline__ u32x4 mb_dy_frag(float d0, float d1, float d2, int lq) {
@@ -850,9 +860,9 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
     w += align_up((size_t)(hidden >> 4) * 64 * 16, 256);
     float* rtmp = (float*)w;
 
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_w2_bf16_kernel, dim3(cdiv((hidden >> 4) * 32, 256)), dim3(256), 0, W2, W2p, hidden, cout);
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_w1dx_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, W1h, cin, hidden);
+    const int nbp = cdiv(cin * hidden, 1024);
+    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bwd_bf16_kernel, dim3(2 * nbp + cdiv((hidden >> 4) * 32, 256)), dim3(256), 0, W1, W2, Wp,
+               W1h, W2p, cin, hidden, cout, nbp);
     const unsigned short* x16 = (const unsigned short*)x;
     const u32x4* Wp16 = (const u32x4*)Wp;
     const int tiles = cdiv(n, MB_T);
