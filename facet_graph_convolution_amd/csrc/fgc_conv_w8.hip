@@ -607,8 +607,10 @@ static bool w8_fast(const CoreParams& p) {
 // workgroups).  FGC_W8_NT16 = 0: never, 2: the data kernel always (developer switch).
 template <bool DATA>
 static bool w8_half_tiles(const CoreParams& p) {
-    static const int mode = getenv("FGC_W8_NT16") ? atoi(getenv("FGC_W8_NT16")) : 1;
-    static const int min_n = getenv("FGC_W8_DATA16_MIN_N") ? atoi(getenv("FGC_W8_DATA16_MIN_N")) : 81920;
+    // (read at every launch: a test switches them between two calls of one process)
+    const char* em = getenv("FGC_W8_NT16");
+    const char* en = getenv("FGC_W8_DATA16_MIN_N");
+    const int mode = em ? atoi(em) : 1, min_n = en ? atoi(en) : 81920;
     if ((p.npad >> 4) > 4 || mode < 1) return false;
     return !DATA || mode >= 2 || p.n >= min_n;
 }

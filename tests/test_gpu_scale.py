@@ -69,6 +69,42 @@ def test_39k_facet_train_step_matches_oracle():
     _train_step_vs_oracle(x, adjs, gt)
 
 
+def test_39k_facet_train_step_with_the_data_kernel_on_half_tiles_matches_oracle(monkeypatch):
+    """The data-gradient kernel takes 16-node tiles from 81 920 nodes per level up (the benchmark's level 0); here it is
+    forced onto them at 47 904 / 11 976 / 2 994 nodes so that the form is held against the oracle too (its da | dg rows
+    live in spare floats of the edge table: conv_w8_kernel<DATA, ..., NT = 16>)."""
+    monkeypatch.setenv("FGC_W8_DATA16_MIN_N", "0")
+    _train_step_vs_oracle(*_mesh(140, 140))
+
+
+@pytest.mark.parametrize("dtype,env", [("f32", "FGC_NO_FUSED_DS"), ("bf16", "FGC_NO_FUSED_DS_BF16")])
+def test_160k_facet_fused_ds_prologue_agrees_with_the_separate_launch(dtype, env, monkeypatch):
+    """Levels beyond 131 072 nodes (here 195k at level 0): the d-logits kernel's prologue computes s = dy * lrelu'(y) / deg
+    there too since the bias-gradient partials are one per tile at every size.  Size-independent property: the two ways of
+    computing s agree - every gradient that does not pass through the bias partial sums bit for bit, the biases to fp32
+    rounding of sums over 195k rows."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    x, adjs, gt = _mesh(400, 200)
+    assert x.shape[1] > 131072
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv(env, mode)
+        net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
+        net.set_samples(samp)
+        net.set_rotation(np.eye(3))
+        net.forward_backward(rotate=True)
+        torch.cuda.synchronize()
+        grads[mode] = [g.clone() for g in net.params.grads]
+        del net
+    from facet_graph_convolution_amd.net import param_spec
+    for i, (a, b) in enumerate(zip(grads["0"], grads["1"])):
+        if param_spec()[i][0] == "bias":
+            assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-6), i
+        else:
+            assert torch.equal(a, b), i
+
+
 def test_100k_facet_forward_matches_oracle():
     """BASELINE config 2 at full size: torus 250 x 200 = 100 000 facets, forward of the whole network (the oracle's
     backward does not fit in host memory at this size)."""
