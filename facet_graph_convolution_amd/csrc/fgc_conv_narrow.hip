@@ -23,7 +23,7 @@ namespace fgc {
 
 typedef float f32x2n __attribute__((ext_vector_type(2)));
 constexpr int NB = 256;          // nodes per workgroup (= 8 tiles of 32)
-constexpr int EB_FWD = 4;        // edges requested together (forward)
+constexpr int EB_FWD = 8;        // edges requested together (forward; 4 -> 8: two dependent batches per node instead of four, -1.5 us)
 constexpr int EB_BWD = 2;        // (backward: twice the per-lane state, half the batch)
 
 struct NarrowFwd {
