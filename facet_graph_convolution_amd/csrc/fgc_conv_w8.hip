@@ -15,7 +15,8 @@ namespace fgc {
 
 // developer knock-outs for phase timing (results are wrong with any bit set; never set in the shipped build):
 // 1 = no MFMA instructions (operand loads kept), 2 = no aggregation FMAs (gathers kept), 4 = no soft-assignment math,
-// 8 = no matrix phase at all (barriers kept), 16 = no row gathers, 32 = no output epilogue, 64 = no logit-row gathers
+// 8 = no matrix phase at all (barriers kept), 16 = no row gathers, 32 = no output epilogue, 64 = no logit-row gathers,
+// 128 = data kernel: no r stores, 256 = data kernel: no dl gathers
 #ifndef FGC_KO
 #define FGC_KO 0
 #endif
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
             q[8] = l[8] * inv;
             if (!PIPE) q[9] = __int_as_float(jj[t] >> p.shift);
-            if (DATA) {
+            if (DATA && !(FGC_KO & 256)) {
                 const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(de.dl), 0, -1, 0x00020000);
                 const unsigned dof = __umul24((unsigned)p.eid[e0 + k], FGC_DL_LD * 4u);
                 const f32x4 d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof, 0, 0));
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             }
         }        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
             const int j = tile0 + node;
-            if (j < p.n && cbase < p.cg) {
+            if (!(FGC_KO & 128) && j < p.n && cbase < p.cg) {
                 if constexpr (BF) {
                     unsigned* rr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)j * de.rld + cbase);
 #pragma unroll
