@@ -211,7 +211,7 @@ struct LogitParams {
 constexpr int K1_CTW = 5;  // column tiles of dz per wave: kpass/16 <= 18 -> ceil(18/4)
 // developer knock-outs of the deep d-logits kernel for phase timing (results are wrong with any bit set; never set in the
 // shipped build): 1 = no dz-GEMM MFMAs, 2 = no packed-weight loads, 4 = no dz tile stores, 8 = no per-node product MFMAs,
-// 16 = no neighbour-row gathers, 32 = no softmax backward / dl stores
+// 16 = no neighbour-row gathers, 32 = no softmax backward / dl stores, 64 = no dl stores (softmax backward kept)
 #ifndef FGC_KO1
 #define FGC_KO1 0
 #endif
@@ -934,7 +934,7 @@ __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd
                 f32x4 dl;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dl[t] = ok ? q[t] * (g[t] - dot) : 0.f;
-                if (ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = dl;
+                if (!(FGC_KO1 & 64) && ok && lq < 3) *reinterpret_cast<f32x4*>(lp.dl + (size_t)(e0 + edge) * FGC_DL_LD + 4 * lq) = dl;
                 da += dl;
             }
 #pragma unroll
