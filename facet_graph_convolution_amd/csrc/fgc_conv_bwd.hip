@@ -1776,12 +1776,20 @@ int tn_balanced_splits(int desired, int maxs, int rows) {
     return desired;
 }
 
-// An XCD has 32 CUs x 4 resident workgroups of these kernels = 128 slots and is given tiles x (slabs / 8) workgroups:
-// as many slabs as fill those slots once (a count just above 96 or 128 leaves a few CUs with one workgroup more than the
-// rest, and the launch waits for them).
+// An XCD has 32 CUs x 4 resident workgroups of these kernels = 128 slots and is given tiles x (slabs / 8) workgroups: the
+// slab count fills a whole number of slots per CU exactly once (a count just above a multiple of 32 leaves a few CUs with one
+// workgroup more than the rest, and the launch waits for them).
 static int tn_splits(int P, int Q, int rows) {
     const int tiles = cdiv(P, 64) * cdiv(Q, 64);
-    return tn_balanced_splits(8 * std::max(1, 128 / tiles), cdiv(rows, 128), rows);
+    // Two workgroups per CU (64 slots per XCD), not the four that fit: the kernel is bound by the matrix pipe and by HBM,
+    // which eight waves per CU keep as busy as sixteen, and every workgroup less is a 16 KB slab less to write and to sum
+    // (measured over 32 ... 256 slots: 64 is the minimum of the step, 2.192 -> 2.179 ms; the GEMMs 1-2 us faster each, the
+    // sums 17 -> 12 us per launch).  Layers with more than 32 output tiles (the 128 -> 128 layer of the coarsest level)
+    // would get one slab per XCD that way and keep 128 slots (32 -> 39 us otherwise).  FGC_TN_SLOTS: developer knob.
+    static const int slots = getenv("FGC_TN_SLOTS") ? atoi(getenv("FGC_TN_SLOTS")) : 64;
+    int per = slots / tiles;
+    if (per < 2) per = std::max(1, 2 * slots / tiles);
+    return tn_balanced_splits(8 * per, cdiv(rows, 128), rows);
 }
 
 // Nodes per workgroup of the deep d-logits kernel: half tiles (16 nodes, four workgroups per CU) for the fp32 network on
@@ -1846,7 +1854,9 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
     w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
                   reduce_tmp_floats(cdiv(d->n, k1n), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
-    w.narrow = narrow_supported(d) ? take(narrow_bwd_floats(d)) : nullptr;
+    // (the first layer's scratch ends with the scratch of its fixed-order sums; the db partials of stage 1 are summed with
+    //  them and need theirs behind it - it used to be missing: 64 groups x cout floats written past the workspace)
+    w.narrow = narrow_supported(d) ? take(narrow_bwd_floats(d) + reduce_tmp_floats(w.nb_db, d->cout) + 64) : nullptr;
     w.bytes = off;
     return w;
 }

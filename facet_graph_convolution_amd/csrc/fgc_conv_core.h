@@ -139,8 +139,9 @@ __device__ __forceinline__ int softmax_phase(const CoreParams& p, const Smem& s,
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const int kk = kbase + kl + LPN * t;
-        // (unconditional, clamped into the node's list: no exec-masked load)
-        const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(e0 + min(kk, max(kend - 1, 0))) * 4u, 0, 0);
+        // (unconditional, clamped into the node's list: no exec-masked load.  A node WITHOUT edges reads the entry in front
+        //  of its empty list: for the padding nodes at the end of a level e0 == nnz, one past the array)
+        const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(kend > 0 ? e0 + min(kk, kend - 1) : max(e0 - 1, 0)) * 4u, 0, 0);
         jj[t] = kk < kend ? jv : 0;
     }
 #pragma unroll

@@ -227,8 +227,9 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
-            // (unconditional, clamped into the node's list: no exec-masked load)
-            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(e0 + min(k, max(d - 1, 0))) * 4u, 0, 0);
+            // (unconditional, clamped into the node's list: no exec-masked load.  A node WITHOUT edges reads the entry in
+            //  front of its empty list: for the padding nodes at the end of a level e0 == nnz, one past the array)
+            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(d > 0 ? e0 + min(k, d - 1) : max(e0 - 1, 0)) * 4u, 0, 0);
             jj[t] = k < d ? jv : 0;
         }
 #pragma unroll

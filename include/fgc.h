@@ -156,7 +156,7 @@ typedef struct fgc_conv_desc {
     int32_t n;              /* nodes of this level */
     int32_t nnz;            /* edges */
     const int32_t* rowptr;  /* [n+1] */
-    const int32_t* col;     /* [nnz] */
+    const int32_t* col;     /* [nnz]; at least one readable entry (a level of nothing but edgeless nodes reads col[0]) */
     const float* x0;        /* [(n >> shift), c0] */
     const float* x1;        /* [(n >> shift), c1] or NULL */
     int32_t c0, c1;         /* cin = c0 + c1 */
