@@ -1,0 +1,152 @@
+"""No kernel of a training step writes outside the buffers it was given.
+
+Every device tensor that `FacetDenoiser` allocates while it is built and bound (parameters, activations and their gradient
+twins, the shared backward scratch, every per-layer workspace) is placed between two 64 KB guard zones filled with a
+byte pattern; after a forward + backward + Adam step - eager, and replayed from a hipGraph - the guard zones must be
+untouched.  (Found the hard way at the end of round 2: the first layer's backward scratch was 8 KB short and the fixed-order
+sum of its bias gradient wrote past the workspace, silently for a whole round - DESIGN.md section 6.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 64 * 1024
+PATTERN = 0xA5
+
+
+class _Guarded:
+    """Context manager: torch.empty / zeros / empty_like / zeros_like / eye on a CUDA device return views into padded
+    storage for as long as it is active."""
+
+    def __init__(self):
+        self.bases = []
+        self.saved = {}
+
+    def _alloc(self, shape, dtype, device, zero):
+        dtype = dtype or torch.float32
+        nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+        pad = (nbytes + 255) // 256 * 256
+        base = self.saved["empty"](pad + 2 * GUARD, dtype=torch.uint8, device=device)
+        base.fill_(PATTERN)
+        view = base[GUARD:GUARD + nbytes].view(dtype).view(*shape)
+        if zero:
+            view.zero_()
+        self.bases.append((base, nbytes))
+        return view
+
+    @staticmethod
+    def _is_cuda(device):
+        return device is not None and str(device).startswith("cuda")
+
+    def __enter__(self):
+        for name in ("empty", "zeros", "empty_like", "zeros_like", "eye"):
+            self.saved[name] = getattr(torch, name)
+
+        def make(name, zero):
+            real = self.saved[name]
+
+            def f(*size, **kw):
+                if not self._is_cuda(kw.get("device")) or kw.get("pin_memory"):
+                    return real(*size, **kw)
+                shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+                return self._alloc(shape, kw.get("dtype"), kw["device"], zero)
+            return f
+
+        def make_like(name, zero):
+            real = self.saved[name]
+
+            def f(t, **kw):
+                dev = kw.get("device", t.device)
+                if not self._is_cuda(dev):
+                    return real(t, **kw)
+                return self._alloc(tuple(t.shape), kw.get("dtype", t.dtype), dev, zero)
+            return f
+
+        def eye(n, **kw):
+            if not self._is_cuda(kw.get("device")):
+                return self.saved["eye"](n, **kw)
+            out = self._alloc((n, n), kw.get("dtype"), kw["device"], True)
+            out.copy_(self.saved["eye"](n, dtype=out.dtype))
+            return out
+
+        torch.empty, torch.zeros = make("empty", False), make("zeros", True)
+        torch.empty_like, torch.zeros_like = make_like("empty_like", False), make_like("zeros_like", True)
+        torch.eye = eye
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(torch, name, fn)
+
+    def check(self, what):
+        torch.cuda.synchronize()
+        bad = []
+        for k, (base, nbytes) in enumerate(self.bases):
+            pad = (nbytes + 255) // 256 * 256
+            lo, hi = base[:GUARD], base[GUARD + pad:]
+            if not bool((lo == PATTERN).all()) or not bool((hi == PATTERN).all()):
+                first = int((hi != PATTERN).nonzero()[0]) if not bool((hi == PATTERN).all()) else -1
+                bad.append((k, nbytes, first, int((hi != PATTERN).sum()), int((lo != PATTERN).sum())))
+        assert not bad, "%s: guard zones overwritten (allocation #, bytes, first byte past the end, count after, count before): %s" % (
+            what, bad[:5])
+
+
+def _mesh(nu, nv):
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import torus, add_noise
+    V, F = torus(nu, nv)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F, 0.2, seed=3), F, V, seed=7)
+    return ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("size", [(24, 20), (140, 140), (320, 256)])
+def test_training_step_stays_inside_its_buffers(dtype, size):
+    """960 facets (a handful of tiles), 39 200 (the oracle-parity size) and 163 840 (levels beyond 131k nodes: the sizes the
+    missing scratch was found at)."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    x, adjs, gt = _mesh(*size)
+    with _Guarded() as g:
+        net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
+        assert len(g.bases) > 40
+        g.check("bind")
+        rs = np.random.RandomState(1)
+        for step in range(2):
+            net.train_step(sample_ind=rs.randint(x.shape[1], size=4000), R=np.eye(3))
+        g.check("eager steps")
+        for step in range(3):
+            net.train_step(sample_ind=rs.randint(x.shape[1], size=4000), R=np.eye(3), capture=True)
+        g.check("hipGraph steps")
+        net.forward(rotate=False)
+        g.check("inference forward")
+
+
+def test_multi_scale_training_step_stays_inside_its_buffers():
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    x, adjs, gt = _mesh(64, 48)
+    with _Guarded() as g:
+        net = FacetDenoiser("cuda:0", seed=0, multi_scale=True).bind_mesh(x, adjs, gt=gt)
+        rs = np.random.RandomState(1)
+        for step in range(2):
+            net.train_step(sample_ind=rs.randint(x.shape[1], size=4000), R=np.eye(3))
+        net.forward_multi_scale()
+        g.check("multi-scale steps")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_facet_sharded_step_stays_inside_its_buffers(world):
+    """N shards in one process (shard.sim_run): halo tails, packed exchange buffers, interior / boundary tile lists."""
+    from facet_graph_convolution_amd.shard import make_sim_shards, sim_forward_backward
+    x, adjs, gt = _mesh(96, 64)
+    with _Guarded() as g:
+        nets = make_sim_shards(x, adjs, gt, world, "cuda:0", seed=0)
+        samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+        for n in nets:
+            n.set_rotation(np.eye(3))
+            n.set_samples(samp)
+        sim_forward_backward(nets, rotate=True)
+        g.check("sharded step")
