@@ -150,3 +150,54 @@ def test_facet_sharded_step_stays_inside_its_buffers(world):
             n.set_samples(samp)
         sim_forward_backward(nets, rotate=True)
         g.check("sharded step")
+
+
+def _conv_cases():
+    import test_gpu_conv
+    return list(test_gpu_conv.CONV_CASES)
+
+
+OP_TESTS = [
+    ("test_gpu_ops", "test_mlp_forward", dict(n=1000, cin=32)),
+    ("test_gpu_ops", "test_mlp_forward", dict(n=130, cin=128)),
+    ("test_gpu_ops", "test_mlp_backward", dict(n=5000, cin=32)),
+    ("test_gpu_ops", "test_mlp_backward", dict(n=6, cin=32)),
+    ("test_gpu_ops", "test_mlp_backward", dict(n=333, cin=128)),
+    ("test_gpu_ops", "test_mlp_backward", dict(n=70, cin=48)),
+    ("test_gpu_ops", "test_elementwise_ops", {}),
+    ("test_gpu_ops", "test_normalize_and_loss", dict(n=5000)),
+    ("test_gpu_ops", "test_rotate_adam_epilogue_gather", {}),
+    ("test_gpu_ops", "test_vertex_update_matches_reference", dict(tag="ico3")),
+    ("test_gpu_ops", "test_vertex_update_matches_reference", dict(tag="torus_open")),
+    ("test_gpu_ops", "test_multiscale_vertex_update_matches_reference", {}),
+    ("test_gpu_conv", "test_conv_forward_matches_golden", "ALL_CASES"),
+    ("test_gpu_conv", "test_conv_backward_matches_golden", "ALL_CASES"),
+    ("test_gpu_conv", "test_conv_concat_upsample_and_pool_match_oracle", {}),
+    ("test_gpu_conv", "test_conv_backward_fused_addressing_matches_oracle", dict(mode="concat")),
+    ("test_gpu_conv", "test_conv_backward_fused_addressing_matches_oracle", dict(mode="upsample")),
+    ("test_gpu_conv", "test_partial_calls_compose_to_the_whole_layer", {}),
+    ("test_gpu_conv", "test_first_layer_backward_without_input_gradient", dict(case="c1_raw")),
+    ("test_gpu_conv", "test_first_layer_backward_without_input_gradient", dict(case="c1_coarsened")),
+    ("test_gpu_model_api", "test_custom_conv2d_signature_and_return", {}),
+    ("test_gpu_model_api", "test_multiscale_heads_train_through_the_operator_api", {}),
+    ("test_gpu_bf16", "test_bf16_mlp_kernels_against_torch", {}),
+]
+
+
+@pytest.mark.parametrize("module,name,kw", OP_TESTS, ids=["%s-%s" % (n, "-".join(str(v) for v in k.values()) if isinstance(k, dict) else "all")
+                                                        for _, n, k in OP_TESTS])
+def test_operator_level_tests_stay_inside_their_buffers(golden_dir, module, name, kw):
+    """The operator-level parity tests (conv forward / backward cases, MLP shapes incl. the odd ones, elementwise ops,
+    vertex update, the reference-style operator API) once more with every torch.empty / zeros(..., device=cuda) they and
+    the package make between guard zones: outputs, workspaces and gradient buffers of the C-ABI calls."""
+    import importlib
+    import inspect
+    fn = getattr(importlib.import_module(module), name)
+    runs = [dict(case=c) for c in _conv_cases()] if kw == "ALL_CASES" else [dict(kw)]
+    for args in runs:
+        if "golden_dir" in inspect.signature(fn).parameters:
+            args["golden_dir"] = golden_dir
+        with _Guarded() as g:
+            fn(**args)
+            assert g.bases, "nothing was allocated through the guarded constructors"
+            g.check("%s(%s)" % (name, {k: v for k, v in args.items() if k != "golden_dir"}))
