@@ -21,16 +21,17 @@ class _Guarded:
     """Context manager: torch.empty / zeros / empty_like / zeros_like / eye on a CUDA device return views into padded
     storage for as long as it is active."""
 
-    def __init__(self):
+    def __init__(self, pattern=PATTERN):
         self.bases = []
         self.saved = {}
+        self.pattern = pattern
 
     def _alloc(self, shape, dtype, device, zero):
         dtype = dtype or torch.float32
         nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
         pad = (nbytes + 255) // 256 * 256
         base = self.saved["empty"](pad + 2 * GUARD, dtype=torch.uint8, device=device)
-        base.fill_(PATTERN)
+        base.fill_(self.pattern)
         view = base[GUARD:GUARD + nbytes].view(dtype).view(*shape)
         if zero:
             view.zero_()
@@ -87,9 +88,10 @@ class _Guarded:
         for k, (base, nbytes) in enumerate(self.bases):
             pad = (nbytes + 255) // 256 * 256
             lo, hi = base[:GUARD], base[GUARD + pad:]
-            if not bool((lo == PATTERN).all()) or not bool((hi == PATTERN).all()):
-                first = int((hi != PATTERN).nonzero()[0]) if not bool((hi == PATTERN).all()) else -1
-                bad.append((k, nbytes, first, int((hi != PATTERN).sum()), int((lo != PATTERN).sum())))
+            P = self.pattern
+            if not bool((lo == P).all()) or not bool((hi == P).all()):
+                first = int((hi != P).nonzero()[0]) if not bool((hi == P).all()) else -1
+                bad.append((k, nbytes, first, int((hi != P).sum()), int((lo != P).sum())))
         assert not bad, "%s: guard zones overwritten (allocation #, bytes, first byte past the end, count after, count before): %s" % (
             what, bad[:5])
 
@@ -123,6 +125,31 @@ def test_training_step_stays_inside_its_buffers(dtype, size):
         g.check("hipGraph steps")
         net.forward(rotate=False)
         g.check("inference forward")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_results_do_not_depend_on_what_lies_around_the_buffers(dtype):
+    """Reads: the same two training steps with the guard zones filled with 0x00 and with 0xFF (NaN as a float, -1 as an
+    index).  A kernel that reads past a buffer and lets the value reach a result - or an address - shows up as a different
+    gradient (or a fault)."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    x, adjs, gt = _mesh(140, 140)
+    out = []
+    for pattern in (0x00, 0xFF):
+        with _Guarded(pattern) as g:
+            net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
+            rs = np.random.RandomState(1)
+            for step in range(2):
+                loss = net.train_step(sample_ind=rs.randint(x.shape[1], size=4000), R=np.eye(3))
+            g.check("pattern %#x" % pattern)
+            out.append(([t.clone() for t in net.params.grads], net.params.theta.clone(), loss.clone(),
+                        net.buffers["nconv"].clone()))
+            del net
+    (ga, ta, la, na), (gb, tb, lb, nb) = out
+    assert torch.equal(la, lb) and torch.equal(na, nb) and torch.equal(ta, tb)
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        assert torch.equal(a, b), "gradient %d depends on the bytes around the buffers" % i
+    assert bool(torch.isfinite(ta).all())
 
 
 def test_multi_scale_training_step_stays_inside_its_buffers():
