@@ -96,20 +96,22 @@ class _Guarded:
             what, bad[:5])
 
 
-def _mesh(nu, nv):
+def _mesh(nu, nv, flips=0):
     from facet_graph_convolution_amd.dataClasses import TrainingSet
-    from facet_graph_convolution_amd.meshgen import torus, add_noise
+    from facet_graph_convolution_amd.meshgen import torus, add_noise, flip_edges
     V, F = torus(nu, nv)
+    if flips:
+        F = flip_edges(F, flips, seed=1)     # irregular: facet degrees above 16 (24-slot kernels, LONG d-logits form)
     ds = TrainingSet()
     ds.addMeshWithGT(add_noise(V, F, 0.2, seed=3), F, V, seed=7)
     return ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("size", [(24, 20), (140, 140), (320, 256)])
+@pytest.mark.parametrize("size", [(24, 20), (140, 140), (320, 256), (100, 64, 3000), (24, 20, 400)])
 def test_training_step_stays_inside_its_buffers(dtype, size):
     """960 facets (a handful of tiles), 39 200 (the oracle-parity size) and 163 840 (levels beyond 131k nodes: the sizes the
-    missing scratch was found at)."""
+    missing scratch was found at); 12 800 and 960 facets with flipped edges (irregular graphs: the 24-slot kernels)."""
     from facet_graph_convolution_amd.net import FacetDenoiser
     x, adjs, gt = _mesh(*size)
     with _Guarded() as g:
