@@ -1797,9 +1797,11 @@ static int tn_splits(int P, int Q, int rows) {
 // prologue and of ds_db_kernel) are counted in these units by the workspace plan, the launches and the reductions.
 // FGC_K1_NT16=0: 32-node tiles everywhere.
 static int k1_nodes(const fgc_conv_desc* d) {
-    static const bool on = !(getenv("FGC_K1_NT16") && getenv("FGC_K1_NT16")[0] == '0');
-    static const bool k1m = !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1');
-    static const bool k1deep = !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+    // (read on every call, like the launch code reads FGC_NO_K1M / FGC_NO_K1DEEP: a process that changes a switch between
+    //  two calls gets slot counts and kernels that agree)
+    const bool on = !(getenv("FGC_K1_NT16") && getenv("FGC_K1_NT16")[0] == '0');
+    const bool k1m = !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1');
+    const bool k1deep = !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
     if (!on || !k1m || !k1deep) return TILE;
     const int cin = d->c0 + d->c1;
     const ConvGeom g1 = conv_geom(cin, d->cout);

@@ -800,12 +800,10 @@ class FacetDenoiser:
         self._enqueue_forward(rotate)
         return self._mesh["B"]["nconv"]
 
-    def forward_multi_scale(self, rotate=False):
-        """The multi-scale denoising forward of inferNet (train.py:188-193): the three heads, each through
-        normalizeTensor.  Returns (n_conv0 [N0,3], n_conv1 [N0/4,3], n_conv2 [N0/16,3]) in node order."""
-        if not self.multi_scale:
-            raise RuntimeError("the network was built without the multi-scale heads (multi_scale=True)")
-        self._enqueue_forward(rotate)
+    def _forward_ms_gen(self, rotate):
+        """The multi-scale forward as a schedule: the network, then normalizeTensor on the two coarse heads (on a
+        facet-sharded run one scalar all-reduce each: utils.py:1705 takes the mean over the whole tensor)."""
+        yield from self._forward_gen(rotate)
         M, L, st = self._mesh, self.L, self._st()
         B = M["B"]
         for k, level in (("1", 1), ("2", 2)):
@@ -815,9 +813,17 @@ class FacetDenoiser:
                 _lib.check(L.fgc_normalize_fwd(_p(y), nk, _p(part), part.numel(), _p(out), _p(sc), st), "normalize")
             else:
                 tot = part.sum().reshape(1)
-                self.comm.all_reduce_sum(tot)
+                yield ("sum", tot)
                 sc[0:1] = tot / (3.0 * M["n_total"][level]) + 1e-5
                 _lib.check(L.fgc_normalize_apply(_p(y), nk, _p(sc), _p(out), st), "normalize")
+
+    def forward_multi_scale(self, rotate=False):
+        """The multi-scale denoising forward of inferNet (train.py:188-193): the three heads, each through
+        normalizeTensor.  Returns (n_conv0 [N0,3], n_conv1 [N0/4,3], n_conv2 [N0/16,3]) in node order."""
+        if not self.multi_scale:
+            raise RuntimeError("the network was built without the multi-scale heads (multi_scale=True)")
+        self._drain(self._forward_ms_gen(rotate))
+        B = self._mesh["B"]
         return B["nconv"], B["nconv1"], B["nconv2"]
 
     def measure_exchanges(self, step_fn, steps=3):

@@ -266,6 +266,11 @@ class PackedExchange:
     def pack(self):
         self._run(self._row_jobs()[0], "halo pack")
 
+    def poison_tails(self):
+        """Tests only (shard.sim_run): NaN in every row this exchange is going to deliver."""
+        for j in self.unpack_jobs:
+            j["dst"][j["dst_row"]:j["dst_row"] + j["rows"]].fill_(float("nan"))
+
     def unpack(self):
         self._run(self._row_jobs()[1], "halo unpack")
 
@@ -292,7 +297,9 @@ class DistComm:
             self._gloo_a2a(r, send.cpu(), recv_splits, send_splits)
             recv.copy_(r)
             return None
-        if send.numel() == 0 and recv.numel() == 0:
+        # Issued by EVERY rank of a world > 1 even when this rank neither sends nor receives (a shard without a halo at
+        # some level): whether to call a collective must never be a rank-local decision.  A world of one has no peers.
+        if self.world == 1 and send.numel() == 0 and recv.numel() == 0:
             return None
         return self.dist.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=self.group,
                                            async_op=async_op)
@@ -358,33 +365,47 @@ def graphs_to_host_csr(adjs):
     return out
 
 
-def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0, dtype="f32"):
+def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0, dtype="f32", multi_scale=False):
     """`world` shard networks of one mesh inside ONE process (parity tests of the sharded schedule on a single GPU)."""
     from .net import FacetDenoiser
     gh = graphs_to_host_csr(adjs)
     nets = []
     for r in range(world):
         plan = ShardPlan(gh, r, world)
-        nets.append(FacetDenoiser(device, seed=seed, dtype=dtype).bind_mesh(x, adjs, gt=gt, plan=plan))
+        nets.append(FacetDenoiser(device, seed=seed, dtype=dtype, multi_scale=multi_scale).bind_mesh(x, adjs, gt=gt, plan=plan))
     return nets
 
 
-def sim_run(nets, make_gen):
-    """Advance the schedules of all shards in lock step; every yielded request is an exchange among them."""
+def sim_run(nets, make_gen, poison=True):
+    """Advance the schedules of all shards; every yielded exchange / all-reduce request is served among them.
+
+    Exchanges and sums are COLLECTIVE: all shards must arrive at them in the same order.  A ("wait", key) is
+    rank-local (one shard may overlap an exchange with its interior tiles while a peer with a small interior blocks), so
+    every generator is advanced to its next collective request on its own.  An overlapped exchange is modelled the way
+    the hardware may behave at worst: the rows are packed when it begins, but they only land in the halo tails at the
+    shard's ("wait", key) - and until then the tails hold NaN (`poison`), so a kernel of the overlapped stretch that
+    lets a halo row reach a result fails the parity tests instead of reading last step's values."""
     gens = [make_gen(n) for n in nets]
-    while True:
-        reqs = []
-        for g in gens:
+    pending = [dict() for _ in nets]
+
+    def advance(i):
+        while True:
             try:
-                reqs.append(next(g))
+                r = next(gens[i])
             except StopIteration:
-                reqs.append(None)
+                assert not pending[i], "a begun exchange was never awaited"
+                return None
+            if r[0] == "wait":
+                pending[i].pop(r[1]).unpack()
+                continue
+            return r
+
+    while True:
+        reqs = [advance(i) for i in range(len(nets))]
         if all(r is None for r in reqs):
             return
         assert all(r is not None for r in reqs), "shards disagree on the exchange schedule"
         assert len({r[0] for r in reqs}) == 1, "shards disagree on the exchange schedule"
-        if reqs[0][0] == "wait":       # the exchange already happened when it was begun
-            continue
         if reqs[0][0] == "call":       # launches a shard makes outside its captured graphs (see net._loss_backward_gen)
             for r in reqs:
                 r[1]()
@@ -407,10 +428,41 @@ def sim_run(nets, make_gen):
                 so = np.cumsum([0] + ps.send_splits)
                 assert ps.send_splits[dst] == pd.recv_splits[src], (src, dst)
                 pd.recv_buf[ro[src]:ro[src + 1]].copy_(ps.send_buf[so[dst]:so[dst + 1]])
-        for px in pxs:
-            px.unpack()
+        for i, (px, r) in enumerate(zip(pxs, reqs)):
+            if r[2] is None:
+                px.unpack()
+            else:
+                assert r[2] not in pending[i], "two exchanges in flight under one key"
+                pending[i][r[2]] = px
+                if poison:
+                    px.poison_tails()
 
 
 def sim_forward_backward(nets, rotate=True):
     sim_run(nets, lambda n: n._forward_gen(rotate))
     sim_run(nets, lambda n: n._loss_backward_gen(rotate))
+
+
+def sim_forward_multi_scale(nets, rotate=False):
+    sim_run(nets, lambda n: n._forward_ms_gen(rotate))
+
+
+def sim_forward_backward_captured(nets, rotate=True):
+    """The step of sim_forward_backward with every shard's launches replayed from its hipGraph segments (one graph per
+    stretch between two exchanges, net._capture_segments), the requests served between the replays - what
+    `forward_backward(capture=True)` does on a sharded rank, with the simulated exchange in place of the communicator.
+    Run one eager step first: one-time set-up inside the library must not happen under capture."""
+    for n in nets:
+        if n._graph_fb is None:
+            n._graph_fb = ((n._capture_segments(lambda: n._forward_gen(rotate)),
+                            n._capture_segments(lambda: n._loss_backward_gen(rotate))), rotate)
+
+    def replay(segs):
+        for g, req in segs:
+            g.replay()
+            if req is not None:
+                yield req
+
+    sim_run(nets, lambda n: replay(n._graph_fb[0][0]))
+    sim_run(nets, lambda n: replay(n._graph_fb[0][1]))
+

@@ -215,3 +215,96 @@ def test_bf16_rejects_what_it_does_not_cover(golden_dir):
         net.train_step(sample_ind=np.arange(100), R=np.eye(3))
     with pytest.raises(ValueError):
         FacetDenoiser("cuda:0", dtype="fp8")
+
+
+def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act):
+    """One conv layer with FGC_CONV_BF16 straight through the C ABI: bf16 x / y / dy / ds / r / dx, fp32 everything else.
+    Returns (y bf16, dx0, dx1, [dW0, db, du, dc, dv])."""
+    import ctypes as C
+    from facet_graph_convolution_amd import _lib, ops
+    from facet_graph_convolution_amd._lib import ConvBwdIO, AG_LD, DL_LD, FGC_M, ptr, stream_ptr, check
+    L = _lib.lib()
+    dev = x0.device
+    d = ops.make_conv_desc(g, x0, x1, shift, params, True, act, 0.1)
+    d.flags = _lib.CONV_BF16
+    d.src_rows = x0.shape[0]
+    n, cout = g.n, d.cout
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    ws = torch.empty(L.fgc_conv_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
+    ag = torch.empty(x0.shape[0], AG_LD, **f32)
+    y = torch.empty(n, cout, **bf)
+    check(L.fgc_conv_fwd(C.byref(d), ptr(ag), ptr(y), None, ptr(ws), ws.numel(), stream_ptr()), "fgc_conv_fwd bf16")
+    trow, tcol, tedge = g.transposed()
+    io = ConvBwdIO()
+    io.trowptr, io.tcol, io.tedge = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr()
+    io.max_in_deg = g.max_in_deg
+    ds = torch.empty(n, cout, **bf)
+    dl = torch.empty(max(g.nnz, 1), DL_LD, **f32)
+    dag = torch.empty(n, AG_LD, **f32)
+    r = torch.empty(n, FGC_M * cout + 24, **bf)
+    grads = [torch.empty_like(p) for p in params]
+    dx0 = torch.empty_like(x0)
+    dx1 = torch.empty_like(x1) if x1 is not None else None
+    io.ag, io.y, io.dy = ag.data_ptr(), y.data_ptr(), dy.data_ptr()
+    io.ds, io.dl, io.dag, io.r = ds.data_ptr(), dl.data_ptr(), dag.data_ptr(), r.data_ptr()
+    io.dx0, io.dx1 = dx0.data_ptr(), (dx1.data_ptr() if dx1 is not None else None)
+    io.dW0, io.db, io.du, io.dc, io.dv = [t.data_ptr() for t in grads]
+    wsb = torch.empty(L.fgc_conv_bwd_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
+    check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(wsb), wsb.numel(), stream_ptr()), "fgc_conv_bwd bf16")
+    torch.cuda.synchronize()
+    return y, dx0, dx1, grads
+
+
+@pytest.mark.parametrize("mode,cin,cout", [("plain", 32, 64), ("plain", 64, 128), ("concat", 128, 64), ("upsample", 128, 64),
+                                           ("plain", 128, 128)])
+def test_bf16_conv_kernels_against_float64_on_the_same_rounded_operands(mode, cin, cout):
+    """Kernel error isolated from storage error: one conv layer, forward and backward, through the bf16 kernels against
+    the float64 oracle fed the SAME bf16-rounded x and dy (and, for lrelu', the bf16 kernel's own stored y).  What is
+    left is what the kernels themselves round: the output y and dx to bf16 (2^-9 relative per element), s and r to bf16
+    inside the backward (each a sum's operand: the errors average out over the nodes) - a wrong term, a dropped edge or
+    a misplaced column would show as O(1e-1).  Bounds, as fractions of each tensor's largest entry (measured on the five
+    shapes in brackets): y 4e-3 [2.6-3.0e-3], dx 5e-3 [2.5-3.7e-3], dW0 3e-3 [2.0-2.4e-3], db 1e-5 [1e-7], du / dv 6e-3
+    [2.4-4.2e-3: da | dg travel as bf16 behind the r row], dc 1e-2 [1.4-6.6e-3: a sum over all edges of signed d-logits that
+    cancel per edge].  The end-to-end comparisons in this file keep their 10x looser bounds for STORAGE error."""
+    from facet_graph_convolution_amd.graph import FacetGraph
+    from oracle import model_ref as R
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(11)
+    n = 2048
+    adj = np.zeros((n, 23), dtype=np.int32)
+    for i in range(n):
+        deg = rs.randint(3, 13)
+        adj[i, 0] = i + 1
+        adj[i, 1:1 + deg] = rs.randint(max(1, i - 60), min(n, i + 60) + 1, size=deg)
+    g = FacetGraph(adj, dev)
+    rows = n // 4 if mode == "upsample" else n
+    widths = [cin // 2, cin // 2] if mode == "concat" else [cin]
+    xs = [torch.tensor(rs.normal(size=(rows, w)).astype(np.float32)).to(torch.bfloat16) for w in widths]
+    dy = torch.tensor(rs.normal(size=(n, cout)).astype(np.float32)).to(torch.bfloat16)
+    p = R.conv_params(cin, cout, 21)
+    p[0] = p[0].to(torch.bfloat16).float()       # the kernels pack W0 as a bf16 MFMA operand: exact for these values
+    xd = [t.to(dev).contiguous() for t in xs]
+    y, dx0, dx1, grads = _bf16_conv_fwd_bwd(g, xd[0], xd[1] if len(xd) > 1 else None, 2 if mode == "upsample" else 0,
+                                            [t.to(dev) for t in p], dy.to(dev).contiguous(), act=1)
+    # float64 oracle on the rounded operands
+    X = [t.double().requires_grad_(True) for t in xs]
+    P = [t.double().requires_grad_(True) for t in p]
+    xin = torch.cat(X, 1)[None]
+    if mode == "upsample":
+        xin = R.custom_upsampling(xin, 2)
+    pre = R.custom_conv2d(xin, torch.tensor(adj[None]), P)[0]
+    yref = torch.where(pre > 0, pre, 0.1 * pre)
+    ygpu = y.cpu().double()
+    e_y = (ygpu - yref.detach()).abs().max().item() / yref.abs().max().item()
+    # the backward kernels take lrelu'(y) from the stored (bf16) y: give the oracle the same slopes
+    slope = torch.where(ygpu > 0, torch.ones_like(ygpu), torch.full_like(ygpu, 0.1))
+    (pre * slope * dy.double()).sum().backward()
+    errs = {"y": e_y}
+    for name, got, ref in [("dx0", dx0, X[0].grad)] + ([("dx1", dx1, X[1].grad)] if dx1 is not None else []) + \
+            list(zip(["dW0", "db", "du", "dc", "dv"], grads, [t.grad for t in P])):
+        errs[name] = (got.cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+    print("%s %d->%d: %s" % (mode, cin, cout, ", ".join("%s %.1e" % kv for kv in errs.items())))
+    bound = {"y": 4e-3, "dx0": 5e-3, "dx1": 5e-3, "dW0": 3e-3, "db": 1e-5, "du": 6e-3, "dv": 6e-3, "dc": 1e-2}
+    for k, v in errs.items():
+        assert v < bound[k], (k, errs)

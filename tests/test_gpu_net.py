@@ -146,10 +146,10 @@ def test_facet_sharded_step_matches_single_gpu(golden_dir, tag, world):
             assert np.abs(a - b).max() / scale < 1e-3, "grad %d" % i
 
 
-def _run_ranks(nproc, backend, port):
+def _run_ranks(nproc, backend, port, **extra_env):
     import subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FGC_TOOL_BACKEND=backend, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, FGC_TOOL_BACKEND=backend, MASTER_ADDR="127.0.0.1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "tools", "shard_gloo_2proc.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -160,6 +160,14 @@ def test_two_process_sharded_step_over_gloo():
     """One process per shard (two of them on this one GPU), exchanges through torch.distributed: the same DistComm a
     multi-GPU run uses, host-staged because RCCL wants one device per rank."""
     _run_ranks(2, "gloo", 29631)
+
+
+@pytest.mark.parametrize("min_tiles", ["0", "8"])
+def test_two_process_split_schedule_over_gloo(min_tiles):
+    """The same two processes with the interior / boundary split forced (FGC_SPLIT_MIN_TILES): exchange_begin / finish
+    of the real DistComm round every big layer, eager and replayed from hipGraph segments, all 44 gradients against the
+    unsharded network."""
+    _run_ranks(2, "gloo", 29633 + int(min_tiles), FGC_SPLIT_MIN_TILES=min_tiles)
 
 
 def test_rccl_code_path_world_of_one():

@@ -1,0 +1,228 @@
+"""The facet-sharded SCHEDULE the multi-GPU benchmark runs, held against the unsharded network.
+
+At 100k facets per rank every big layer takes the interior / boundary split with an overlapped exchange
+(net.py: `split_min_tiles`, FGC_SPLIT_MIN_TILES, default 1024 interior tiles): interior tiles (and the logit rows of
+owned sources) while the halo rows travel, the boundary tiles after the wait; backward the same with the data-gradient
+kernel.  The fixtures' meshes have a few dozen tiles per shard and never reach that branch on their own, so here it is
+(a) forced onto them (FGC_SPLIT_MIN_TILES = 0 and 8), eager and replayed from hipGraph segments, fp32 and bf16, regular
+and irregular meshes; (b) reached naturally: a 200k-facet torus in 2 shards; (c) run at the sizes of BASELINE configs 4 and
+5: the 1M-facet torus and the 500k-facet multi-scale forward as 8 shards in one process, inside guard zones.
+
+`shard.sim_run` delivers an overlapped exchange only at the shard's wait and keeps NaN in the halo tails until then: a
+kernel of the overlapped stretch that lets a halo row reach a result cannot pass."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _prep(golden_dir, tag):
+    prep = np.load(os.path.join(golden_dir, "prep_%s.npz" % tag))
+    return prep["x"], [prep["adj0"], prep["adj1"], prep["adj2"]], prep["gt"]
+
+
+def _mesh(nu, nv, flips=0, seed=0):
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import torus, add_noise, flip_edges
+    V, F = torus(nu, nv)
+    if flips:
+        F = flip_edges(F, flips, seed=1)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F, 0.2, seed=1 + seed), F, V, seed=seed)
+    return ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+
+
+def _took_the_split_branch(nets):
+    """(forward layers, backward layers) of shard 0 that run interior | exchange | boundary."""
+    n = nets[0]
+    g = n._mesh["graphs"]
+    fwd = sum(1 for lay in n.layers[1:] if g[lay.level].tiles["tiles_int"][1] >= n.split_min_tiles)
+    bwd = sum(1 for lay in n.layers[1:] if g[lay.level].tiles["ttiles_int"][1] >= n.split_min_tiles)
+    return fwd, bwd
+
+
+def _compare(ref, nets, tol_n, tol_loss, tol_g):
+    torch.cuda.synchronize()
+    full = ref.buffers["nconv"].cpu().numpy()
+    assert np.isfinite(full).all()
+    worst = 0.0
+    for n in nets:
+        P = n._mesh["plan"].levels[0]
+        got = n.buffers["nconv"].cpu().numpy()
+        assert np.isfinite(got).all(), "NaN reached the output: a kernel of an overlapped stretch read a halo row"
+        np.testing.assert_allclose(got, full[P.lo:P.hi], rtol=0, atol=tol_n)
+        assert abs(n.buffers["loss"][0].item() - ref.buffers["loss"][0].item()) < tol_loss * max(1.0, abs(ref.buffers["loss"][0].item()))
+        assert torch.equal(n.params.grad, nets[0].params.grad), "ranks hold different all-reduced gradients"
+    for i, (g, gr) in enumerate(zip(nets[0].params.grads, ref.params.grads)):
+        a, b = g.cpu().numpy(), gr.cpu().numpy()
+        assert np.isfinite(a).all(), "grad %d" % i
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)
+        worst = max(worst, err)
+        assert err < tol_g, "grad %d: rel err %.3e" % (i, err)
+    return worst
+
+
+def _step_pair(x, adjs, gt, world, dtype, samp, R):
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.shard import make_sim_shards
+    ref = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
+    nets = make_sim_shards(x, adjs, gt, world, "cuda:0", 0, dtype=dtype)
+    for n in [ref] + nets:
+        n.set_rotation(R)
+        n.set_samples(samp)
+    ref.forward_backward(rotate=True)
+    return ref, nets
+
+
+TOL = {"f32": (1e-6, 1e-4, 1e-3), "bf16": (1e-5, 1e-3, 1e-2)}     # test_gpu_net.py / test_gpu_bf16.py: sharded vs unsharded
+
+
+def _eager_then_segments(ref, nets, dtype):
+    from facet_graph_convolution_amd.shard import sim_forward_backward, sim_forward_backward_captured
+    sim_forward_backward(nets, rotate=True)
+    worst = _compare(ref, nets, *TOL[dtype])
+    eager = [n.params.grad.clone() for n in nets]
+    for _ in range(2):
+        sim_forward_backward_captured(nets, rotate=True)
+    _compare(ref, nets, *TOL[dtype])
+    for n, g in zip(nets, eager):
+        assert torch.equal(n.params.grad, g), "hipGraph segments differ from the eager schedule"
+    return worst
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag,world", [("ico3", 2), ("torus640", 3)])
+def test_split_schedule_with_empty_interiors(golden_dir, tag, world, dtype, monkeypatch):
+    """The fixture meshes keep the reference's node order (not the Morton order of the native preprocessing): every tile
+    of a shard touches its halo.  Threshold 0 forces the split anyway: an EMPTY interior call (logits of the owned rows
+    only), every tile after the wait; eager and replayed from hipGraph segments."""
+    monkeypatch.setenv("FGC_SPLIT_MIN_TILES", "0")
+    x, adjs, gt = _prep(golden_dir, tag)
+    z = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
+    ref, nets = _step_pair(x, adjs, gt, world, dtype, z["sample_ind"], z["R"])
+    assert nets[0].split_min_tiles == 0 and _took_the_split_branch(nets) == (7, 7)
+    assert nets[0]._mesh["graphs"][0].tiles["tiles_int"][1] == 0
+    _eager_then_segments(ref, nets, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("nu,nv,world,min_tiles", [(64, 48, 2, "0"), (64, 48, 4, "8"), (96, 64, 3, "8")])
+def test_forced_split_schedule_matches_the_unsharded_network(nu, nv, world, min_tiles, dtype, monkeypatch):
+    """Natively preprocessed tori (Morton order: 20-100 interior tiles per shard at level 0, a dozen at level 1).
+    Threshold 0: every layer splits.  Threshold 8: level 0 splits, level 1 splits on SOME shards only (12 / 4 / 13
+    interior tiles on the three shards of the 96 x 64 torus), level 2 blocks - shards overlap and block side by side."""
+    monkeypatch.setenv("FGC_SPLIT_MIN_TILES", min_tiles)
+    x, adjs, gt = _mesh(nu, nv, seed=0)
+    samp = np.random.RandomState(4).randint(x.shape[1], size=4000)
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    R = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    ref, nets = _step_pair(x, adjs, gt, world, dtype, samp, R)
+    took = [_took_the_split_branch([n]) for n in nets]
+    assert all(f >= 2 and b >= 2 for f, b in took), took
+    if (nu, world) == (96, 3):
+        assert len(set(took)) > 1, "the shards were meant to disagree on which layers split: %s" % took
+    assert nets[0]._mesh["graphs"][0].tiles["tiles_int"][1] >= 8
+    _eager_then_segments(ref, nets, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_forced_split_schedule_on_an_irregular_mesh(dtype, monkeypatch):
+    """Facet degrees up to K = 23 (24-slot kernels, the LONG d-logits form) under the split schedule, 3 shards."""
+    from facet_graph_convolution_amd.shard import sim_forward_backward
+    monkeypatch.setenv("FGC_SPLIT_MIN_TILES", "4")
+    # (900 flips: out-degrees up to 20, in-degrees up to 23 - the bf16 data-gradient kernel takes at most 24 in-edges)
+    x, adjs, gt = _mesh(48, 40, flips=900 if dtype == "bf16" else 1600, seed=0)
+    assert max(int((a[0] > 0).sum(1).max()) for a in adjs) > 16
+    samp = np.random.RandomState(4).randint(x.shape[1], size=4000)
+    ref, nets = _step_pair(x, adjs, gt, 3, dtype, samp, np.eye(3))
+    assert min(_took_the_split_branch(nets)) >= 1
+    sim_forward_backward(nets, rotate=True)
+    tol = TOL[dtype] if dtype == "f32" else (1e-5, 1e-3, 2e-2)    # (few rows per tensor: test_gpu_bf16.py's irregular bound)
+    _compare(ref, nets, *tol)
+
+
+def test_split_schedule_stays_inside_its_buffers(monkeypatch):
+    """Guard zones round every buffer of three shards under the forced split schedule (tile lists, packed exchange
+    buffers, halo tails), eager and hipGraph segments."""
+    from test_gpu_guard import _Guarded
+    from facet_graph_convolution_amd.shard import make_sim_shards, sim_forward_backward, sim_forward_backward_captured
+    monkeypatch.setenv("FGC_SPLIT_MIN_TILES", "8")
+    x, adjs, gt = _mesh(96, 64, seed=3)
+    with _Guarded() as g:
+        nets = make_sim_shards(x, adjs, gt, 3, "cuda:0", seed=0)
+        samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+        for n in nets:
+            n.set_rotation(np.eye(3))
+            n.set_samples(samp)
+        assert min(_took_the_split_branch(nets)) >= 1
+        sim_forward_backward(nets, rotate=True)
+        g.check("split schedule, eager")
+        for _ in range(2):
+            sim_forward_backward_captured(nets, rotate=True)
+        g.check("split schedule, hipGraph segments")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_200k_facets_in_two_shards_reach_the_split_branch_on_their_own(dtype):
+    """The benchmark's own shape (100k facets per rank, default threshold): the level-0 layers split, the coarse levels
+    block - forward, loss and all 44 gradients against the unsharded network, eager and hipGraph segments."""
+    assert "FGC_SPLIT_MIN_TILES" not in os.environ
+    x, adjs, gt = _mesh(500, 200, seed=0)
+    samp = np.random.RandomState(100).randint(x.shape[1], size=4000)
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    R = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    ref, nets = _step_pair(x, adjs, gt, 2, dtype, samp, R)
+    assert nets[0].split_min_tiles == 1024
+    fwd, bwd = _took_the_split_branch(nets)
+    assert fwd == 2 and bwd == 2, (fwd, bwd)          # upconv1, dconv1 (conv1 has no producer to wait for; backward: no exchange)
+    worst = _eager_then_segments(ref, nets, dtype)
+    print("200k facets, 2 shards, %s: worst rel gradient difference to the unsharded network %.2e" % (dtype, worst))
+
+
+def test_config4_one_million_facets_in_eight_shards():
+    """BASELINE config 4 at its own size: the 1 000 000-facet torus (1000 x 500) as 8 shards against the unsharded
+    network - unit normals within 1e-6, loss 1e-4, every gradient within 1e-3 of its tensor's largest entry - with every
+    buffer of the nine networks between guard zones."""
+    from test_gpu_guard import _Guarded
+    from facet_graph_convolution_amd.shard import sim_forward_backward
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    x, adjs, gt = _mesh(1000, 500, seed=0)
+    assert (np.abs(gt[0]).sum(1) > 1e-3).sum() == 1000000
+    samp = np.random.RandomState(100).randint(x.shape[1], size=4000)
+    R = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    with _Guarded() as g:
+        ref, nets = _step_pair(x, adjs, gt, 8, "f32", samp, R)
+        fwd, bwd = _took_the_split_branch(nets)
+        assert fwd >= 2 and bwd >= 2, (fwd, bwd)
+        sim_forward_backward(nets, rotate=True)
+        worst = _compare(ref, nets, 1e-6, 1e-4, 1e-3)
+        g.check("1M facets, 8 shards")
+    halo = [nets[0]._mesh["nh"][l] / nets[0]._mesh["ns"][l] for l in range(3)]
+    print("1M facets, 8 shards: worst rel gradient difference %.2e; halo / owned rows on shard 0: %s" % (
+        worst, ", ".join("%.3f" % h for h in halo)))
+
+
+def test_config5_multiscale_500k_facets_in_eight_shards():
+    """BASELINE config 5 at its own size: the multi-scale denoising forward (three heads, each through normalizeTensor)
+    of the 500 000-facet torus as 8 shards against the unsharded network, inside guard zones."""
+    from test_gpu_guard import _Guarded
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.shard import make_sim_shards, sim_forward_multi_scale
+    x, adjs, gt = _mesh(500, 500, seed=0)
+    with _Guarded() as g:
+        ref = FacetDenoiser("cuda:0", seed=0, multi_scale=True).bind_mesh(x, adjs)
+        outs = [t.cpu().numpy() for t in ref.forward_multi_scale()]
+        nets = make_sim_shards(x, adjs, None, 8, "cuda:0", seed=0, multi_scale=True)
+        assert _took_the_split_branch(nets)[0] >= 2
+        sim_forward_multi_scale(nets)
+        torch.cuda.synchronize()
+        for n in nets:
+            for lvl, (key, full) in enumerate(zip(("nconv", "nconv1", "nconv2"), outs)):
+                P = n._mesh["plan"].levels[lvl]
+                got = n.buffers[key].cpu().numpy()
+                assert np.isfinite(got).all()
+                np.testing.assert_allclose(got, full[P.lo:P.hi], rtol=0, atol=1e-6, err_msg="head of level %d" % lvl)
+        g.check("500k facets multi-scale, 8 shards")

@@ -15,7 +15,7 @@ def _graphs(golden_dir, tag="ico3"):
     return [csr_from_klist(z["adj%d" % l]) for l in range(3)], z
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_plan_is_consistent(golden_dir, world):
     gh, _ = _graphs(golden_dir)
     plans = [ShardPlan(gh, r, world) for r in range(world)]
@@ -117,16 +117,91 @@ def _worker(rank, world, port, golden_dir, out):
         dist.destroy_process_group()
 
 
-def test_gloo_world2_halo_exchange(golden_dir):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_halo_exchange(golden_dir, world):
+    """World 2, and world 8 = the rank count of the driver's scaling run (8 processes over gloo on the CPU)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=240)
         assert p.exitcode == 0
-    res = dict(q.get(timeout=5) for _ in range(2))
-    assert res == {0: True, 1: True}
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res == {r: True for r in range(world)}
+
+
+def test_a_rank_without_a_halo_still_issues_the_collective():
+    """Whether to call a collective is never a rank-local decision (a shard whose level has no halo - a disconnected
+    component - would otherwise skip an all-to-all its peers issue).  Only a world of one skips."""
+    from facet_graph_convolution_amd.shard import DistComm
+
+    class FakeDist:
+        def __init__(self):
+            self.calls = 0
+
+        def all_to_all_single(self, recv, send, rs, ss, group=None, async_op=False):
+            self.calls += 1
+            return "work"
+
+    for world, expect in ((1, 0), (2, 1), (8, 1)):
+        c = DistComm.__new__(DistComm)
+        c.dist, c.group, c.world, c.rank, c.host_staged = FakeDist(), None, world, 0, False
+        out = c.all_to_all_flat(torch.empty(0), [0] * world, torch.empty(0), [0] * world, async_op=True)
+        assert c.dist.calls == expect and (out == "work") == bool(expect)
+
+
+def test_sim_run_serves_waits_per_rank_and_delivers_at_the_wait():
+    """shard.sim_run: ranks may disagree on WHERE they wait (one overlaps, its peer blocks), not on the collectives; an
+    overlapped exchange lands at the wait and its destination rows are NaN until then."""
+    from facet_graph_convolution_amd import shard
+
+    class FakePx:
+        def __init__(self, log, name):
+            self.log, self.name = log, name
+            self.send_splits = self.recv_splits = [0, 0]
+            self.send_buf = self.recv_buf = torch.zeros(0)
+
+        def pack(self):
+            self.log.append((self.name, "pack"))
+
+        def unpack(self):
+            self.log.append((self.name, "unpack"))
+
+        def poison_tails(self):
+            self.log.append((self.name, "poison"))
+
+    log = []
+
+    class FakeNet:
+        def __init__(self, name):
+            self.px = FakePx(log, name)
+
+        def _packed(self, req):
+            return self.px
+
+    def overlapping(net):
+        yield ("xchg", [], "k")
+        log.append((net.px.name, "interior"))
+        yield ("wait", "k")
+        log.append((net.px.name, "boundary"))
+
+    def blocking(net):
+        yield ("xchg", [], None)
+        log.append((net.px.name, "whole"))
+
+    nets = [FakeNet("a"), FakeNet("b")]
+    gens = {"a": overlapping, "b": blocking}
+    shard.sim_run(nets, lambda n: gens[n.px.name](n))
+    a = [e for n, e in log if n == "a"]
+    b = [e for n, e in log if n == "b"]
+    assert a == ["pack", "poison", "interior", "unpack", "boundary"] and b == ["pack", "unpack", "whole"]
+
+    def never_waits(net):
+        yield ("xchg", [], "k")
+
+    with pytest.raises(AssertionError):
+        shard.sim_run([FakeNet("a")], never_waits)

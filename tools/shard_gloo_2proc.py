@@ -40,5 +40,10 @@ if rank == 0:
     ref.set_samples(samp); ref.set_rotation(np.eye(3)); ref.forward_backward(rotate=True); torch.cuda.synchronize()
     print("sharded loss %.6f |g| %.6f  vs single %.6f |g| %.6f" % (loss, gn, ref.buffers["loss"][0].item(), ref.params.grad.norm().item()))
     assert abs(loss - ref.buffers["loss"][0].item()) < 1e-3 and abs(gn - ref.params.grad.norm().item()) < 1e-3 * gn
+    for i, (a, b) in enumerate(zip(net.params.grads, ref.params.grads)):
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-3)
+        assert err < 1e-3, "grad %d differs from the unsharded network: %.3e" % (i, err)
+    g = net._mesh["graphs"]
+    print("split threshold %d: interior tiles per level %s" % (net.split_min_tiles, [g[l].tiles["tiles_int"][1] for l in range(3)]))
     print("OK")
 dist.destroy_process_group()
