@@ -220,17 +220,20 @@ def physical_cores():
     return len(seen) or (os.cpu_count() or 1)
 
 
-def cpu_baseline(sample_faces=(140, 140), full=(250, 200)):
-    """The oracle timed on this host (bounded: about 30 s of CPU work, so that the default bench run stays within
-    minutes): (1) one forward+backward of the reference-shaped torch-CPU restatement on a 39 200-facet torus - the
-    backward of the full 100k mesh keeps the materialised [N0,23,288] tensors of every layer alive and does not fit
-    in 62 GB; (2) one forward on the full 100 000-facet mesh of the headline."""
+def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
+    """The oracle timed on this host as BASELINE.md section 3 prescribes, on a BOUNDED sample (about 30 s of CPU work in
+    all, so that the default bench run stays within minutes): the reference-shaped torch-CPU restatement
+    (oracle/model_ref.py: zero-row pad -> K-padded gather -> per-edge softmax -> multiply -> reduce) on a 7 200-facet
+    torus of the same family as the headline mesh, same seeds and weights as the GPU run -
+      * forward + backward and forward only, 2 warm-ups then the median of 5 runs, torch threads = all cores in the
+        affinity mask (`value`, `forward`);
+      * the same with 32 threads (1 warm-up, median of 3): on the 128-core boxes the K-padded ops stop scaling there;
+      * ONE forward on the full 100 000-facet headline mesh (its backward keeps the materialised [N0,23,288] tensors of
+        every layer alive and does not fit in host memory)."""
     import torch
     from oracle import model_ref as R
     logical = os.cpu_count() or 1
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
-    threads = min(affinity, 32)   # more threads than this only add contention on these op sizes
-    torch.set_num_threads(threads)
 
     def tensors(nu, nv):
         ds, F = build_mesh(nu, nv, seed=7)
@@ -241,30 +244,97 @@ def cpu_baseline(sample_faces=(140, 140), full=(250, 200)):
 
     x, gt, adjs, F = tensors(*sample_faces)
     params = [p.requires_grad_(True) for p in R.init_params(0)]
+    plain = [p.detach() for p in params]
     samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
-    t0 = time.time()
-    loss, _ = R.train_loss(x, adjs, gt, params, samp, torch.eye(3))
-    loss.backward()
-    dt = time.time() - t0
-    out = {"value": F / dt, "unit": "facets/s", "cores": threads, "kind": "port",
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        t0 = time.perf_counter()
+        loss, _ = R.train_loss(x, adjs, gt, params, samp, torch.eye(3))
+        loss.backward()
+        return time.perf_counter() - t0
+
+    def fwd():
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            R.normalizeTensor(R.get_model_reg_multi_scale(x, adjs, plain))
+            return time.perf_counter() - t0
+
+    def timed(fn, threads, warm, runs):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            fn()
+        ts = sorted(fn() for _ in range(runs))
+        return ts[len(ts) // 2], ts
+
+    t_all0 = time.perf_counter()
+    fb_all, fb_all_ts = timed(fwd_bwd, affinity, 2, 5)
+    f_all, _ = timed(fwd, affinity, 2, 5)
+    t32 = min(affinity, 32)
+    if t32 == affinity:     # a host of 32 cores or fewer: the two thread counts are the same measurement
+        fb_32, f_32 = fb_all, f_all
+    else:
+        fb_32, _ = timed(fwd_bwd, t32, 1, 3)
+        f_32, _ = timed(fwd, t32, 1, 3)
+    best_threads, fb_best = (affinity, fb_all) if fb_all <= fb_32 else (t32, fb_32)
+    out = {"value": F / fb_best, "unit": "facets/s", "cores": best_threads, "kind": "port",
            "cpu_model": cpu_model(), "logical_cpus": logical, "physical_cores": physical_cores(),
            "cpus_in_affinity_mask": affinity,
-           "sample": "oracle/model_ref.py (reference-shaped K-padded torch CPU fp32), 1 forward+backward of the "
-                     "full net on a torus %dx%d = %d facets (N0=%d), %.1f s" % (sample_faces[0], sample_faces[1], F,
-                                                                                 x.shape[1], dt)}
-    del loss, x, gt, adjs
+           "forward_backward": {"all_cores": {"threads": affinity, "facets_per_s": F / fb_all,
+                                              "median_s": fb_all, "runs_s": [round(t, 3) for t in fb_all_ts]},
+                                "threads_32": {"threads": t32, "facets_per_s": F / fb_32, "median_s": fb_32}},
+           "forward": {"all_cores": {"threads": affinity, "facets_per_s": F / f_all, "median_s": f_all},
+                       "threads_32": {"threads": t32, "facets_per_s": F / f_32, "median_s": f_32}},
+           "sample": "oracle/model_ref.py (reference-shaped K-padded torch CPU fp32), full net on a torus %dx%d = %d facets "
+                     "(N0=%d): forward+backward and forward, 2 warm-ups + median of 5 at %d threads, 1 + median of 3 at %d "
+                     "threads; `value` = forward+backward at the faster thread count; %.0f s of CPU time in all" % (
+                         sample_faces[0], sample_faces[1], F, x.shape[1], affinity, t32, time.perf_counter() - t_all0)}
+    del x, gt, adjs
     if full:
+        torch.set_num_threads(best_threads)
         x, gt, adjs, F = tensors(*full)
         with torch.no_grad():
-            plain = [p.detach() for p in params]
-            t0 = time.time()
+            t0 = time.perf_counter()
             y = R.normalizeTensor(R.get_model_reg_multi_scale(x, adjs, plain))
-            dtf = time.time() - t0
-        out["forward_only_full_mesh"] = {"value": F / dtf, "unit": "facets/s",
-                                         "sample": "1 forward of the full net on the torus %dx%d = %d facets (N0=%d), %.1f s" %
-                                                   (full[0], full[1], F, x.shape[1], dtf)}
+            dtf = time.perf_counter() - t0
+        out["forward_only_full_mesh"] = {"value": F / dtf, "unit": "facets/s", "threads": best_threads,
+                                         "sample": "1 forward (not warmed) of the full net on the torus %dx%d = %d facets "
+                                                   "(N0=%d), %.1f s" % (full[0], full[1], F, x.shape[1], dtf)}
         del y
     return out
+
+
+def csrc_sha16():
+    """sha256 over the kernel sources (csrc/*.hip, *.h and include/fgc.h, sorted by name), first 16 hex digits: what a
+    PMC pass under profiles/ is valid for.  (.git does not travel to the GPU box; file contents do.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "facet_graph_convolution_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + \
+            [os.path.join(REPO, "include", "fgc.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic_db(dtype, nu, nv):
+    """PMC traffic (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes; tools/pmc_traffic.sh) of the newest
+    pass kept under profiles/ - used only when it was taken on THIS build's kernel sources and on this workload.
+    Returns (db, note)."""
+    import glob
+    suffix = "_bf16" if dtype == "bf16" else ""
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic_families%s.json" % suffix)), reverse=True)
+    if not cands or (nu, nv) != (250, 200):
+        return {}, "no PMC pass recorded for this workload"
+    db = json.load(open(cands[0]))
+    meta = db.get("meta", {})
+    have = meta.get("csrc_sha16")
+    if have != csrc_sha16():
+        return {}, "stale: %s was taken on kernel sources %s (commit %s), this build is %s - rerun tools/pmc_traffic.sh" % (
+            os.path.basename(cands[0]), have, meta.get("commit"), csrc_sha16())
+    return db, "%s (commit %s, kernel sources %s)" % (os.path.basename(cands[0]), meta.get("commit"), have)
 
 
 # kernel name -> family (the kernel FUNCTION, all template instances and both directions of the shared core together)
@@ -316,13 +386,20 @@ def main(argv=None):
     train = args.what == "train"
     shard = world > 1 and args.mode == "shard"
     mk = dict(seed=0, multi_scale=args.multi_scale, dtype=args.dtype)
+    startup = {}
+    t_start = time.perf_counter()
     if shard:
         from facet_graph_convolution_amd.shard import ShardPlan, DistComm, graphs_to_host_csr
         nu = args.nu * world if args.scaling == "weak" else args.nu
         ds, F_total = build_mesh(nu, args.nv, seed=0)          # every rank builds the same mesh (seeded)
+        startup["preprocess_s"] = time.perf_counter() - t_start
+        t1 = time.perf_counter()
         plan = ShardPlan(graphs_to_host_csr(ds.adj_list[0]), rank, world)
+        startup["shard_plan_s"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
         net = FacetDenoiser(dev, **mk).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0] if train else None,
                                                  plan=plan, comm=DistComm())
+        startup["bind_s"] = time.perf_counter() - t1
         n0 = ds.in_list[0].shape[1]            # samples are drawn over the WHOLE mesh, same stream on every rank
         rs = np.random.RandomState(100)
         F = F_total / world                    # facets per GPU (for the per-GPU accounting below)
@@ -330,8 +407,11 @@ def main(argv=None):
     else:
         nu = args.nu
         ds, F = build_mesh(args.nu, args.nv, seed=rank)
+        startup["preprocess_s"] = time.perf_counter() - t_start
         F_total = F * world
+        t1 = time.perf_counter()
         net = FacetDenoiser(dev, **mk).bind_mesh(ds.in_list[0], ds.adj_list[0], gt=ds.gt_list[0] if train else None)
+        startup["bind_s"] = time.perf_counter() - t1
         n0 = ds.in_list[0].shape[1]
         rs = np.random.RandomState(100 + rank)
         halo_frac = None
@@ -464,12 +544,16 @@ def main(argv=None):
     families = None
     kernels = {}
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    if not args.no_roofline and not shard and train:
+    traffic_note = None
+    if not args.no_roofline and train and (shard or world == 1):
         # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
-        # `steps` eager steps of the same work as the timed region
+        # `steps` eager steps of the same work as the timed region.  Facet-sharded: every rank runs the steps (they hold
+        # collectives), rank 0's table is the one reported; a layer that runs as interior | exchange | boundary launches
+        # counts with the SUM of its launches
         net.profile_start()
         for k in range(args.steps):
-            net.set_step_inputs_device(S_all[k % nsteps_total], R_all[k % nsteps_total])
+            kk = k % nsteps_total
+            net.set_step_inputs_device(S_all[kk], R_all[kk], S_loc[kk] if S_loc else None)
             net.forward_backward(rotate=True, capture=False)
             net.adam_step()
         prof = net.profile_stop()
@@ -491,6 +575,8 @@ def main(argv=None):
                 elif "gemm_tn" in kern and cnt == args.steps:
                     kind = "bwd_weight"
             avg_us = ms / cnt * 1e3
+            if kind in ("fwd", "bwd_data") and cnt > args.steps and cnt % args.steps == 0:
+                avg_us = ms / args.steps * 1e3        # interior + boundary launches of one layer: their sum
             fl = kernel_flops(kind, *dims[layer]) if kind else None
             by = kernel_bytes(kind, layer, *dims[layer], 2 if args.dtype == "bf16" else 4) if kind else None
             if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern):
@@ -514,10 +600,8 @@ def main(argv=None):
         # families = kernel FUNCTIONS (conv_w8 forward and data-gradient are the same kernel over the graph and its
         # transpose); HBM bytes per launch of each family's reported launch from the PMC passes kept under profiles/
         # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md); null when no pass is recorded
-        traffic_db = {}
-        tpath = os.path.join(REPO, "profiles", "r2_traffic_families%s.json" % ("_bf16" if args.dtype == "bf16" else ""))
-        if os.path.exists(tpath) and args.nu == 250 and args.nv == 200:
-            traffic_db = json.load(open(tpath))
+        traffic_db, traffic_note = ({}, "PMC passes are taken on the single-GPU run") if shard else \
+            load_traffic_db(args.dtype, args.nu, args.nv)
         fam = {}
         for ms, key, cnt, avg_us, fl in rows:
             f = fam.setdefault(family_of(key.split("/", 1)[1]), {"ms": 0.0, "flop": 0.0, "rows": []})
@@ -553,7 +637,8 @@ def main(argv=None):
                         "mfma_tflops": d["achieved"], "mfma_frac": d["frac"],
                         "family_share_of_step": d["share_of_step"],
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
-                        "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step")}
+                        "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
+                        "traffic_source": traffic_note}
         elif families:
             d = families[0]
             roofline = {"bound": "mfma", "kernel": d["kernel"], "family": d["family"], "achieved": d["achieved"],
@@ -561,8 +646,17 @@ def main(argv=None):
                         "avg_kernel_us": d["avg_kernel_us"], "launch_flops": d["launch_flops"],
                         "family_share_of_step": d["share_of_step"], "family_frac": d["family_frac"],
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
-                        "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step")}
+                        "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
+                        "traffic_source": traffic_note,
+                        "launches_per_step": round(sum(c for c, _ in prof.values()) / args.steps, 1)}
 
+    # the world as the collective back end itself counts it: every rank contributes a one to an all-reduce
+    world_check = None
+    if world > 1:
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        world_check = {"backend": "RCCL" if backend == "nccl" else backend, "ranks_in_all_reduce": int(one.item()),
+                       "get_world_size": dist.get_world_size()}
     fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net, elem=2 if args.dtype == "bf16" else 4)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -602,6 +696,8 @@ def main(argv=None):
                                        "1 mesh per GPU, flat-gradient all-reduce (%s world size %d)" % (
                                            "RCCL" if backend == "nccl" else backend, dist.get_world_size()))},
             "loss_deg": loss,
+            "startup_s": {k: round(v, 2) for k, v in startup.items()},
+            "world_check": world_check,
             "repeats_ms_per_step": [round(v, 4) for v in rep_ms],
             "ms_per_step_min": min(rep_ms),
             "ms_per_step_median": float(np.median(rep_ms)),

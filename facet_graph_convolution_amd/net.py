@@ -832,19 +832,21 @@ class FacetDenoiser:
         step, their summed time and bytes sent by this rank.  Diagnostic only: never inside a timed region."""
         import time
         comm = self.comm
-        stats = {"n": 0, "s": 0.0, "bytes": 0}
+        stats = {"n": 0, "s": 0.0, "bytes": 0, "each": []}
 
         class Timed:
             world, rank, host_staged = comm.world, comm.rank, comm.host_staged
 
-            def _t(self, fn, nbytes):
+            def _t(self, fn, nbytes, kind="all_to_all"):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 fn()
                 torch.cuda.synchronize()
-                stats["s"] += time.perf_counter() - t0
+                dt = time.perf_counter() - t0
+                stats["s"] += dt
                 stats["n"] += 1
                 stats["bytes"] += nbytes
+                stats["each"].append((kind, nbytes, dt))
 
             def exchange(self, px):
                 self._t(lambda: comm.exchange(px), px.send_buf.numel() * 4)
@@ -857,7 +859,7 @@ class FacetDenoiser:
                 pass
 
             def all_reduce_sum(self, t):
-                self._t(lambda: comm.all_reduce_sum(t), t.numel() * t.element_size())
+                self._t(lambda: comm.all_reduce_sum(t), t.numel() * t.element_size(), "all_reduce")
 
         self.comm = Timed()
         try:
@@ -866,8 +868,13 @@ class FacetDenoiser:
             torch.cuda.synchronize()
         finally:
             self.comm = comm
-        return {"collectives_per_step": stats["n"] // steps, "blocking_ms_per_step": stats["s"] / steps * 1e3,
-                "bytes_sent_per_step": stats["bytes"] // steps}
+        per = stats["n"] // steps
+        # the step's collectives in schedule order (pack + collective + unpack, blocking), averaged over the steps
+        each = [{"kind": stats["each"][i][0], "bytes_sent": stats["each"][i][1],
+                 "ms": round(sum(stats["each"][i + k * per][2] for k in range(steps)) / steps * 1e3, 4)}
+                for i in range(per)] if per * steps == stats["n"] else None
+        return {"collectives_per_step": per, "blocking_ms_per_step": stats["s"] / steps * 1e3,
+                "bytes_sent_per_step": stats["bytes"] // steps, "per_collective": each}
 
     def forward_backward(self, rotate=True, capture=False):
         """One forward + backward (train.py:492-520 without the optimiser); loss in buffers['loss'][0]."""

@@ -35,6 +35,9 @@ def test_single_gpu_line_has_the_contract_fields_and_family_rooflines():
     fams = [f["family"] for f in j["families"]]
     assert len(fams) == 3 and "conv_w8" in fams and j["roofline"]["family"] == fams[0]
     assert 0 < j["roofline"]["frac"] < 1 and len(j["repeats_ms_per_step"]) == 2
+    # PMC traffic is quoted only from a pass taken on THIS build's kernel sources and on the 250 x 200 workload
+    assert j["roofline"]["traffic"] is None and j["roofline"]["traffic_source"]
+    assert j["roofline"]["launches_per_step"] > 20 and j["startup_s"]["preprocess_s"] > 0 and j["world_check"] is None
 
 
 def test_two_ranks_from_a_plain_shell_over_gloo():
@@ -44,6 +47,15 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert "facet-sharded over 2 GPUs" in j["config"]["parallelism"] and "world size 2" in j["config"]["parallelism"]
     assert j["exchange"]["collectives_per_step"] > 0 and j["exchange"]["bytes_sent_per_step"] > 0
     assert 0 < j["loss_deg"] < 180
+    # the N > 1 line is complete: rank 0's hipEvent roofline (a split layer counts with the sum of its launches), the
+    # step's collectives one by one, start-up times, and the world as the back end's own all-reduce counts it
+    assert j["roofline"] is not None and 0 < j["roofline"]["frac"] < 1 and len(j["families"]) == 3
+    assert j["cpu_baseline"] is None                  # (the contract times the CPU on rank 0 at N = 1 only)
+    per = j["exchange"]["per_collective"]
+    assert len(per) == j["exchange"]["collectives_per_step"] == 17
+    assert [c["kind"] for c in per].count("all_reduce") == 3 and all(c["ms"] > 0 for c in per)
+    assert j["world_check"] == {"backend": "gloo", "ranks_in_all_reduce": 2, "get_world_size": 2}
+    assert set(j["startup_s"]) == {"preprocess_s", "shard_plan_s", "bind_s"}
     # the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
     assert j["hipgraph_replay"]["graphs_per_step"] > 17 and j["hipgraph_replay"]["eager_ms_per_step"] > 0
     assert j["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in j["config"]["parallelism"]

@@ -93,10 +93,12 @@ def main():
     out["method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes of tools/pmc_steps.py %d "
                      "(torus 250x200, 100000 facets, forward+backward+Adam); values of the last step; hbm = 2 x FETCH_SIZE "
                      "(gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; counter values are KB" % steps)
-    if len(sys.argv) > 5:
-        out["commit"] = sys.argv[5]
-    if len(sys.argv) > 6:
-        out["command"] = sys.argv[6]
+    # what the pass is valid for: bench.py quotes these figures only while the kernel sources hash to the same value
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha16
+    out["meta"] = {"commit": sys.argv[5] if len(sys.argv) > 5 else None, "command": sys.argv[6] if len(sys.argv) > 6 else None,
+                   "csrc_sha16": csrc_sha16()}
     json.dump(out, open(outp, "w"), indent=1)
     ws = whole[-1]
     print("whole step: FETCH %.1f MB x2 + WRITE %.1f MB = %.1f MB over %d launches" % (

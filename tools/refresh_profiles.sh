@@ -1,19 +1,19 @@
 #!/bin/bash
 # Developer helper (GPU box): regenerate every measurement file of a round at one commit.
-# usage: tools/refresh_profiles.sh <tag> <commit> [first-stage]  ->  gpurun_out/refresh/<tag>_*  (copy what should be judged
+# usage: tools/refresh_profiles.sh <tag> <commit> [first-stage] [round prefix, default r3]  ->  gpurun_out/refresh/<tag>_*  (copy what should be judged
 # into profiles/).  Stages: 1 traffic, 2 fp32 rocprof + default bench + agreement note, 3 bf16, 4 configs c3 / c4 / c5.
 # Steps: PMC traffic passes (fp32, bf16) -> profiles traffic files in place, so the bench lines after them carry this build's
 # `traffic`; rocprofv3 --kernel-trace --stats of the bench command; the default bench line; bf16, c3, c4, c5 lines.
-tag=$1; commit=${2:-unknown}; first=${3:-1}
+tag=$1; commit=${2:-unknown}; first=${3:-1}; rnd=${4:-r3}
 o=gpurun_out/refresh; rm -rf $o; mkdir -p $o
 export TMPDIR=/tmp
 set -e
 if [ $first -le 1 ]; then
 bash tools/pmc_traffic.sh f32 f32 $commit > $o/traffic_f32.log 2>&1
-cp gpurun_out/traffic_f32.json profiles/r2_traffic_families.json; cp gpurun_out/traffic_f32.txt profiles/r2_traffic_summary.txt
+cp gpurun_out/traffic_f32.json profiles/${rnd}_traffic_families.json; cp gpurun_out/traffic_f32.txt profiles/${rnd}_traffic_summary.txt
 bash tools/pmc_traffic.sh bf16 bf16 $commit > $o/traffic_bf16.log 2>&1
-cp gpurun_out/traffic_bf16.json profiles/r2_traffic_families_bf16.json; cp gpurun_out/traffic_bf16.txt profiles/r2_traffic_summary_bf16.txt
-cp profiles/r2_traffic_*.json profiles/r2_traffic_summary*.txt $o/
+cp gpurun_out/traffic_bf16.json profiles/${rnd}_traffic_families_bf16.json; cp gpurun_out/traffic_bf16.txt profiles/${rnd}_traffic_summary_bf16.txt
+cp profiles/${rnd}_traffic_*.json profiles/${rnd}_traffic_summary*.txt $o/
 echo "traffic done"
 fi
 if [ $first -le 2 ]; then
