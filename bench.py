@@ -423,8 +423,7 @@ def main(argv=None):
     nsteps_total = args.warmup + args.steps
     samp_host = [rs.randint(n0, size=4000) for _ in range(nsteps_total)]
     rot_host = [rand_rotation_matrix(randnums=rs.uniform(size=3)) for _ in range(nsteps_total)]
-    S_all = torch.from_numpy(np.stack(samp_host).astype(np.int32)).to(dev)
-    R_all = torch.from_numpy(np.stack(rot_host).astype(np.float32).reshape(nsteps_total, 9)).to(dev)
+    SR_all = FacetDenoiser.pack_step_inputs(samp_host, rot_host, dev)    # row k: samples + rotation of step k
     S_loc = [net.local_samples_device(s) for s in samp_host] if (shard and train) else None
     torch.cuda.synchronize()
     counter = [0]
@@ -439,7 +438,7 @@ def main(argv=None):
         if not train:
             net.forward_multi_scale() if args.multi_scale else net.forward(rotate=False)
             return
-        net.set_step_inputs_device(S_all[k], R_all[k], S_loc[k] if S_loc else None)
+        net.set_step_inputs_packed(SR_all[k], S_loc[k] if S_loc else None)
         net.forward_backward(rotate=True, capture=bool(args.graph) or graph_mode[0])
         if world > 1 and not shard:
             if backend == "nccl":
@@ -496,13 +495,13 @@ def main(argv=None):
 
         def walk(nn, capture):
             for k in range(args.warmup):
-                nn.set_step_inputs_device(S_all[k], R_all[k])
+                nn.set_step_inputs_packed(SR_all[k])
                 nn.forward_backward(rotate=True, capture=capture)
                 nn.adam_step()
             torch.cuda.synchronize()
             t = time.perf_counter()
             for k in range(args.warmup, nsteps_total):
-                nn.set_step_inputs_device(S_all[k], R_all[k])
+                nn.set_step_inputs_packed(SR_all[k])
                 nn.forward_backward(rotate=True, capture=capture)
                 nn.adam_step()
             torch.cuda.synchronize()
@@ -553,7 +552,7 @@ def main(argv=None):
         net.profile_start()
         for k in range(args.steps):
             kk = k % nsteps_total
-            net.set_step_inputs_device(S_all[kk], R_all[kk], S_loc[kk] if S_loc else None)
+            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None)
             net.forward_backward(rotate=True, capture=False)
             net.adam_step()
         prof = net.profile_stop()

@@ -81,6 +81,47 @@ __global__ void upsample4_bwd_kernel(const float* __restrict__ dy, float* __rest
     }
 }
 
+// the same four ops for any group size 2^steps (custom_binary_tree_pooling / custom_upsampling with steps != 2,
+// model.py:779-788,817-825): the operator API only - the network's 4:1 forms are fused into the conv kernels
+__global__ void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count, int c, int group) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const float* p = x + (r * group) * c + (int)(i % c);
+        float m = p[0];
+        for (int k = 1; k < group; ++k) m = fmaxf(m, p[(int64_t)k * c]);
+        y[i] = m;
+    }
+}
+__global__ void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                float* __restrict__ dx, int64_t count, int c, int group, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const int64_t b = (r * group) * c + (int)(i % c);
+        const float m = y[i];
+        float ne = 0.f;
+        for (int k = 0; k < group; ++k) ne += x[b + (int64_t)k * c] == m ? 1.f : 0.f;
+        const float g = dy[i] / ne;      // tf.reduce_max: the gradient is split evenly over the entries equal to the maximum
+        for (int k = 0; k < group; ++k) {
+            const int64_t o = b + (int64_t)k * c;
+            const float v = x[o] == m ? g : 0.f;
+            dx[o] = accumulate ? dx[o] + v : v;
+        }
+    }
+}
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count_out, int c, int group) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count_out; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[((i / c) / group) * c + i % c];
+}
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t count_in, int c, int group,
+                                    int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count_in; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* p = dy + ((i / c) * group) * c + (int)(i % c);
+        float v = 0.f;
+        for (int k = 0; k < group; ++k) v += p[(int64_t)k * c];
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
 // ---- block reduction helper (deterministic) ---------------------------------------------------
 __device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats LDS */) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -256,6 +297,123 @@ __global__ void angular_loss_bwd_kernel(const float* __restrict__ fn, const floa
     }
 }
 
+// ---- the loss end of a training step in two launches (fgc_loss_step) --------------------------------
+// normalize_fwd, the rotation of the ground truth, the sampled angular loss, its gradient and both stages of
+// normalize_bwd were seven launches of 5 ... 13 us each, every one waiting for the one before.  Only the SAMPLED rows
+// carry a loss, normalizeTensor's backward is linear in the incoming gradient, and the number of real samples enters
+// every gradient as one global factor, so:
+//   A (one workgroup per 256 samples, no communication between them): s = mean|y| + eps from the MLP's partials (every
+//     workgroup sums them itself, in the same order); per sample: normalised row, rotated ground truth, angle, and the
+//     gradient of the angle taken back through the row's normalisation - WITHOUT the 1 / (real samples) factor -
+//     scattered into `gacc` (rows of d xs; duplicates of a sample add identical values, so the order of the atomic
+//     adds does not matter); per workgroup one partial {sum of angles, real samples, sum(d xs . y)}
+//   B (all rows): every workgroup sums A's partials (fixed order) -> loss, real samples, ds; dy = gacc / (real s) +
+//     sign(y) ds / (3n), n_conv = the normalised rows; gacc is zero again afterwards
+// (One workgroup for all samples was the first version: its 12k scattered float atomics from ONE compute unit took 55 us.)
+constexpr int LOSS_SAMPLES_PER_BLOCK = 256;
+__device__ __forceinline__ void norm_row(const float* y3, float s, float (&a)[3], float& norm, float& inv) {
+    const float eps = 1e-5f;
+    a[0] = y3[0] / s;
+    a[1] = y3[1] / s;
+    a[2] = y3[2] / s;
+    norm = sqrtf(eps + (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]));
+    inv = norm > eps ? 1.0f / (norm + eps) : 0.f;
+}
+__global__ __launch_bounds__(LOSS_SAMPLES_PER_BLOCK) void loss_step_samples_kernel(
+    const float* __restrict__ y, float count, const float* __restrict__ part, int nparts, const float* __restrict__ gt,
+    const float* __restrict__ Rd, const int* __restrict__ idx, int ns, float* __restrict__ gacc,
+    float* __restrict__ scratch /* [2 + 3 * blocks] */) {
+    __shared__ float red[4];
+    const float close = 0.9999999f, eps = 1e-5f;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += LOSS_SAMPLES_PER_BLOCK) v += part[i];
+    const float s = block_sum(v, red) / count + 1e-5f;
+    const int sidx = blockIdx.x * LOSS_SAMPLES_PER_BLOCK + threadIdx.x;
+    float lsum = 0.f, rsum = 0.f, acc = 0.f;
+    if (sidx < ns) {
+        const int r = idx[sidx];
+        float g0[3], yr[3], g[3], a[3], norm, inv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g0[c] = gt[3 * (size_t)r + c];
+            yr[c] = y[3 * (size_t)r + c];
+        }
+        if (Rd) {
+            g[0] = Rd[0] * g0[0] + Rd[1] * g0[1] + Rd[2] * g0[2];
+            g[1] = Rd[3] * g0[0] + Rd[4] * g0[1] + Rd[5] * g0[2];
+            g[2] = Rd[6] * g0[0] + Rd[7] * g0[1] + Rd[8] * g0[2];
+        } else {
+            g[0] = g0[0]; g[1] = g0[1]; g[2] = g0[2];
+        }
+        norm_row(yr, s, a, norm, inv);
+        const float dt = (a[0] * inv) * g[0] + (a[1] * inv) * g[1] + (a[2] * inv) * g[2];
+        if ((fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2])) > 10e-4f) {     // a real row (train.py:1283-1292)
+            lsum = 180.f * acosf(fminf(fmaxf(dt, -close), close)) / 3.14159265358979323846f;
+            rsum = 1.f;
+            // (tf.minimum / maximum pass the gradient only while the cosine is strictly inside the clip)
+            if (!(dt > close || dt < -close) && norm > eps) {
+                const float kf = -(180.f / 3.14159265358979323846f) / sqrtf(1.f - dt * dt);
+                const float d[3] = {kf * g[0], kf * g[1], kf * g[2]};
+                const float dot = d[0] * a[0] + d[1] * a[1] + d[2] * a[2];
+                const float kk = dot * inv * inv / norm;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float gx = d[c] * inv - a[c] * kk;
+                    acc += gx * yr[c];
+                    atomicAdd(&gacc[3 * (size_t)r + c], gx);
+                }
+            }
+        }
+    }
+    lsum = block_sum(lsum, red);
+    rsum = block_sum(rsum, red);
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) scratch[0] = s;
+        float* o = scratch + 2 + 3 * blockIdx.x;
+        o[0] = lsum;
+        o[1] = rsum;
+        o[2] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void loss_step_rows_kernel(const float* __restrict__ y, int n, float* __restrict__ scratch,
+                                                             int nblk, float inv_count, float* __restrict__ gacc,
+                                                             float* __restrict__ dy, float* __restrict__ nconv,
+                                                             float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float l = 0.f, rr = 0.f, ac = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        l += scratch[2 + 3 * i];
+        rr += scratch[3 + 3 * i];
+        ac += scratch[4 + 3 * i];
+    }
+    l = block_sum(l, red);
+    rr = block_sum(rr, red);
+    ac = block_sum(ac, red);
+    const float s = scratch[0];
+    const float inr = 1.0f / rr;                      // (no real sample: inf / nan, as the reference's 0 / 0)
+    const float ds_all = -(ac * inr) / (s * s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        loss_out[0] = l * inr;
+        loss_out[1] = rr;
+        scratch[1] = ds_all;
+    }
+    const float ds = ds_all * inv_count, gs = inr / s;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const float yr[3] = {y[3 * r], y[3 * r + 1], y[3 * r + 2]};
+        float a[3], norm, inv;
+        norm_row(yr, s, a, norm, inv);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = gacc[3 * r + c];
+            gacc[3 * r + c] = 0.f;
+            const float sg = yr[c] > 0.f ? 1.f : (yr[c] < 0.f ? -1.f : 0.f);
+            dy[3 * r + c] = g * gs + sg * ds;
+            if (nconv) nconv[3 * r + c] = a[c] * inv;
+        }
+    }
+}
+
 // ---- rotation augmentation (train.py:439-451) ---------------------------------------------------
 __global__ void rotate_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t nvec,
                                    const float* __restrict__ Rd) {
@@ -400,6 +558,39 @@ extern "C" int fgc_upsample4_bwd(const float* dy, float* dx, int32_t n_in, int32
     return FGC_OK;
 }
 
+extern "C" int fgc_pool_fwd(const float* x, float* y, int32_t n_out, int32_t c, int32_t group, void* stream) {
+    FGC_CHECK_ARG(x && y && n_out > 0 && c > 0 && group >= 1, "fgc_pool_fwd: bad arguments");
+    const int64_t cnt = (int64_t)n_out * c;
+    FGC_LAUNCH("pool_fwd_kernel", ST, pool_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, cnt, c, group);
+    FGC_CHECK_LAUNCH("fgc_pool_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_pool_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t n_out, int32_t c,
+                            int32_t group, int32_t accumulate, void* stream) {
+    FGC_CHECK_ARG(x && y && dy && dx && n_out > 0 && c > 0 && group >= 1, "fgc_pool_bwd: bad arguments");
+    const int64_t cnt = (int64_t)n_out * c;
+    FGC_LAUNCH("pool_bwd_kernel", ST, pool_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, dy, dx, cnt, c, group,
+               accumulate);
+    FGC_CHECK_LAUNCH("fgc_pool_bwd");
+    return FGC_OK;
+}
+extern "C" int fgc_upsample_fwd(const float* x, float* y, int32_t n_in, int32_t c, int32_t group, void* stream) {
+    FGC_CHECK_ARG(x && y && n_in > 0 && c > 0 && group >= 1, "fgc_upsample_fwd: bad arguments");
+    const int64_t cnt = (int64_t)n_in * group * c;
+    FGC_LAUNCH("upsample_fwd_kernel", ST, upsample_fwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, x, y, cnt, c, group);
+    FGC_CHECK_LAUNCH("fgc_upsample_fwd");
+    return FGC_OK;
+}
+extern "C" int fgc_upsample_bwd(const float* dy, float* dx, int32_t n_in, int32_t c, int32_t group, int32_t accumulate,
+                                void* stream) {
+    FGC_CHECK_ARG(dy && dx && n_in > 0 && c > 0 && group >= 1, "fgc_upsample_bwd: bad arguments");
+    const int64_t cnt = (int64_t)n_in * c;
+    FGC_LAUNCH("upsample_bwd_kernel", ST, upsample_bwd_kernel, dim3(ew_grid(cnt)), dim3(EW_THREADS), 0, dy, dx, cnt, c, group,
+               accumulate);
+    FGC_CHECK_LAUNCH("fgc_upsample_bwd");
+    return FGC_OK;
+}
+
 extern "C" int32_t fgc_norm_num_partials(int32_t n) { return cdiv(n, NORM_ROWS_PER_BLOCK); }
 
 extern "C" int fgc_normalize_fwd(const float* x, int32_t n, const float* abs_partial, int32_t num_partials, float* y,
@@ -471,6 +662,22 @@ extern "C" int fgc_angular_loss_bwd(const float* fn, const float* gt, const int3
     FGC_LAUNCH("angular_loss_bwd_kernel", ST, angular_loss_bwd_kernel, dim3(cdiv(ns, 256)), dim3(256), 0, fn, gt, sample_ind, ns, loss_out,
                        dloss, dfn);
     FGC_CHECK_LAUNCH("fgc_angular_loss_bwd");
+    return FGC_OK;
+}
+
+extern "C" int32_t fgc_loss_step_scratch_floats(int32_t ns) { return 2 + 3 * cdiv(ns, LOSS_SAMPLES_PER_BLOCK); }
+
+extern "C" int fgc_loss_step(const float* y, int32_t n, const float* abs_partial, int32_t num_partials, const float* gt,
+                             const float* R, const int32_t* sample_ind, int32_t ns, float* gacc, float* n_conv, float* dy,
+                             float* loss_out, float* scratch, void* stream) {
+    FGC_CHECK_ARG(y && abs_partial && num_partials > 0 && gt && sample_ind && gacc && dy && loss_out && scratch && n > 0 &&
+                  ns > 0, "fgc_loss_step: bad arguments");
+    const int nblk = cdiv(ns, LOSS_SAMPLES_PER_BLOCK);
+    FGC_LAUNCH("loss_step_samples_kernel", ST, loss_step_samples_kernel, dim3(nblk), dim3(LOSS_SAMPLES_PER_BLOCK), 0, y,
+               3.0f * (float)n, abs_partial, num_partials, gt, R, sample_ind, ns, gacc, scratch);
+    FGC_LAUNCH("loss_step_rows_kernel", ST, loss_step_rows_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, y, n, scratch, nblk,
+               1.0f / (3.0f * (float)n), gacc, dy, n_conv, loss_out);
+    FGC_CHECK_LAUNCH("fgc_loss_step");
     return FGC_OK;
 }
 

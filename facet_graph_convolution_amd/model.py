@@ -161,6 +161,48 @@ class _Up4Fn(torch.autograd.Function):
         return ops.upsample4_bwd(dy.contiguous())
 
 
+class _PoolFn(torch.autograd.Function):
+    """max over 2^steps consecutive rows for any steps (the 4:1 form has its own kernels above)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = ops.pool_fwd(x, group)
+        ctx.save_for_backward(x, y)
+        ctx.group = group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        return ops.pool_bwd(x, y, dy.contiguous(), ctx.group), None
+
+
+class _UpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return ops.upsample_fwd(x, group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample_bwd(dy.contiguous(), ctx.group), None
+
+
+class _LinFn(torch.autograd.Function):
+    """x W + b through libfgc (fgc_lin_fwd / fgc_lin_bwd: fp32 MFMA, fixed-order sum over the rows)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return ops.lin_fwd(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx, dW, db = ops.lin_bwd(x, dy.contiguous(), W, need_dx=ctx.needs_input_grad[0])
+        return dx, dW, db
+
+
 class _MlpFn(torch.autograd.Function):
     """lrelu(x W1 + b1) W2 + b2 with the hidden layer kept on chip."""
 
@@ -213,15 +255,17 @@ def custom_conv2d(x, adj, out_channels, M, biasMask=True, translation_invariance
 
 
 def custom_lin(input, out_channels):
-    """model.py:763-769: a plain library GEMM (rocBLAS through torch.addmm)."""
+    """model.py:763-769, through libfgc (fgc_lin_fwd / fgc_lin_bwd).  A caller that composes custom_lin -> lrelu ->
+    custom_lin itself (model.py:937-941) materialises the hidden tensor, as the reference does; get_model_reg_multi_scale
+    below uses the fused head (fgc_mlp_*), which keeps it on chip."""
     xr = _rows(input)
     W = weight_variable([xr.shape[1], out_channels])
     b = bias_variable([out_channels])
-    return torch.addmm(b, xr, W).unsqueeze(0)
+    return _LinFn.apply(xr.contiguous(), W, b).unsqueeze(0)
 
 
 def custom_binary_tree_pooling(x, steps=1, pooltype='max'):
-    """model.py:779-788.  steps=2 ('max') is what the network uses; other step counts chain 2:1 poolings."""
+    """model.py:779-788.  steps=2 ('max') is what the network uses; any other step count is one 2^steps : 1 launch."""
     if pooltype == 'avg_ignore_zeros':      # model.py:792-814: inference-time pooling of positions / normals
         if steps % 2 or x.requires_grad:
             raise NotImplementedError("avg_ignore_zeros is built 4:1 per call and without a gradient")
@@ -232,22 +276,21 @@ def custom_binary_tree_pooling(x, steps=1, pooltype='max'):
     if pooltype != 'max':
         raise NotImplementedError("'max' (model.py:863,875) and 'avg_ignore_zeros' are built")
     xr = _rows(x)
-    if steps % 2 == 0:
-        for _ in range(steps // 2):
-            xr = _Pool4Fn.apply(xr.contiguous())
-        return xr.unsqueeze(0)
-    n, c = xr.shape
-    return xr.reshape(-1, 2 ** steps, c).amax(dim=1).unsqueeze(0)
+    if steps == 2:
+        return _Pool4Fn.apply(xr.contiguous()).unsqueeze(0)
+    if steps < 0 or xr.shape[0] % (2 ** steps):
+        raise ValueError("pooling %d rows by 2^%d" % (xr.shape[0], steps))
+    return _PoolFn.apply(xr.contiguous(), 2 ** steps).unsqueeze(0)      # any other step count: one 2^steps : 1 launch
 
 
 def custom_upsampling(x, steps=1):
     """model.py:817-825."""
     xr = _rows(x)
-    if steps % 2 == 0:
-        for _ in range(steps // 2):
-            xr = _Up4Fn.apply(xr.contiguous())
-        return xr.unsqueeze(0)
-    return xr.repeat_interleave(2 ** steps, dim=0).unsqueeze(0)
+    if steps == 2:
+        return _Up4Fn.apply(xr.contiguous()).unsqueeze(0)
+    if steps < 0:
+        raise ValueError("steps must be >= 0")
+    return _UpFn.apply(xr.contiguous(), 2 ** steps).unsqueeze(0)
 
 
 def lrelu(x, alpha):

@@ -147,6 +147,9 @@ class FacetDenoiser:
         self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
         # the gradient of the 4:1 max pooling behind conv1 / conv2 is a term of those layers' backward stage 1
         self.fused_pool = os.environ.get("FGC_NO_FUSED_POOL", "0") != "1"
+        # the loss end of an unsharded training step (normalise, rotate the ground truth, sampled loss, both gradients) in
+        # two launches instead of seven (fgc_loss_step); FGC_NO_FUSED_LOSS=1: the separate entry points
+        self.fused_loss = os.environ.get("FGC_NO_FUSED_LOSS", "0") != "1"
         # parameter slots
         k = 0
         self.slot = {}
@@ -261,8 +264,7 @@ class FacetDenoiser:
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
         B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
         B["loss"] = torch.zeros(2, **f)
-        B["R"] = torch.eye(3, **f).reshape(9).contiguous()
-        B["sample_ind"] = torch.zeros(COST_SAMPLES, dtype=torch.int32, device=dev)
+        self._alloc_step_inputs(B, COST_SAMPLES)
         if gtt is not None:
             B["gt"] = gtt.contiguous().to(dev)
             B["gtr"] = torch.empty_like(B["gt"])
@@ -368,6 +370,16 @@ class FacetDenoiser:
         self._graph_fb = None
         return self
 
+    def _alloc_step_inputs(self, B, ns):
+        """The per-step inputs - sample indices (train.py:561) and the rotation (train.py:563-565) - live in ONE device
+        buffer [ns ints | 9 floats | pad]: a step refreshes them with a single device-to-device copy
+        (set_step_inputs_packed)."""
+        B["step_in"] = torch.zeros(ns + 12, dtype=torch.int32, device=self.device)
+        B["loss_scratch"] = torch.zeros(self.L.fgc_loss_step_scratch_floats(ns), dtype=torch.float32, device=self.device)
+        B["sample_ind"] = B["step_in"][:ns]
+        B["R"] = B["step_in"][ns:ns + 9].view(torch.float32)
+        B["R"].copy_(torch.eye(3, dtype=torch.float32).reshape(9))
+
     def bind_cached(self, key, x, adjs, gt=None, max_bytes=64 << 30):
         """bind_mesh with the bound state (graphs, activations, descriptors: ~7 KB per facet) kept in HBM under `key`,
         so that a training loop that alternates between meshes (train.py:556 draws one per iteration) switches
@@ -425,7 +437,8 @@ class FacetDenoiser:
     def sharded(self):
         return self._mesh["plan"] is not None
 
-    def _forward_gen(self, rotate):
+    def _forward_gen(self, rotate, defer_normalize=False):
+        """defer_normalize: an unsharded TRAINING step leaves normalizeTensor to fgc_loss_step (which writes n_conv too)."""
         M, L, st = self._mesh, self.L, self._st()
         B, ws = M["B"], M["B"]["ws"]
         n0 = M["ns"][0]
@@ -496,6 +509,8 @@ class FacetDenoiser:
         _lib.check(self._mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
                                  _p(B["y0"]), _p(B["abs_part"]), _p(ws), ws.numel(), st), "head0")
         self._tag("fwd:normalize")
+        if defer_normalize and not self.sharded:
+            return
         if not self.sharded:
             _lib.check(L.fgc_normalize_fwd(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(),
                                            _p(B["nconv"]), _p(B["norm_scratch"]), st), "normalize")
@@ -513,7 +528,8 @@ class FacetDenoiser:
         n0 = ns[0]
         gt = B["gt"]
         self._tag("bwd:loss")
-        if rotate:
+        fused = self._fused_loss_now()
+        if rotate and not fused:
             _lib.check(L.fgc_rotate_rows(_p(B["gt"]), _p(B["gtr"]), n0, 1, _p(B["R"]), st), "rotate gt")
             gt = B["gtr"]
 
@@ -538,13 +554,22 @@ class FacetDenoiser:
             else:
                 B["g_nconv"].zero_()
 
-        if self.sharded:
+        if fused:
+            # normalise + rotate the sampled ground-truth rows + loss + both gradients: two launches (g_nconv is the
+            # zero-on-entry / zero-on-exit scratch of fgc_loss_step)
+            samp = B["sample_ind"]
+            _lib.check(L.fgc_loss_step(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(), _p(B["gt"]),
+                                       _p(B["R"]) if rotate else None, _p(samp), samp.numel(), _p(B["g_nconv"]),
+                                       _p(B["nconv"]), _p(B["g_y0"]), _p(B["loss"]), _p(B["loss_scratch"]), st), "loss step")
+        elif self.sharded:
             # a rank's own samples are a list of another length (and another tensor) every step: these few launches are
             # a request of their own, served by an eager call also when the schedule is replayed from hipGraphs
             yield ("call", loss_rows)
         else:
             loss_rows()
-        if not self.sharded:
+        if fused:
+            pass
+        elif not self.sharded:
             _lib.check(L.fgc_normalize_bwd(_p(B["y0"]), _p(B["g_nconv"]), n0, _p(B["g_y0"]), _p(B["norm_scratch"]),
                                            st), "normalize bwd")
         else:
@@ -735,8 +760,11 @@ class FacetDenoiser:
             if req is not None:
                 self._serve(req, pending)
 
-    def _enqueue_forward(self, rotate):
-        self._drain(self._forward_gen(rotate))
+    def _fused_loss_now(self):
+        return self.fused_loss and not self.sharded
+
+    def _enqueue_forward(self, rotate, training=False):
+        self._drain(self._forward_gen(rotate, defer_normalize=training and self._fused_loss_now()))
 
     def _enqueue_loss_backward(self, rotate):
         self._drain(self._loss_backward_gen(rotate))
@@ -762,7 +790,9 @@ class FacetDenoiser:
         t = np.asarray(sample_ind).astype(np.int32)
         B = self._mesh["B"]
         if t.size != B["sample_ind"].numel():
-            B["sample_ind"] = torch.empty(t.size, dtype=torch.int32, device=self.device)
+            R = B["R"].clone()
+            self._alloc_step_inputs(B, t.size)
+            B["R"].copy_(R)
             self._graph_fb = None
         self._upload(B["sample_ind"], t)
         if self.sharded:
@@ -781,6 +811,26 @@ class FacetDenoiser:
         B = self._mesh["B"]
         B["sample_ind"].copy_(sample_ind_dev)
         B["R"].copy_(R_dev.reshape(9))
+        if self.sharded:
+            if sample_local_dev is None:
+                raise ValueError("a sharded network needs the rank's local sample list (local_samples_device)")
+            B["sample_ind_local"] = sample_local_dev
+
+    @staticmethod
+    def pack_step_inputs(sample_inds, rotations, device):
+        """[steps, ns + 12] int32 on the device: row k = the samples and the rotation (bit pattern of 9 floats) of step k,
+        in the layout of the network's step-input buffer."""
+        S = np.stack([np.asarray(s).astype(np.int32) for s in sample_inds])
+        R = np.stack([np.asarray(r, dtype=np.float32).reshape(9) for r in rotations]).view(np.int32)
+        out = np.zeros((S.shape[0], S.shape[1] + 12), dtype=np.int32)
+        out[:, :S.shape[1]] = S
+        out[:, S.shape[1]:S.shape[1] + 9] = R
+        return torch.from_numpy(out).to(device)
+
+    def set_step_inputs_packed(self, packed_row, sample_local_dev=None):
+        """One device-to-device copy refreshes samples and rotation (a row of pack_step_inputs)."""
+        B = self._mesh["B"]
+        B["step_in"].copy_(packed_row)
         if self.sharded:
             if sample_local_dev is None:
                 raise ValueError("a sharded network needs the rank's local sample list (local_samples_device)")
@@ -888,7 +938,7 @@ class FacetDenoiser:
                 # instead of ~110 launches); the first call runs one step eagerly (lazy one-time set-up inside the
                 # library must not happen under capture), every later one replays
                 if self._graph_fb is None:
-                    self._enqueue_forward(rotate)
+                    self._enqueue_forward(rotate, training=True)
                     self._enqueue_loss_backward(rotate)
                     torch.cuda.synchronize()
                     self._graph_fb = ((self._capture_segments(lambda: self._forward_gen(rotate)),
@@ -904,17 +954,17 @@ class FacetDenoiser:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
-                    self._enqueue_forward(rotate)
+                    self._enqueue_forward(rotate, training=True)
                     self._enqueue_loss_backward(rotate)
                 torch.cuda.current_stream().wait_stream(s)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._enqueue_forward(rotate)
+                    self._enqueue_forward(rotate, training=True)
                     self._enqueue_loss_backward(rotate)
                 self._graph_fb = (g, rotate)
             self._graph_fb[0].replay()
         else:
-            self._enqueue_forward(rotate)
+            self._enqueue_forward(rotate, training=True)
             self._enqueue_loss_backward(rotate)
         return self._mesh["B"]["loss"]
 

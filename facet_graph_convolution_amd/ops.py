@@ -209,6 +209,71 @@ def upsample4_bwd(dy, dx=None, accumulate=False):
     return dx
 
 
+def pool_fwd(x, group):
+    """max over each `group` consecutive rows (custom_binary_tree_pooling with group = 2^steps, model.py:779-788)."""
+    x = _f32c(x)
+    n, c = x.shape
+    if n % group:
+        raise ValueError("pooling needs a multiple of %d rows, got %d" % (group, n))
+    y = torch.empty(n // group, c, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_pool_fwd(ptr(x), ptr(y), n // group, c, int(group), stream_ptr()), "fgc_pool_fwd")
+    return y
+
+
+def pool_bwd(x, y, dy, group):
+    x, y, dy = _f32c(x), _f32c(y), _f32c(dy)
+    dx = torch.empty_like(x)
+    check(_lib.lib().fgc_pool_bwd(ptr(x), ptr(y), ptr(dy), ptr(dx), y.shape[0], y.shape[1], int(group), 0, stream_ptr()),
+          "fgc_pool_bwd")
+    return dx
+
+
+def upsample_fwd(x, group):
+    """every row repeated `group` times consecutively (custom_upsampling with group = 2^steps, model.py:817-825)."""
+    x = _f32c(x)
+    n, c = x.shape
+    y = torch.empty(n * group, c, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_upsample_fwd(ptr(x), ptr(y), n, c, int(group), stream_ptr()), "fgc_upsample_fwd")
+    return y
+
+
+def upsample_bwd(dy, group):
+    dy = _f32c(dy)
+    n, c = dy.shape
+    dx = torch.empty(n // group, c, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().fgc_upsample_bwd(ptr(dy), ptr(dx), n // group, c, int(group), 0, stream_ptr()), "fgc_upsample_bwd")
+    return dx
+
+
+def lin_fwd(x, W, b):
+    """custom_lin (model.py:763-769): x [n, cin] W [cin, cout] + b."""
+    _req_cuda(x, W, b)
+    x, W, b = _f32c(x), _f32c(W), _f32c(b)
+    n, cin = x.shape
+    cout = W.shape[1]
+    if W.shape[0] != cin or b.shape[0] != cout:
+        raise ValueError("custom_lin: x %s, W %s, b %s" % (tuple(x.shape), tuple(W.shape), tuple(b.shape)))
+    y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
+    check(_lib.lib().fgc_lin_fwd(ptr(x), n, cin, cout, ptr(W), ptr(b), ptr(y), stream_ptr()), "fgc_lin_fwd")
+    return y
+
+
+def lin_bwd(x, dy, W, need_dx=True):
+    """Returns (dx or None, dW, db)."""
+    _req_cuda(x, dy, W)
+    x, dy, W = _f32c(x), _f32c(dy), _f32c(W)
+    n, cin = x.shape
+    cout = W.shape[1]
+    L = _lib.lib()
+    ws = _workspace(L.fgc_lin_bwd_workspace_bytes(n, cin, cout), x.device, "lin")
+    dx = torch.empty_like(x) if need_dx else None
+    dW = torch.empty_like(W)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device)
+    check(L.fgc_lin_bwd(ptr(x), ptr(dy), n, cin, cout, ptr(W), ptr(dx), ptr(dW), ptr(db), ptr(ws), ws.numel(), stream_ptr()),
+          "fgc_lin_bwd")
+    return dx, dW, db
+
+
 def normalize_fwd(x, abs_partial=None):
     """normalizeTensor on [n,3]; returns (y, scratch) - scratch feeds normalize_bwd."""
     x = _f32c(x)

@@ -340,6 +340,24 @@ int fgc_pool4_bwd_bf16(const void* x, const void* y, const void* dy, void* dx, i
 int fgc_upsample4_fwd(const float* x, float* y, int32_t n_in, int32_t c, void* stream);
 int fgc_upsample4_bwd(const float* dy, float* dx, int32_t n_in, int32_t c, int32_t accumulate, void* stream);
 
+/* custom_binary_tree_pooling 'max' (model.py:779-788) and custom_upsampling (model.py:817-825) for any steps:
+ * group = 2^steps consecutive rows per pooled row (the 4:1 forms above are group = 4).  Pooling gradient = tf.reduce_max's:
+ * split evenly over the entries equal to the maximum. */
+int fgc_pool_fwd(const float* x, float* y, int32_t n_out, int32_t c, int32_t group, void* stream);
+int fgc_pool_bwd(const float* x, const float* y, const float* dy, float* dx, int32_t n_out, int32_t c, int32_t group,
+                 int32_t accumulate, void* stream);
+int fgc_upsample_fwd(const float* x, float* y, int32_t n_in, int32_t c, int32_t group, void* stream);
+int fgc_upsample_bwd(const float* dy, float* dx, int32_t n_in, int32_t c, int32_t group, int32_t accumulate, void* stream);
+
+/* custom_lin (model.py:763-769) on its own: y [n, cout] = x [n, cin] W [cin, cout] + b, and its gradients
+ * (dx may be NULL; dW [cin, cout], db [cout]; the sum over the n rows is split over workgroups and added in a fixed order).
+ * Exact fp32 products on v_mfma_f32_16x16x4_f32.  The network's own two linear layers are fgc_mlp_fwd / fgc_mlp_bwd (hidden
+ * layer kept on chip); this is for callers that compose custom_lin -> lrelu -> custom_lin themselves. */
+size_t fgc_lin_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t cout);
+int fgc_lin_fwd(const float* x, int32_t n, int32_t cin, int32_t cout, const float* W, const float* b, float* y, void* stream);
+int fgc_lin_bwd(const float* x, const float* dy, int32_t n, int32_t cin, int32_t cout, const float* W, float* dx, float* dW,
+                float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* normalizeTensor (utils.py:1700-1715).  scratch: 2 + fgc_norm_num_partials(n) floats.
  * If abs_partial/num_partials come from fgc_mlp_fwd they are used for the global mean,
  * otherwise pass NULL/0 and the op reduces |x| itself. */
@@ -365,6 +383,24 @@ int fgc_angular_loss_fwd(const float* fn, const float* gt, const int32_t* sample
                          void* stream);
 int fgc_angular_loss_bwd(const float* fn, const float* gt, const int32_t* sample_ind, int32_t ns, int32_t n,
                          const float* loss_out, float dloss, float* dfn, void* stream);
+
+/* The loss end of one training step in TWO launches: normalizeTensor on the network output (utils.py:1700-1715), the
+ * rotation of the ground truth (train.py:439-451, applied to the sampled rows only), the sampled angular loss
+ * (train.py:509-517, faceNormalsLoss train.py:1272-1294), its gradient, and normalizeTensor's gradient - what
+ * fgc_normalize_fwd + fgc_rotate_rows + fgc_angular_loss_fwd / _bwd + fgc_normalize_bwd do in seven.
+ *   y [n,3]: the network output; abs_partial / num_partials: the partial sums of |y| that fgc_mlp_fwd leaves;
+ *   gt [n,3]: UNROTATED ground truth; R: device pointer to 9 floats or NULL (identity); sample_ind int32 [ns];
+ *   gacc [n,3]: scratch that must be ZERO on entry and is zero again when the call has run (only sampled rows are ever
+ *   touched: the caller zero-fills it once, when it allocates it);
+ *   n_conv [n,3] (may be NULL): the normalised rows; dy [n,3]: d loss / d y; loss_out [2] = {loss in degrees, real rows};
+ *   scratch: fgc_loss_step_scratch_floats(ns) floats ([0] = mean|y| + eps, [1] = d loss / d of it, then one partial
+ *   triple per 256 samples).
+ * Same arithmetic per row as the separate entry points; sums over the samples instead of over all rows, and the division
+ * by the number of real samples is applied once, at the end. */
+int32_t fgc_loss_step_scratch_floats(int32_t ns);
+int fgc_loss_step(const float* y, int32_t n, const float* abs_partial, int32_t num_partials, const float* gt,
+                  const float* R, const int32_t* sample_ind, int32_t ns, float* gacc, float* n_conv, float* dy,
+                  float* loss_out, float* scratch, void* stream);
 
 /* random-rotation augmentation (train.py:439-451): every 3-vector v of every row becomes R v.
  * R: DEVICE pointer to 9 floats (row major; kept on the device so that a captured hipGraph can be

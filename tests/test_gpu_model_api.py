@@ -51,6 +51,40 @@ def test_custom_conv2d_signature_and_return(golden_dir):
         M.custom_conv2d(torch.tensor(z["x"], device="cuda:0"), torch.tensor(z["adj"]), 32, 9, rotation_invariance=True)
 
 
+def test_operator_api_composes_a_head_from_custom_lin_and_odd_step_pooling():
+    """A caller written against model.py composes custom_lin -> lrelu -> custom_lin itself (model.py:937-941) and may pool
+    with any step count: every op goes through libfgc (no torch fallback), forward and backward, and equals the fused head /
+    the oracle."""
+    from facet_graph_convolution_amd import model as M
+    from oracle import model_ref as R
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    x = torch.tensor(rs.normal(size=(1, 512, 32)).astype(np.float32), device=dev, requires_grad=True)
+    store = M.VariableStore(dev, seed=3)
+    with M.variable_store(store):
+        pooled = M.custom_binary_tree_pooling(x, steps=1)                     # 2:1
+        h = M.lrelu(M.custom_lin(pooled, 1024), 0.1)
+        y = M.custom_lin(h, 3)
+        up = M.custom_upsampling(y, steps=3)                                  # 1:8
+    assert len(store.vars) == 4 and tuple(y.shape) == (1, 256, 3) and tuple(up.shape) == (1, 2048, 3)
+    w = torch.tensor(rs.normal(size=(1, 2048, 3)).astype(np.float32), device=dev)
+    (up * w).sum().backward()
+    torch.cuda.synchronize()
+    # float64 oracle with the same variables
+    xr = x.detach().cpu().double().requires_grad_(True)
+    P = [v.detach().cpu().double().requires_grad_(True) for v in store.vars]
+    pr = R.custom_binary_tree_pooling(xr, 1)
+    yr = R.custom_lin(R.lrelu(R.custom_lin(pr, P[0], P[1])), P[2], P[3])
+    (R.custom_upsampling(yr, 3) * w.cpu().double()).sum().backward()
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() < 3e-6
+    for got, ref in [(x.grad, xr.grad)] + [(v.grad, p.grad) for v, p in zip(store.vars, P)]:
+        assert (got.cpu().double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    # the fused head (what get_model_reg_multi_scale uses) on the same variables gives the same output
+    with M.variable_store(store):
+        y_fused = M._head(M.custom_binary_tree_pooling(x.detach(), steps=1), 1024, 3, 0.1)
+    assert (y_fused - y.detach()).abs().max().item() < 3e-6
+
+
 def test_train_and_infer_drivers(tmp_path):
     from facet_graph_convolution_amd.dataClasses import TrainingSet, InferenceMesh
     from facet_graph_convolution_amd.meshgen import icosphere, add_noise

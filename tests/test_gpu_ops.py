@@ -108,6 +108,53 @@ def test_elementwise_ops():
                                du.reshape(16, 4, 48).sum(1).numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("n,cin,cout", [(1000, 32, 1024), (333, 1024, 3), (70, 48, 5), (5000, 64, 96), (1, 6, 3)])
+def test_custom_lin_forward_backward(n, cin, cout):
+    """fgc_lin_fwd / fgc_lin_bwd (custom_lin, model.py:763-769, on its own) against float64: y within 3e-6 of the largest
+    output, gradients within 5e-6 of each tensor's largest entry (exact fp32 products, fp32 sums; 5 000 rows = three
+    partial slabs summed in a fixed order; ragged tiles in every dimension)."""
+    from facet_graph_convolution_amd import ops
+    rs = np.random.RandomState(n + cin)
+    x, W, b = _t(rs.normal(size=(n, cin)) * 0.5), _t(rs.normal(size=(cin, cout)) * 0.05), _t(rs.normal(size=cout) * 0.01)
+    dy = _t(rs.normal(size=(n, cout)))
+    X, Wd, Bd = x.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    Y = X @ Wd + Bd
+    Y.backward(dy.double())
+    y = ops.lin_fwd(x.to(DEV), W.to(DEV), b.to(DEV))
+    dx, dW, db = ops.lin_bwd(x.to(DEV), dy.to(DEV), W.to(DEV))
+    dx2, dW2, db2 = ops.lin_bwd(x.to(DEV), dy.to(DEV), W.to(DEV), need_dx=False)
+    torch.cuda.synchronize()
+    assert dx2 is None and torch.equal(dW, dW2) and torch.equal(db, db2)       # fixed summation order: bitwise repeatable
+    assert (y.cpu().double() - Y.detach()).abs().max().item() < 3e-6 * max(1.0, Y.abs().max().item())
+    for got, ref in ((dx, X.grad), (dW, Wd.grad), (db, Bd.grad)):
+        assert (got.cpu().double() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item()), tuple(ref.shape)
+
+
+@pytest.mark.parametrize("steps", [0, 1, 2, 3])
+def test_pooling_and_upsampling_for_any_step_count(steps):
+    """custom_binary_tree_pooling / custom_upsampling with steps other than the network's 2 (model.py:779-788,817-825): one
+    2^steps : 1 launch each way, against the oracle; ties in a group share the pooling gradient evenly."""
+    from facet_graph_convolution_amd import ops
+    from oracle import model_ref as R
+    rs = np.random.RandomState(steps)
+    g = 2 ** steps
+    x = _t(rs.normal(size=(16 * g, 24)))
+    if g > 1:
+        x[1] = x[0]                        # a tie in every column of the first group
+    xr = x.clone().requires_grad_(True)
+    ref = R.custom_binary_tree_pooling(xr[None], steps)[0]
+    dp = _t(rs.normal(size=(16, 24)))
+    (ref * dp).sum().backward()
+    xd = x.to(DEV)
+    p = ops.pool_fwd(xd, g)
+    assert torch.equal(p.cpu(), ref.detach())
+    np.testing.assert_allclose(ops.pool_bwd(xd, p, dp.to(DEV), g).cpu().numpy(), xr.grad.numpy(), atol=1e-7)
+    u = ops.upsample_fwd(p, g)
+    assert torch.equal(u.cpu(), R.custom_upsampling(p.cpu()[None], steps)[0])
+    du = _t(rs.normal(size=(16 * g, 24)))
+    np.testing.assert_allclose(ops.upsample_bwd(du.to(DEV), g).cpu().numpy(), du.reshape(16, g, 24).sum(1).numpy(), atol=1e-6)
+
+
 @pytest.mark.parametrize("n", [100, 5000])
 def test_normalize_and_loss(n):
     from facet_graph_convolution_amd import ops
@@ -132,6 +179,59 @@ def test_normalize_and_loss(n):
     dx = ops.normalize_bwd(xd, dfn, scratch)
     ref = xr.grad.numpy()
     np.testing.assert_allclose(dx.cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,ns,rotate", [(100, 4000, True), (5000, 4000, False), (70000, 9000, True)])
+def test_fused_loss_step_matches_oracle_and_the_separate_entry_points(n, ns, rotate):
+    """fgc_loss_step (two launches) against the float64 oracle - normalizeTensor, rotated ground truth, sampled angular
+    loss, gradient back to the network output - and against the seven-launch chain it replaces; duplicate samples, a fake
+    (all-zero ground truth) row, a zero output row, more samples than one sweep of the kernel; called twice: its scratch
+    must be zero again after every call."""
+    import ctypes as C
+    from facet_graph_convolution_amd import _lib, ops
+    from oracle import model_ref as R
+    L = _lib.lib()
+    rs = np.random.RandomState(n)
+    x = _t(rs.normal(size=(n, 3)) * 0.3)
+    x[7] = 0.0
+    gt = _t(rs.normal(size=(n, 3)))
+    gt = gt / gt.norm(dim=1, keepdim=True)
+    gt[5] = 0.0
+    idx = rs.randint(n, size=ns).astype(np.int32)
+    idx[:3] = 5          # the fake row, sampled three times
+    idx[3:6] = 11        # duplicates of a real row
+    idx = torch.tensor(idx)
+    Rm = _t(np.linalg.qr(rs.normal(size=(3, 3)))[0]) if rotate else torch.eye(3)
+    xr = x.double().requires_grad_(True)
+    nref = R.normalizeTensor(xr[None])
+    gtr = (gt.double() @ Rm.double().t())
+    loss_ref = R.faceNormalsLoss(nref[:, idx.long()], gtr[None][:, idx.long()])
+    loss_ref.backward()
+    xd, gtd, idxd, Rd = x.to(DEV), gt.to(DEV), idx.to(DEV), Rm.reshape(9).contiguous().to(DEV)
+    # |y| partials as fgc_mlp_fwd leaves them: any split of the sum (here: one partial per 64 rows)
+    part = torch.stack([c.abs().sum() for c in xd.split(64)]).contiguous()
+    gacc = torch.zeros(n, 3, device=DEV)
+    nconv, dy = torch.empty(n, 3, device=DEV), torch.empty(n, 3, device=DEV)
+    loss, scratch = torch.zeros(2, device=DEV), torch.zeros(L.fgc_loss_step_scratch_floats(ns), device=DEV)
+    p = _lib.ptr
+    for call in range(2):
+        _lib.check(L.fgc_loss_step(p(xd), n, p(part), part.numel(), p(gtd), p(Rd) if rotate else None, p(idxd), ns, p(gacc),
+                                   p(nconv), p(dy), p(loss), p(scratch), _lib.stream_ptr()), "fgc_loss_step")
+        torch.cuda.synchronize()
+        assert not bool(gacc.any()), "the scratch must be zero again after the call"
+        np.testing.assert_allclose(nconv.cpu().numpy(), nref[0].detach().numpy(), atol=2e-6)
+        assert abs(loss[0].item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+        assert loss[1].item() == float((gtr[idx.long()].abs().sum(1) > 1e-3).sum())
+        ref = xr.grad.numpy()
+        np.testing.assert_allclose(dy.cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max())
+    # the chain of separate launches on the same inputs: same arithmetic per row, sums in another order
+    y2, sc2 = ops.normalize_fwd(xd)
+    gt2 = ops.rotate_rows(gtd, Rm.numpy())
+    out2 = ops.angular_loss_fwd(y2, gt2, idxd)
+    dx2 = ops.normalize_bwd(xd, ops.angular_loss_bwd(y2, gt2, idxd, out2, 1.0), sc2)
+    assert torch.equal(nconv, y2) or (nconv - y2).abs().max().item() < 1e-6
+    assert abs(loss[0].item() - out2[0].item()) < 1e-5 * abs(out2[0].item()) and loss[1].item() == out2[1].item()
+    assert (dy - dx2).abs().max().item() < 1e-5 * dx2.abs().max().item()
 
 
 def test_rotate_adam_epilogue_gather():

@@ -65,12 +65,9 @@ def label(names):
 def main():
     fetch, write, steps, outp = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     assert len(fetch) == len(write) and [r[1] for r in fetch] == [r[1] for r in write], "the two passes ran different launches"
-    # a step starts at the first rotate_rows_kernel after an adam_kernel (or at the first one)
+    # a step starts with the launch that packs the weight operands of every layer (fgc_conv_pack: one per step)
     names = [r[1] for r in fetch]
-    starts = [i for i, k in enumerate(names) if "rotate_rows_kernel" in k and (i == 0 or "rotate_rows" not in names[i - 1])]
-    starts = [i for j, i in enumerate(starts) if j % 2 == 0]          # (x and gt are rotated by two launches per step)
-    # the weight pack launch precedes the rotation inside a step
-    starts = [i - 1 if i > 0 and "pack_many" in names[i - 1] else i for i in starts]
+    starts = [i for i, k in enumerate(names) if "pack_many_kernel" in k]
     assert len(starts) == steps, (len(starts), steps)
     bounds = starts + [len(names)]
     per_key, whole = {}, []
