@@ -635,7 +635,8 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
         if (w8_half_tiles<DATA>(p)) {
             constexpr int NT = 16;
             const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
-            const size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
+            size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
+            if (DATA && getenv("FGC_W8_DATA_SMEM_PAD")) smem16 += (size_t)atoi(getenv("FGC_W8_DATA_SMEM_PAD"));   // (developer knob: fewer resident workgroups)
             FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT>),
                        dim3(2 * core_grid(p)), dim3(NT * 16), smem16, p, fe, de);
             FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles)");
