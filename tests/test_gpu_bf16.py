@@ -257,7 +257,7 @@ def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act):
 
 
 @pytest.mark.parametrize("mode,cin,cout", [("plain", 32, 64), ("plain", 64, 128), ("concat", 128, 64), ("upsample", 128, 64),
-                                           ("plain", 128, 128)])
+                                           ("plain", 128, 128), ("plain", 64, 32), ("concat", 64, 32)])
 def test_bf16_conv_kernels_against_float64_on_the_same_rounded_operands(mode, cin, cout):
     """Kernel error isolated from storage error: one conv layer, forward and backward, through the bf16 kernels against
     the float64 oracle fed the SAME bf16-rounded x and dy (and, for lrelu', the bf16 kernel's own stored y).  What is
