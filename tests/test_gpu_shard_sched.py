@@ -182,6 +182,23 @@ def test_200k_facets_in_two_shards_reach_the_split_branch_on_their_own(dtype):
     print("200k facets, 2 shards, %s: worst rel gradient difference to the unsharded network %.2e" % (dtype, worst))
 
 
+def test_weak_scaling_mesh_of_the_eight_gpu_run_in_eight_shards():
+    """What `bench.py --gpus 8` (the driver's scaling run, config c2 weak) binds: ONE torus of 8 x 100 000 facets
+    (2000 x 200), 100k facets per shard, default split threshold, hipGraph segments as the bench replays them - against
+    the unsharded network, inside guard zones."""
+    from test_gpu_guard import _Guarded
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    x, adjs, gt = _mesh(2000, 200, seed=0)
+    samp = np.random.RandomState(100).randint(x.shape[1], size=4000)
+    R = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    with _Guarded() as g:
+        ref, nets = _step_pair(x, adjs, gt, 8, "f32", samp, R)
+        assert all(_took_the_split_branch([n]) == (2, 2) for n in nets)
+        worst = _eager_then_segments(ref, nets, "f32")
+        g.check("800k facets, 8 shards, eager + hipGraph segments")
+    print("800k facets (c2 x 8), 8 shards: worst rel gradient difference %.2e" % worst)
+
+
 def test_config4_one_million_facets_in_eight_shards():
     """BASELINE config 4 at its own size: the 1 000 000-facet torus (1000 x 500) as 8 shards against the unsharded
     network - unit normals within 1e-6, loss 1e-4, every gradient within 1e-3 of its tensor's largest entry - with every
