@@ -220,6 +220,28 @@ def physical_cores():
     return len(seen) or (os.cpu_count() or 1)
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one (a GPU
+    box hands a job its share of the host - e.g. 16 of 256 logical CPUs - through cpu.max, not through the mask; torch
+    started with one thread per CPU of the MASK then runs hundreds of threads on a sixteenth of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
     """The oracle timed on this host as BASELINE.md section 3 prescribes, on a BOUNDED sample (about 30 s of CPU work in
     all, so that the default bench run stays within minutes): the reference-shaped torch-CPU restatement
@@ -233,7 +255,11 @@ def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
     import torch
     from oracle import model_ref as R
     logical = os.cpu_count() or 1
-    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    affinity = usable_cpus()         # "all cores" = all the cores this job may use (mask and cgroup quota)
+
+    def note(msg):
+        print("bench: cpu_baseline: " + msg, file=sys.stderr, flush=True)
 
     def tensors(nu, nv):
         ds, F = build_mesh(nu, nv, seed=7)
@@ -261,26 +287,34 @@ def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
             R.normalizeTensor(R.get_model_reg_multi_scale(x, adjs, plain))
             return time.perf_counter() - t0
 
-    def timed(fn, threads, warm, runs):
+    def timed(fn, threads, warm, runs, what):
         torch.set_num_threads(threads)
-        for _ in range(warm):
+        t0 = time.perf_counter()
+        first = fn()
+        # (bounded: a run that takes longer than expected gets fewer repeats, never an open-ended wait)
+        if first > 15.0:
+            warm, runs = 1, min(runs, 3)
+        for _ in range(warm - 1):
             fn()
         ts = sorted(fn() for _ in range(runs))
+        note("%s at %d threads: median %.2f s over %d runs (%.0f s)" % (what, threads, ts[len(ts) // 2], runs,
+                                                                          time.perf_counter() - t0))
         return ts[len(ts) // 2], ts
 
     t_all0 = time.perf_counter()
-    fb_all, fb_all_ts = timed(fwd_bwd, affinity, 2, 5)
-    f_all, _ = timed(fwd, affinity, 2, 5)
-    t32 = min(affinity, 32)
-    if t32 == affinity:     # a host of 32 cores or fewer: the two thread counts are the same measurement
+    note("%d facets, %d usable CPUs (mask %d, logical %d)" % (F, affinity, mask, logical))
+    fb_all, fb_all_ts = timed(fwd_bwd, affinity, 2, 5, "forward+backward")
+    f_all, _ = timed(fwd, affinity, 2, 5, "forward")
+    t32 = min(mask, 32)
+    if t32 == affinity:     # the two thread counts are the same measurement
         fb_32, f_32 = fb_all, f_all
     else:
-        fb_32, _ = timed(fwd_bwd, t32, 1, 3)
-        f_32, _ = timed(fwd, t32, 1, 3)
+        fb_32, _ = timed(fwd_bwd, t32, 1, 3, "forward+backward")
+        f_32, _ = timed(fwd, t32, 1, 3, "forward")
     best_threads, fb_best = (affinity, fb_all) if fb_all <= fb_32 else (t32, fb_32)
     out = {"value": F / fb_best, "unit": "facets/s", "cores": best_threads, "kind": "port",
            "cpu_model": cpu_model(), "logical_cpus": logical, "physical_cores": physical_cores(),
-           "cpus_in_affinity_mask": affinity,
+           "cpus_in_affinity_mask": mask, "usable_cpus": affinity,
            "forward_backward": {"all_cores": {"threads": affinity, "facets_per_s": F / fb_all,
                                               "median_s": fb_all, "runs_s": [round(t, 3) for t in fb_all_ts]},
                                 "threads_32": {"threads": t32, "facets_per_s": F / fb_32, "median_s": fb_32}},
@@ -293,6 +327,7 @@ def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
     del x, gt, adjs
     if full:
         torch.set_num_threads(best_threads)
+        note("one forward on the full %dx%d mesh" % full)
         x, gt, adjs, F = tensors(*full)
         with torch.no_grad():
             t0 = time.perf_counter()
