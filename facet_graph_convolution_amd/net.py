@@ -631,7 +631,8 @@ class FacetDenoiser:
             lws = B["wsb_" + name]
             base = (_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0
             if not self.sharded:
-                io.stages, io.flags = 0, base
+                # (an unsharded layer runs all stages in one call: the weight gradient may be fused into the data kernel)
+                io.stages, io.flags = 0, base | _lib.CONV_FUSE_DW
                 _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st), name + " bwd")
                 continue
             lay = next(l for l in self.layers if l.name == name)
