@@ -96,28 +96,6 @@ __device__ __forceinline__ void fma_rows(const float* qb, const f32x2 (&raw)[16]
         z[8] += q8 * xv;
     }
 }
-// AM (bf16, half tiles): the aggregation z = q X runs on the bf16 matrix pipe.  Geometry of its LDS image:
-//   xz   [16 nodes][AM_NODE bytes]: a node's 16 gathered rows of the pass (32 bf16 channels = 64 B each; the two 32-byte
-//        halves of rows 4 .. 7 (mod 8) swapped, so that the transposed reads of the eight rows a 32-lane half touches fall on
-//        eight disjoint 32-byte bank spans); the node's aggregate row z (608 B) is written over them once they are read.
-//        AM_NODE = 1056 B = 264 dwords == 8 (mod 16): the matrix phase's ds_read_b128 pattern over the z rows stays
-//        conflict free
-//   qT   [16 nodes][9 m][4 edge groups][hi x 4 | lo x 4] bf16: the soft assignment as TWO bf16 terms per value (16
-//        significant bits), laid out as the B fragments of v_mfma_f32_16x16x32_bf16: k slots 0-3 of a lane group carry
-//        edges 4g .. 4g+3 against q_hi, slots 4-7 the SAME edges against q_lo
-constexpr int AM_NODE = 1056, AM_QNODE = 576;
-typedef short am_s16x4 __attribute__((ext_vector_type(4)));
-template <int T0, int N>
-__device__ __forceinline__ void gather_rows_am(__amdgpu_buffer_rsrc_t rsrc, unsigned rowbytes, unsigned laneoff,
-                                               const int* ids, f32x2 (&raw)[16]) {
-    unsigned rid[N];
-#pragma unroll
-    for (int t = 0; t < N; ++t) rid[t] = (unsigned)ids[T0 + t];
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-        raw[T0 + t][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, __umul24(rid[t], rowbytes) + laneoff, 0, 0));
-}
-
 // the 16 lanes that write and read a node's q table sit in one wave, whose LDS accesses execute in order: ordering the
 // compiler is all that is needed between the soft-assignment and the aggregation phase (no s_barrier)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -138,34 +116,30 @@ __device__ __forceinline__ void wave_lds_sync() {
 // soft assignment, the aggregation FMAs and every epilogue stay fp32.  FAST shapes only.
 // NT: nodes per workgroup, 32 (eight waves) or 16 (four waves: a half tile each; twice the workgroups, four instead of two
 // resident per CU at the same 16 waves, and twice the packed-weight traffic per node).  NT = 16 needs npad <= 64.
-// AM: the aggregation on the bf16 matrix pipe (bf16 storage, half tiles; see AM_NODE above).  Per node and pass TWO
-// v_mfma_f32_16x16x32_bf16 (rows = 16 channels, columns = the nine assignments, k = the node's 16 edge slots x {q_hi, q_lo})
-// replace 16 x 9 packed FMAs per lane; the vector ALU, which bounds the bf16 kernels, keeps the soft assignment only.
-template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32, bool AM = false>
-__global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+// FUSE (data gradient of a 32-output layer over a 64-wide input, fp32, half tiles): the weight gradient leaves the
+// kernel as per-workgroup partial products instead of r [n, 9 * cout + 24] going to memory and coming back through the
+// weight-gradient GEMM.  The grid is a fixed number of workgroups (three per CU); each walks a contiguous run of half
+// tiles and keeps  [dW0; du; dv]^T-partial [312 x 64] += [r | da | dg]_tile^T x_tile  (K = the tile's 16 nodes, 80 MFMAs
+// per wave and tile) in 80 accumulator registers, written once, at the end, as slab `blockIdx.x` of de.dw_slab; the usual
+// fixed-order slab reduction sums them.  r is never stored.
+constexpr int FUSE_PL = FGC_M * 32 + 24, FUSE_CIN = 64;
+template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32, bool FUSE = false>
+__global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     static_assert(!BF || FAST, "the bf16 form exists for the fast shapes only");
     static_assert(NT == 32 || (NT == 16 && FAST && QS == 16), "half tiles: the pipelined 16-slot form only");
-    static_assert(!AM || (BF && NT == 16 && QS == 16 && !FGC_KO), "matrix-pipe aggregation: bf16 half tiles");
+    static_assert(!FUSE || (DATA && !BF && NT == 16), "fused weight gradient: the fp32 data-gradient kernel on half tiles");
     constexpr int TILE = NT, RT = NT / 16, NW = NT / 4, LW = NT == 32 ? 3 : 2, W8_THREADS = NT * 16;   // (shadow the 32-node constants)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS, NT);
-    // AM: [xz | qT | row ids | da dg | degrees]
-    char* const am_xz = smem_raw;
-    char* const am_qT = smem_raw + NT * AM_NODE;
-    int* const am_ids = reinterpret_cast<int*>(am_qT + NT * AM_QNODE);
-    float* const am_dag = reinterpret_cast<float*>(am_ids + NT * 16);
-    if constexpr (AM) s.deg = reinterpret_cast<int*>(am_dag + NT * 18);
-    constexpr int ZROWB = AM ? AM_NODE : ZSTRIDE_BF * 2;     // bytes between the aggregate rows of two nodes (bf16 forms)
+    const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS, NT);
     constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
     constexpr bool PIPE = FAST && QS == 16;            // rows requested one phase ahead (gather_rows / fma_rows)
     // DATA: the node's da | dg rows for the epilogue live in the two spare floats of the node's first nine edge slots
     // (qbuf[node][m][10] = da[m], [11] = dg[m]): no LDS of their own, which is what lets a fifth half-tile workgroup fit
-    auto dag_slot = [&](int nd, int m) {
-        if constexpr (AM) return am_dag + nd * 18 + 2 * m;
-        else return s.qbuf + (size_t)nd * qnode_stride(QS) + m * QLD + 10;
-    };
+    auto dag_slot = [&](int nd, int m) { return s.qbuf + (size_t)nd * qnode_stride(QS) + m * QLD + 10; };
     int tile0;
-    if constexpr (NT == 32) {
+    if constexpr (FUSE) {
+        tile0 = 0;      // (set per half tile of the workgroup's run, below)
+    } else if constexpr (NT == 32) {
         tile0 = block_tile0(p);
     } else {   // half tiles: workgroup h of 2 * tiles; the XCD map runs over half tiles
         const int h = xcd_tile(blockIdx.x, gridDim.x);
@@ -205,15 +179,6 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
         const unsigned rowbytes = (unsigned)(first ? p.c0 : p.c1) * ESZ;
         const unsigned laneoff = (unsigned)(pass * KC + 2 * kl - (first ? 0 : p.c0)) * ESZ;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
-        if constexpr (AM) {
-            const int* ids = am_ids + node * 16;
-            gather_rows_am<0, 8>(rsrc, rowbytes, laneoff, ids, xa);
-            if (dw > 8) gather_rows_am<8, 4>(rsrc, rowbytes, laneoff, ids, xa);
-            if (dw > 12) gather_rows_am<12, 1>(rsrc, rowbytes, laneoff, ids, xa);
-            if (dw > 13) gather_rows_am<13, 1>(rsrc, rowbytes, laneoff, ids, xa);
-            if (dw > 14) gather_rows_am<14, 2>(rsrc, rowbytes, laneoff, ids, xa);
-            return;
-        }
         gather_rows<0, 8, BF>(rsrc, rowbytes, laneoff, qb, xa);
         // (13 is the degree of a regular triangle mesh's facet graph - 12 neighbours and the facet itself: slot 12 on its own
         //  instead of a batch of four saves 3 of 16 row requests and 27 of 144 packed FMAs per lane and pass there)
@@ -223,6 +188,31 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
         if (dw > 14) gather_rows<14, 2, BF>(rsrc, rowbytes, laneoff, qb, xa);
     };
 
+    // FUSE: this workgroup's run of half tiles (every XCD gets a contiguous range of runs) and its weight-gradient partial
+    f32x4 acc_dw[FUSE ? 20 : 1];
+    int h_first = 0, h_count = 1;
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) acc_dw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nh = (p.n + 15) >> 4;
+        const int per = (nh + (int)gridDim.x - 1) / (int)gridDim.x;
+        h_first = xcd_tile(blockIdx.x, gridDim.x) * per;
+        h_count = __builtin_amdgcn_readfirstlane(max(0, min(per, nh - h_first)));
+    }
+    for (int it = 0; it < h_count; ++it) {
+    float xb[4] = {0.f, 0.f, 0.f, 0.f};   // FUSE: the B fragments of the tile's input rows (this wave's 16 columns)
+    if constexpr (FUSE) {
+        tile0 = (h_first + it) * 16;
+        const int col = 16 * wave + lr;
+        const bool first = col < de.c0f;                 // wave-uniform: c0f is a multiple of 16
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int j = tile0 + 4 * ks + lq;
+            const size_t row = (size_t)(min(j, p.n - 1) >> de.shiftf);
+            const float v = first ? de.x0[row * de.c0f + col] : de.x1[row * de.c1f + (col - de.c0f)];
+            xb[ks] = j < p.n ? v : 0.f;
+        }
+    }
     // ---------------- phase S: per-edge soft assignment (edges kl and kl + 16 of this thread's node)
     int dwave = 0;  // FAST: wave-uniform trip count of the edge loop
     float dgsum[FGC_M];
@@ -273,24 +263,12 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
         int jj[SPL];
         f32x4 g0[SPL], g1[SPL];
         float g8[SPL];
-        // DATA with one slot per lane (QS = 16): the edge's d-logits row is requested TOGETHER with its logit row - edge id
-        // beside the neighbour id, the row beside the neighbour's row, both unconditional from clamped indices - instead of
-        // behind the soft-assignment arithmetic inside the `k < d` branch (a load under an exec mask also makes the
-        // compiler drain every outstanding load first)
-        constexpr bool DL_EARLY = DATA && SPL == 1 && !(FGC_KO & 256);
-        int ee[SPL];
-        f32x4 dl0[SPL], dl1[SPL];
-        float dl8[SPL];
-        const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DATA ? de.dl : p.ag), 0, -1, 0x00020000);
-        const __amdgpu_buffer_rsrc_t eid_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(DATA ? p.eid : p.col), 0, -1, 0x00020000);
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
             // (unconditional, clamped into the node's list: no exec-masked load.  A node WITHOUT edges reads the entry in
             //  front of its empty list: for the padding nodes at the end of a level e0 == nnz, one past the array)
-            const unsigned eo = (unsigned)(d > 0 ? e0 + min(k, d - 1) : max(e0 - 1, 0)) * 4u;
-            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, eo, 0, 0);
-            if constexpr (DL_EARLY) ee[t] = __builtin_amdgcn_raw_buffer_load_b32(eid_rs, eo, 0, 0);
+            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(d > 0 ? e0 + min(k, d - 1) : max(e0 - 1, 0)) * 4u, 0, 0);
             jj[t] = k < d ? jv : 0;
         }
 #pragma unroll
@@ -300,42 +278,17 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             g0[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go, 0, 0));
             g1[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ag_rs, go + 16u, 0, 0));
             g8[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ag_rs, go + 32u, 0, 0));
-            if constexpr (DL_EARLY) {
-                const unsigned dof = __umul24((unsigned)ee[t], FGC_DL_LD * 4u);
-                dl0[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof, 0, 0));
-                dl1[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof + 16u, 0, 0));
-                dl8[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dl_rs, dof + 32u, 0, 0));
-            }
         }
         if constexpr (PIPE) {
             // the row ids go to the table first (slots past the degree: row 0 with weight zero), and the rows of pass 0
             // leave right behind the logit rows
-            if constexpr (AM) am_ids[node * 16 + kl] = jj[0] >> p.shift;
-            else s.qbuf[(size_t)node * qnode_stride(QS) + kl * QLD + 9] = __int_as_float(jj[0] >> p.shift);
+            s.qbuf[(size_t)node * qnode_stride(QS) + kl * QLD + 9] = __int_as_float(jj[0] >> p.shift);
             wave_lds_sync();
             issue(0, dwave);
         }
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
             const int k = kl + 16 * t;
-            // AM: this slot's nine assignments as two bf16 terms each, into the B-fragment image (zeros for an empty slot)
-            auto am_store_q = [&](const float (&qv)[FGC_M]) {
-                char* qrow = am_qT + node * AM_QNODE + (k >> 2) * 16 + (k & 3) * 2;
-#pragma unroll
-                for (int m = 0; m < FGC_M; ++m) {
-                    const unsigned short hi = f_to_bf(qv[m]);
-                    const unsigned short lo = f_to_bf(qv[m] - bf_to_f(hi));
-                    *reinterpret_cast<unsigned short*>(qrow + m * 64) = hi;
-                    *reinterpret_cast<unsigned short*>(qrow + m * 64 + 8) = lo;
-                }
-            };
-            if constexpr (AM) {
-                if (k >= d) {
-                    const float zq[FGC_M] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    am_store_q(zq);
-                    continue;
-                }
-            }
             if (k >= d) {
                 if (FAST && (PIPE || k < dfill)) {  // zero-weight slot pointing at a valid row
                     float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
@@ -368,22 +321,13 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                 sum += l[m];
             }
             const float inv = 1.0f / sum;
-            if constexpr (AM) {
-#pragma unroll
-                for (int m = 0; m < FGC_M; ++m) l[m] *= inv;
-                am_store_q(l);
-            } else {
             float* q = s.qbuf + (size_t)node * qnode_stride(QS) + k * QLD;
             *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
             *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
             q[8] = l[8] * inv;
             if (!PIPE) q[9] = __int_as_float(jj[t] >> p.shift);
-            }
-            if constexpr (DL_EARLY) {
-                dgsum[0] += dl0[t][0]; dgsum[1] += dl0[t][1]; dgsum[2] += dl0[t][2]; dgsum[3] += dl0[t][3];
-                dgsum[4] += dl1[t][0]; dgsum[5] += dl1[t][1]; dgsum[6] += dl1[t][2]; dgsum[7] += dl1[t][3];
-                dgsum[8] += dl8[t];
-            } else if (DATA && !(FGC_KO & 256)) {
+            if (DATA && !(FGC_KO & 256)) {
+                const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(de.dl), 0, -1, 0x00020000);
                 const unsigned dof = __umul24((unsigned)p.eid[e0 + k], FGC_DL_LD * 4u);
                 const f32x4 d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof, 0, 0));
                 const f32x4 d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof + 16u, 0, 0));
@@ -409,7 +353,9 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                     *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
                     // da | dg behind the node's r row: [du; dv] = (da | dg)^T x rides in the dW0 GEMM
-                    if constexpr (BF) {
+                    if constexpr (FUSE) {
+                        // (they ride in this kernel's own weight-gradient partial, from the edge table)
+                    } else if constexpr (BF) {
                         u32x2* rt = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)i * de.rld +
                                                              (de.rld - 24));
                         rt[0] = f4_to_bf4(f32x4{da[0], da[1], da[2], da[3]});
@@ -447,58 +393,6 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) z[m] = f32x2{0.f, 0.f};
         const int cbase = pass * KC + 2 * cl;
-        if constexpr (AM) {
-            if (pass > 0) __syncthreads();  // the previous pass' matrix phase has read the z rows this pass overwrites
-            // ---- the rows of this pass: registers -> the node's staging rows (slots past the wave's ladder: zeros)
-            {
-                char* xrow = am_xz + node * AM_NODE + (kl & 7) * 4;
-                const int hsel = kl >> 3;
-                const int nld = dwave > 14 ? 16 : (dwave > 13 ? 14 : (dwave > 12 ? 13 : (dwave > 8 ? 12 : 8)));
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const unsigned v = t < nld ? __builtin_bit_cast(unsigned, xa[t][0]) : 0u;
-                    *reinterpret_cast<unsigned*>(xrow + t * 64 + ((hsel ^ ((t >> 2) & 1)) << 5)) = v;
-                }
-            }
-            wave_lds_sync();                  // a node's rows are written and read by the 16 lanes of one wave
-            if (pass + 1 < p.passes) issue(pass + 1, dwave);   // the next pass' rows travel under the products below
-            // ---- z[node][m][32 channels] = sum over the edge slots of q[m][slot] * x[slot][channel], four nodes per wave
-            const int lrq = lr >> 2, lrp = lr & 3;
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                const int nw = wave * 4 + nd;
-                const char* nb = am_xz + nw * AM_NODE;
-                const u32x4 qf = *reinterpret_cast<const u32x4*>(am_qT + nw * AM_QNODE + min(lr, FGC_M - 1) * 64 + lq * 16);
-                f32x4 zz[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    // block of this 16-lane group: rows = edge slots 4 lq .. 4 lq + 3, columns = channels 16 nt .. + 15
-                    const char* a = nb + (4 * lq + lrq) * 64 + ((nt ^ (lq & 1)) << 5) + lrp * 8;
-                    const am_s16x4 xr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_s16x4*)a);
-                    const u32x2 x2 = __builtin_bit_cast(u32x2, xr);
-                    const u32x4 xf = u32x4{x2[0], x2[1], x2[0], x2[1]};     // the same four edges against q_hi and q_lo
-                    zz[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, qf),
-                                                                     f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                }
-                // C layout: column = lr = assignment m, rows 4 lq + t = channels; the node's staging rows are read: z goes
-                // over them (and, for the data gradient, to r)
-                if (lr < FGC_M) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const u32x2 zp = f4_to_bf4(zz[nt]);
-                        *reinterpret_cast<u32x2*>(am_xz + nw * AM_NODE + (lr * KC + 16 * nt + 4 * lq) * 2) = zp;
-                        if constexpr (DATA) {
-                            const int j = tile0 + nw;
-                            if (j < p.n)
-                                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)j * de.rld + lr * p.cg +
-                                                          pass * KC + 16 * nt + 4 * lq) = zp;
-                        }
-                    }
-                }
-            }
-            if (DATA && !want_gemm) return;
-            __syncthreads();
-        } else {
         if constexpr (PIPE) {
             fma_rows<0, 8, BF>(qb, xa, z);
             if (dwave > 8) fma_rows<8, 4, BF>(qb, xa, z);
@@ -548,7 +442,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             }
         }        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
             const int j = tile0 + node;
-            if (!(FGC_KO & 128) && j < p.n && cbase < p.cg) {
+            if (!FUSE && !(FGC_KO & 128) && j < p.n && cbase < p.cg) {
                 if constexpr (BF) {
                     unsigned* rr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)j * de.rld + cbase);
 #pragma unroll
@@ -572,7 +466,27 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(zr + m * KC) = z[m];
         }
         __syncthreads();
-        }   // (!AM)
+        if constexpr (FUSE) {
+            // ---------------- [dW0; du; dv] partial += [r | da | dg]^T x   (rows = the 312 columns of the node's r row, columns
+            // = this wave's 16 input channels, k = the tile's 16 nodes: four 4-deep steps).  A: one ds_read_b32 per MFMA.
+            const float* za = s.ztile + (size_t)lq * ZSTRIDE + lr;
+#pragma unroll
+            for (int mt = 0; mt < 18; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc_dw[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[(size_t)(4 * ks) * ZSTRIDE + 16 * mt], xb[ks], acc_dw[mt], 0, 0, 0);
+            // rows 288 .. 311: da (0..8) | 0 | dg (12..20) | 0, from the node's edge-table slots
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int nd = 4 * ks + lq;
+                const f32x2 s18 = *reinterpret_cast<const f32x2*>(dag_slot(nd, lr < 9 ? lr : (lr >= 12 ? lr - 12 : 0)));
+                const f32x2 s19 = *reinterpret_cast<const f32x2*>(dag_slot(nd, lr < 5 ? lr + 4 : 0));
+                const float a18 = lr < 9 ? s18[0] : (lr >= 12 ? s18[1] : 0.f);
+                const float a19 = lr < 5 ? s19[1] : 0.f;
+                acc_dw[18] = __builtin_amdgcn_mfma_f32_16x16x4f32(a18, xb[ks], acc_dw[18], 0, 0, 0);
+                acc_dw[19] = __builtin_amdgcn_mfma_f32_16x16x4f32(a19, xb[ks], acc_dw[19], 0, 0, 0);
+            }
+        }
         // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
         if (FGC_KO & 8) return;
         // A fragments: one ds_read_b128 per row tile (fp32: 4 k of a 16-deep group, bf16: 8 k of a 32-deep step)
@@ -596,7 +510,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
         auto mmb = [&](int ks, const u32x4& b) {
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(zb + (size_t)(r * 16 + lr) * ZROWB + ks * 64 + lq * 16);
+                const u32x4 a = *reinterpret_cast<const u32x4*>(zb + (size_t)(r * 16 + lr) * (ZSTRIDE_BF * 2) + ks * 64 + lq * 16);
                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                                 acc[r], 0, 0, 0);
             }
@@ -730,6 +644,30 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             }
         }
     }
+    if constexpr (FUSE) __syncthreads();   // the epilogue's LDS reads are done before the next half tile's soft assignment
+    }   // (half tiles of this workgroup; one trip unless FUSE)
+    if constexpr (FUSE) {
+        // C layout: column = lr (input channel 16 * wave + lr), rows 4 * lq + t of row tile mt
+        float* out = de.dw_slab + (size_t)blockIdx.x * (FUSE_PL * FUSE_CIN) + 16 * wave + lr;
+#pragma unroll
+        for (int mt = 0; mt < 20; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pr = 16 * mt + 4 * lq + t;
+                if (pr < FUSE_PL) out[(size_t)pr * FUSE_CIN] = acc_dw[mt][t];
+            }
+    }
+}
+
+// fused weight gradient (conv_w8_kernel<..., FUSE>): a fixed grid of three workgroups per compute unit
+int launch_data_w8_fused(const CoreParams& p, const DataEpilogue& ep, int nblocks, hipStream_t st) {
+    constexpr int NT = 16;
+    const size_t smem16 = NT * (size_t)ZSTRIDE * 4 + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
+    FwdEpilogue fe{};
+    FGC_LAUNCH("conv_w8_kernel<data+dW>", st, (conv_w8_kernel<true, true, 16, false, NT, true>), dim3(nblocks), dim3(NT * 16), smem16,
+               p, fe, ep);
+    FGC_CHECK_LAUNCH("conv_w8_kernel (fused weight gradient)");
+    return FGC_OK;
 }
 
 bool w8_supported(const CoreParams& p, int max_deg) {
@@ -778,16 +716,6 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
     if constexpr (FAST && QS == 16) {
         if (w8_half_tiles<DATA>(p)) {
             constexpr int NT = 16;
-            if constexpr (BF) {
-                // the aggregation on the bf16 matrix pipe (FGC_NO_AGG_MFMA=1: packed FMAs on the vector ALU)
-                if (!(getenv("FGC_NO_AGG_MFMA") && getenv("FGC_NO_AGG_MFMA")[0] == '1')) {
-                    const size_t smem_am = (size_t)NT * AM_NODE + (size_t)NT * AM_QNODE + NT * 16 * 4 + NT * 18 * 4 + (2 * NT + 4) * 4 + 64;
-                    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, true, NT, true>),
-                               dim3(2 * core_grid(p)), dim3(NT * 16), smem_am, p, fe, de);
-                    FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles, matrix-pipe aggregation)");
-                    return FGC_OK;
-                }
-            }
             const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
             size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
             if (DATA && getenv("FGC_W8_DATA_SMEM_PAD")) smem16 += (size_t)atoi(getenv("FGC_W8_DATA_SMEM_PAD"));   // (developer knob: fewer resident workgroups)
