@@ -55,7 +55,6 @@ CONV_PACKED = 1
 CONV_DEFER_REDUCE = 2
 CONV_SAVE_Z = 4
 CONV_BF16 = 8
-CONV_FUSE_DW = 16      # fgc_conv_bwd_io.flags
 
 
 _SIGS = {

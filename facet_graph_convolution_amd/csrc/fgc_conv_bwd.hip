@@ -1811,22 +1811,6 @@ static int k1_nodes(const fgc_conv_desc* d) {
     return deep ? 16 : TILE;
 }
 
-// Fused weight gradient (conv_w8_kernel<..., FUSE>, fgc_conv_w8.hip): the data-gradient kernel of a 32-output layer over a
-// 64-wide input keeps [dW0; du; dv] partials in registers and writes one slab per workgroup; r is not stored and the
-// weight-gradient GEMM is not launched.  fuse_dw_shape: what the workspace plan may assume from the descriptor alone;
-// fuse_dw: whether THIS call (and the reduction that follows it) takes the fused form - the caller asks for it with
-// FGC_CONV_FUSE_DW in fgc_conv_bwd_io.flags and keeps the flag the same for fgc_conv_bwd and fgc_conv_bwd_reduce.
-constexpr int FUSE_DW_SLABS = 768;       // three resident workgroups per CU on 256 CUs
-constexpr int FUSE_DW_MIN_N = 81920;     // (the level sizes the half-tile data kernel is used from)
-static bool fuse_dw_shape(const fgc_conv_desc* d) {
-    return d->cout == 32 && d->c0 + d->c1 == 64 && d->c0 % 16 == 0 && !(d->flags & FGC_CONV_BF16) && d->n >= FUSE_DW_MIN_N &&
-           (size_t)d->n * 4 * 128 < 0xFFFFFFFFull && !(getenv("FGC_NO_FUSE_DW") && getenv("FGC_NO_FUSE_DW")[0] == '1');
-}
-static bool fuse_dw(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
-    return fuse_dw_shape(d) && (io->flags & FGC_CONV_FUSE_DW) && io->dx0 && io->max_in_deg > 0 && io->max_in_deg <= 16 &&
-           ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)d->x0 % 4) == 0;
-}
-
 struct BwdWorkspace {
     float* Wq;        // logits operand
     float* Wpt;       // data-gradient operand
@@ -1869,9 +1853,8 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
         const int tiles = cdiv(FGC_M * d->cout + 24, TNB_PC) * cdiv(cin, 64);
         w.splitW = tn_balanced_splits(target / tiles, cdiv(d->n, 256), d->n);
     }
-    w.slab = take((size_t)std::max(w.splitW, fuse_dw_shape(d) ? FUSE_DW_SLABS : 0) * (FGC_M * d->cout + 24) * cin);
-    const int maxslabs = std::max(w.splitW, fuse_dw_shape(d) ? FUSE_DW_SLABS : 0);
-    w.rtmp = take(reduce_tmp_floats(maxslabs, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(maxslabs, (size_t)FGC_M * cin) +
+    w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
+    w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
                   reduce_tmp_floats(cdiv(d->n, k1n), 12) + reduce_tmp_floats(w.nb_db, d->cout) + 64);
     // (the first layer's scratch ends with the scratch of its fixed-order sums; the db partials of stage 1 are summed with
     //  them and need theirs behind it - it used to be missing: 64 groups x cout floats written past the workspace)
@@ -1884,7 +1867,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
 static void conv_param_jobs(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, const BwdWorkspace& w, RedJob* jobs) {
     const int cin = d->c0 + d->c1, cout = d->cout;
     const int P = FGC_M * cout, PL = P + 24;
-    const int ns = fuse_dw(d, io) ? FUSE_DW_SLABS : cdiv(d->n, tn_rows_per_slab(d->n, w.splitW));
+    const int ns = cdiv(d->n, tn_rows_per_slab(d->n, w.splitW));
     const size_t sst = (size_t)PL * cin;
     jobs[0] = RedJob{w.slab, sst, ns, P * cin, cin, cin, io->dW0, w.rtmp};
     jobs[1] = RedJob{w.slab + (size_t)P * cin, sst, ns, FGC_M * cin, cin, cin, io->du};
@@ -1963,9 +1946,6 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
 
     const int stages = io->stages ? io->stages : 15;
     const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
-    const bool fused_dw = fuse_dw(d, io);
-    FGC_CHECK_ARG(!fused_dw || ((stages & 12) == 12 && io->data_tile_list == nullptr),
-                  "fgc_conv_bwd: FGC_CONV_FUSE_DW needs stages 4 and 8 in one call and no data_tile_list (stages=%d)", stages);
     FGC_CHECK_ARG(io->data_tile_list == nullptr || (io->n_data_tiles >= 0 && io->n_data_tiles <= cdiv(d->n, TILE)),
                   "fgc_conv_bwd: n_data_tiles=%d outside [0, %d]", io->n_data_tiles, cdiv(d->n, TILE));
     // The deep d-logits kernel of the 32- and 64-wide layers can compute s (and the db partials) in its prologue: one
@@ -2169,13 +2149,6 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                           "gradient (cin=%d cout=%d max_in_deg=%d)", cin, cout, io->max_in_deg);
             rc = launch_data_w8(p, ep, smem, io->max_in_deg, st, true);
             if (rc) return rc;
-        } else if (fused_dw) {
-            FGC_CHECK_ARG(g2.lpn == 8 && w8_supported(p, io->max_in_deg), "fgc_conv_bwd: fused weight gradient: unsupported shape");
-            ep.x0 = d->x0;
-            ep.x1 = d->x1;
-            ep.dw_slab = w.slab;
-            rc = launch_data_w8_fused(p, ep, FUSE_DW_SLABS, st);
-            if (rc) return rc;
         } else if (g2.lpn == 8 && w8_supported(p, io->max_in_deg)) {
             rc = launch_data_w8(p, ep, smem, io->max_in_deg, st);
             if (rc) return rc;
@@ -2193,9 +2166,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const int ns = cdiv(d->n, rps);
         const dim3 g1 = tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns);
         const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
-        if (fused_dw) {
-            // (the data kernel left the partial products in the slabs)
-        } else if (bf16 && tn_bf16_ok(PL, d->c0, d->c1)) {
+        if (bf16 && tn_bf16_ok(PL, d->c0, d->c1)) {
             const unsigned short* r16 = (const unsigned short*)io->r;
             const unsigned short *h0 = (const unsigned short*)d->x0, *h1 = (const unsigned short*)d->x1;
             const int npc = cdiv(PL, TNB_PC);

@@ -25,10 +25,6 @@ struct DataEpilogue {
     float* dx0;
     float* dx1;
     int acc0, acc1;
-    // fused weight gradient (launch_data_w8_fused): the layer's input rows and the partial-product slabs
-    const float* x0;
-    const float* x1;
-    float* dw_slab;
 };
 
 bool w8_supported(const CoreParams& p, int max_deg);
@@ -37,8 +33,5 @@ bool w8_supported(const CoreParams& p, int max_deg);
 bool w8_bf16_supported(const CoreParams& p, int max_deg);
 int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
 int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
-// the data gradient with the weight gradient fused in (fp32, cout = 32 over a 64-wide input, in-degrees <= 16, no tile
-// list): `nblocks` workgroups, slab b of ep.dw_slab [312 x 64] written by workgroup b; r is not written
-int launch_data_w8_fused(const CoreParams& p, const DataEpilogue& ep, int nblocks, hipStream_t st);
 
 }  // namespace fgc

@@ -116,18 +116,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // soft assignment, the aggregation FMAs and every epilogue stay fp32.  FAST shapes only.
 // NT: nodes per workgroup, 32 (eight waves) or 16 (four waves: a half tile each; twice the workgroups, four instead of two
 // resident per CU at the same 16 waves, and twice the packed-weight traffic per node).  NT = 16 needs npad <= 64.
-// FUSE (data gradient of a 32-output layer over a 64-wide input, fp32, half tiles): the weight gradient leaves the
-// kernel as per-workgroup partial products instead of r [n, 9 * cout + 24] going to memory and coming back through the
-// weight-gradient GEMM.  The grid is a fixed number of workgroups (three per CU); each walks a contiguous run of half
-// tiles and keeps  [dW0; du; dv]^T-partial [312 x 64] += [r | da | dg]_tile^T x_tile  (K = the tile's 16 nodes, 80 MFMAs
-// per wave and tile) in 80 accumulator registers, written once, at the end, as slab `blockIdx.x` of de.dw_slab; the usual
-// fixed-order slab reduction sums them.  r is never stored.
-constexpr int FUSE_PL = FGC_M * 32 + 24, FUSE_CIN = 64;
-template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32, bool FUSE = false>
-__global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32>
+__global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     static_assert(!BF || FAST, "the bf16 form exists for the fast shapes only");
     static_assert(NT == 32 || (NT == 16 && FAST && QS == 16), "half tiles: the pipelined 16-slot form only");
-    static_assert(!FUSE || (DATA && !BF && NT == 16), "fused weight gradient: the fp32 data-gradient kernel on half tiles");
     constexpr int TILE = NT, RT = NT / 16, NW = NT / 4, LW = NT == 32 ? 3 : 2, W8_THREADS = NT * 16;   // (shadow the 32-node constants)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS, NT);
@@ -137,9 +129,7 @@ __global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CorePara
     // (qbuf[node][m][10] = da[m], [11] = dg[m]): no LDS of their own, which is what lets a fifth half-tile workgroup fit
     auto dag_slot = [&](int nd, int m) { return s.qbuf + (size_t)nd * qnode_stride(QS) + m * QLD + 10; };
     int tile0;
-    if constexpr (FUSE) {
-        tile0 = 0;      // (set per half tile of the workgroup's run, below)
-    } else if constexpr (NT == 32) {
+    if constexpr (NT == 32) {
         tile0 = block_tile0(p);
     } else {   // half tiles: workgroup h of 2 * tiles; the XCD map runs over half tiles
         const int h = xcd_tile(blockIdx.x, gridDim.x);
@@ -188,31 +178,6 @@ __global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CorePara
         if (dw > 14) gather_rows<14, 2, BF>(rsrc, rowbytes, laneoff, qb, xa);
     };
 
-    // FUSE: this workgroup's run of half tiles (every XCD gets a contiguous range of runs) and its weight-gradient partial
-    f32x4 acc_dw[FUSE ? 20 : 1];
-    int h_first = 0, h_count = 1;
-    if constexpr (FUSE) {
-#pragma unroll
-        for (int i = 0; i < 20; ++i) acc_dw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nh = (p.n + 15) >> 4;
-        const int per = (nh + (int)gridDim.x - 1) / (int)gridDim.x;
-        h_first = xcd_tile(blockIdx.x, gridDim.x) * per;
-        h_count = __builtin_amdgcn_readfirstlane(max(0, min(per, nh - h_first)));
-    }
-    for (int it = 0; it < h_count; ++it) {
-    float xb[4] = {0.f, 0.f, 0.f, 0.f};   // FUSE: the B fragments of the tile's input rows (this wave's 16 columns)
-    if constexpr (FUSE) {
-        tile0 = (h_first + it) * 16;
-        const int col = 16 * wave + lr;
-        const bool first = col < de.c0f;                 // wave-uniform: c0f is a multiple of 16
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int j = tile0 + 4 * ks + lq;
-            const size_t row = (size_t)(min(j, p.n - 1) >> de.shiftf);
-            const float v = first ? de.x0[row * de.c0f + col] : de.x1[row * de.c1f + (col - de.c0f)];
-            xb[ks] = j < p.n ? v : 0.f;
-        }
-    }
     // ---------------- phase S: per-edge soft assignment (edges kl and kl + 16 of this thread's node)
     int dwave = 0;  // FAST: wave-uniform trip count of the edge loop
     float dgsum[FGC_M];
@@ -353,9 +318,7 @@ __global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CorePara
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                     *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
                     // da | dg behind the node's r row: [du; dv] = (da | dg)^T x rides in the dW0 GEMM
-                    if constexpr (FUSE) {
-                        // (they ride in this kernel's own weight-gradient partial, from the edge table)
-                    } else if constexpr (BF) {
+                    if constexpr (BF) {
                         u32x2* rt = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)i * de.rld +
                                                              (de.rld - 24));
                         rt[0] = f4_to_bf4(f32x4{da[0], da[1], da[2], da[3]});
@@ -442,7 +405,7 @@ __global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CorePara
             }
         }        if (DATA) {  // r[j, m*cout + channel] straight from the accumulators
             const int j = tile0 + node;
-            if (!FUSE && !(FGC_KO & 128) && j < p.n && cbase < p.cg) {
+            if (!(FGC_KO & 128) && j < p.n && cbase < p.cg) {
                 if constexpr (BF) {
                     unsigned* rr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)j * de.rld + cbase);
 #pragma unroll
@@ -466,27 +429,6 @@ __global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CorePara
             for (int m = 0; m < FGC_M; ++m) *reinterpret_cast<f32x2*>(zr + m * KC) = z[m];
         }
         __syncthreads();
-        if constexpr (FUSE) {
-            // ---------------- [dW0; du; dv] partial += [r | da | dg]^T x   (rows = the 312 columns of the node's r row, columns
-            // = this wave's 16 input channels, k = the tile's 16 nodes: four 4-deep steps).  A: one ds_read_b32 per MFMA.
-            const float* za = s.ztile + (size_t)lq * ZSTRIDE + lr;
-#pragma unroll
-            for (int mt = 0; mt < 18; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc_dw[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[(size_t)(4 * ks) * ZSTRIDE + 16 * mt], xb[ks], acc_dw[mt], 0, 0, 0);
-            // rows 288 .. 311: da (0..8) | 0 | dg (12..20) | 0, from the node's edge-table slots
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int nd = 4 * ks + lq;
-                const f32x2 s18 = *reinterpret_cast<const f32x2*>(dag_slot(nd, lr < 9 ? lr : (lr >= 12 ? lr - 12 : 0)));
-                const f32x2 s19 = *reinterpret_cast<const f32x2*>(dag_slot(nd, lr < 5 ? lr + 4 : 0));
-                const float a18 = lr < 9 ? s18[0] : (lr >= 12 ? s18[1] : 0.f);
-                const float a19 = lr < 5 ? s19[1] : 0.f;
-                acc_dw[18] = __builtin_amdgcn_mfma_f32_16x16x4f32(a18, xb[ks], acc_dw[18], 0, 0, 0);
-                acc_dw[19] = __builtin_amdgcn_mfma_f32_16x16x4f32(a19, xb[ks], acc_dw[19], 0, 0, 0);
-            }
-        }
         // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
         if (FGC_KO & 8) return;
         // A fragments: one ds_read_b128 per row tile (fp32: 4 k of a 16-deep group, bf16: 8 k of a 32-deep step)
@@ -644,30 +586,6 @@ __global__ __launch_bounds__(NT * 16, FUSE ? 3 : 4) void conv_w8_kernel(CorePara
             }
         }
     }
-    if constexpr (FUSE) __syncthreads();   // the epilogue's LDS reads are done before the next half tile's soft assignment
-    }   // (half tiles of this workgroup; one trip unless FUSE)
-    if constexpr (FUSE) {
-        // C layout: column = lr (input channel 16 * wave + lr), rows 4 * lq + t of row tile mt
-        float* out = de.dw_slab + (size_t)blockIdx.x * (FUSE_PL * FUSE_CIN) + 16 * wave + lr;
-#pragma unroll
-        for (int mt = 0; mt < 20; ++mt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int pr = 16 * mt + 4 * lq + t;
-                if (pr < FUSE_PL) out[(size_t)pr * FUSE_CIN] = acc_dw[mt][t];
-            }
-    }
-}
-
-// fused weight gradient (conv_w8_kernel<..., FUSE>): a fixed grid of three workgroups per compute unit
-int launch_data_w8_fused(const CoreParams& p, const DataEpilogue& ep, int nblocks, hipStream_t st) {
-    constexpr int NT = 16;
-    const size_t smem16 = NT * (size_t)ZSTRIDE * 4 + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
-    FwdEpilogue fe{};
-    FGC_LAUNCH("conv_w8_kernel<data+dW>", st, (conv_w8_kernel<true, true, 16, false, NT, true>), dim3(nblocks), dim3(NT * 16), smem16,
-               p, fe, ep);
-    FGC_CHECK_LAUNCH("conv_w8_kernel (fused weight gradient)");
-    return FGC_OK;
 }
 
 bool w8_supported(const CoreParams& p, int max_deg) {

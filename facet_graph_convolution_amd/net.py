@@ -631,8 +631,7 @@ class FacetDenoiser:
             lws = B["wsb_" + name]
             base = (_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0
             if not self.sharded:
-                # (an unsharded layer runs all stages in one call: the weight gradient may be fused into the data kernel)
-                io.stages, io.flags = 0, base | _lib.CONV_FUSE_DW
+                io.stages, io.flags = 0, base
                 _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st), name + " bwd")
                 continue
             lay = next(l for l in self.layers if l.name == name)

@@ -189,11 +189,6 @@ typedef struct fgc_conv_desc {
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
 #define FGC_CONV_PACKED 1
 #define FGC_CONV_DEFER_REDUCE 2   /* fgc_conv_bwd_io.flags: stage 8 leaves its partial sums for fgc_conv_bwd_reduce */
-#define FGC_CONV_FUSE_DW 16       /* fgc_conv_bwd_io.flags: the caller runs stages 4 and 8 in ONE call without a
-                                  * data_tile_list (an unsharded step) and allows the weight gradient to be formed inside
-                                  * the data-gradient kernel where the library has that form (fp32, 32 outputs over a
-                                  * 64-wide input, in-degrees <= 16, levels of >= 81920 nodes): r is then neither written
-                                  * nor read.  Keep the flag the same for fgc_conv_bwd and fgc_conv_bwd_reduce. */
 #define FGC_CONV_SAVE_Z 4         /* fgc_conv_desc.flags, first layer over a narrow input (cin <= 8): the forward pass
                                   * leaves the aggregates z [n, roundup4(9*cin)] in its workspace (sized for it by
                                   * fgc_conv_workspace_bytes when the flag is set) so that the backward pass, given
