@@ -672,7 +672,8 @@ def main(argv=None):
                         "family_share_of_step": d["share_of_step"],
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
-                        "traffic_source": traffic_note}
+                        "traffic_source": traffic_note,
+                        "launches_per_step": round(sum(c for c, _ in prof.values()) / args.steps, 1)}
         elif families:
             d = families[0]
             roofline = {"bound": "mfma", "kernel": d["kernel"], "family": d["family"], "achieved": d["achieved"],
