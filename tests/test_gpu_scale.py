@@ -62,6 +62,14 @@ def test_39k_facet_bf16_storage_train_step_within_its_stated_tolerance_of_the_or
     _train_step_vs_oracle(x, adjs, gt, dtype="bf16", tol=(5e-3, 1e-2, 8e-2))
 
 
+def test_config3_mesh_bf16_train_step_within_its_stated_tolerance_of_the_oracle():
+    """BASELINE config 3 on its own mesh (torus 250 x 100 = 50 000 facets): one bf16-storage train step against the fp32
+    oracle, same bounds as the 39k case."""
+    x, adjs, gt = _mesh(250, 100, seed=0)
+    assert (np.abs(gt[0]).sum(1) > 1e-3).sum() == 50000
+    _train_step_vs_oracle(x, adjs, gt, dtype="bf16", tol=(5e-3, 1e-2, 8e-2))
+
+
 def test_39k_facet_train_step_matches_oracle():
     """torus 140 x 140 = 39 200 facets (about 1 500 level-0 tiles, six per CU): full forward + backward."""
     x, adjs, gt = _mesh(140, 140)
