@@ -21,8 +21,9 @@ int reduce_slabs(const char* what, const float* slab, int nslabs, size_t count, 
 
 // Several independent reductions in (at most) two launches: stage 1 sums groups of RED_GROUP slabs of every job, stage
 // 2 sums the group results (jobs with a single group finish in stage 1).  Same summation order as reduce_slabs, so the
-// results are bit-identical to one reduce_slabs call per job as long as nslabs <= RED_GROUP^2 (longer lists are summed
-// in proportionally larger groups: still a fixed order, a different one).
+// results are bit-identical to one reduce_slabs call per job for nslabs <= RED_GROUP (lists of up to 2 * RED_GROUP slabs are
+// summed by ONE workgroup per column block in a single stage, longer than RED_GROUP^2 in proportionally larger groups:
+// still a fixed order, a different one).
 struct RedJob {
     const float* slab;   // element j of slab s at slab[s * stride + j]
     size_t stride;

@@ -154,7 +154,10 @@ static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, flo
         const RedJob& j = jobs[q];
         if (j.tmp) t = j.tmp;
         // two stages always suffice: very long slab lists get proportionally larger groups
-        const int group = std::max(RED_GROUP, (j.nslabs + RED_GROUP - 1) / RED_GROUP);
+        int group = std::max(RED_GROUP, (j.nslabs + RED_GROUP - 1) / RED_GROUP);
+        // up to two groups' worth of slabs (the MLP's 128 parameter slabs): one workgroup walks them all - a second launch
+        // costs more than the longer walk
+        if (j.nslabs <= 2 * RED_GROUP) group = std::max(group, j.nslabs);
         const int groups = (j.nslabs + group - 1) / group;
         if (j.nslabs <= 0 || j.count <= 0) {
             set_error("reduce_jobs: job %d has %d slabs of %d elements", q, j.nslabs, j.count);
