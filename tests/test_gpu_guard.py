@@ -168,7 +168,9 @@ def test_multi_scale_training_step_stays_inside_its_buffers():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_facet_sharded_step_stays_inside_its_buffers(world):
-    """N shards in one process (shard.sim_run): halo tails, packed exchange buffers, interior / boundary tile lists."""
+    """N shards in one process (shard.sim_run): halo tails, packed exchange buffers - the blocking schedule (these shards
+    have fewer interior tiles than the split threshold).  The interior / boundary split with its tile lists runs inside
+    guard zones in tests/test_gpu_shard_sched.py (forced, and at 200k / 800k / 1M facets)."""
     from facet_graph_convolution_amd.shard import make_sim_shards, sim_forward_backward
     x, adjs, gt = _mesh(96, 64)
     with _Guarded() as g:
