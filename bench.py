@@ -553,7 +553,7 @@ def main(argv=None):
         te = timed_block()
         graph_mode[0] = True
         hipgraph = {"ms_per_step": dt / args.steps * 1e3, "eager_ms_per_step": te / args.steps * 1e3,
-                    "graphs_per_step": sum(len(sg) for sg in net._graph_fb[0]), "matches_eager": None,
+                    "graphs_per_step": sum(1 for sg in net._graph_fb[0] for g, _ in sg if g is not None), "matches_eager": None,
                     "timed_region": "hipgraph"}
 
     # forward-only rate (BASELINE config 2 wording), untimed extra

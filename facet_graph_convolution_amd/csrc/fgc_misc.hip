@@ -319,15 +319,25 @@ __device__ __forceinline__ void norm_row(const float* y3, float s, float (&a)[3]
     norm = sqrtf(eps + (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]));
     inv = norm > eps ? 1.0f / (norm + eps) : 0.f;
 }
+// SHARD (fgc_loss_shard_*): the rows of y are split over ranks.  The sum of |y| over ALL ranks is in scratch[0] (the caller
+// all-reduced it), `count` counts the elements of the whole tensor, idx holds this rank's samples as local row ids (ns may
+// be 0: the launch still has the step's full number of workgroups, the empty ones leave zero partials), and the partials go
+// to scratch[4 + 3 b] - the caller all-reduces that table before the all-rows kernel.
+template <bool SHARD>
 __global__ __launch_bounds__(LOSS_SAMPLES_PER_BLOCK) void loss_step_samples_kernel(
     const float* __restrict__ y, float count, const float* __restrict__ part, int nparts, const float* __restrict__ gt,
     const float* __restrict__ Rd, const int* __restrict__ idx, int ns, float* __restrict__ gacc,
-    float* __restrict__ scratch /* [2 + 3 * blocks] */) {
+    float* __restrict__ scratch /* [2 + 3 * blocks]; SHARD: [4 + 3 * blocks] */) {
     __shared__ float red[4];
     const float close = 0.9999999f, eps = 1e-5f;
-    float v = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += LOSS_SAMPLES_PER_BLOCK) v += part[i];
-    const float s = block_sum(v, red) / count + 1e-5f;
+    float s;
+    if constexpr (SHARD) {
+        s = scratch[0] / count + 1e-5f;
+    } else {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += LOSS_SAMPLES_PER_BLOCK) v += part[i];
+        s = block_sum(v, red) / count + 1e-5f;
+    }
     const int sidx = blockIdx.x * LOSS_SAMPLES_PER_BLOCK + threadIdx.x;
     float lsum = 0.f, rsum = 0.f, acc = 0.f;
     if (sidx < ns) {
@@ -369,28 +379,39 @@ __global__ __launch_bounds__(LOSS_SAMPLES_PER_BLOCK) void loss_step_samples_kern
     rsum = block_sum(rsum, red);
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) {
-        if (blockIdx.x == 0) scratch[0] = s;
-        float* o = scratch + 2 + 3 * blockIdx.x;
+        if (!SHARD && blockIdx.x == 0) scratch[0] = s;
+        float* o = scratch + (SHARD ? 4 : 2) + 3 * blockIdx.x;
         o[0] = lsum;
         o[1] = rsum;
         o[2] = acc;
     }
 }
-__global__ __launch_bounds__(256) void loss_step_rows_kernel(const float* __restrict__ y, int n, float* __restrict__ scratch,
-                                                             int nblk, float inv_count, float* __restrict__ gacc,
-                                                             float* __restrict__ dy, float* __restrict__ nconv,
-                                                             float* __restrict__ loss_out) {
+__global__ __launch_bounds__(256) void abs_sum_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
     __shared__ float red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += part[i];
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) out[0] = v;
+}
+// SHARD: scratch[0] = the all-reduced sum of |y|, scratch[4 ...] = the all-reduced partial table; inv_count = 1 / elements
+// of the WHOLE tensor
+template <bool SHARD>
+__global__ __launch_bounds__(256) void loss_step_rows_kernel(const float* __restrict__ y, int n, float* __restrict__ scratch,
+                                                             int nblk, float inv_count, float count,
+                                                             float* __restrict__ gacc, float* __restrict__ dy,
+                                                             float* __restrict__ nconv, float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    constexpr int P0 = SHARD ? 4 : 2;
     float l = 0.f, rr = 0.f, ac = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) {
-        l += scratch[2 + 3 * i];
-        rr += scratch[3 + 3 * i];
-        ac += scratch[4 + 3 * i];
+        l += scratch[P0 + 3 * i];
+        rr += scratch[P0 + 1 + 3 * i];
+        ac += scratch[P0 + 2 + 3 * i];
     }
     l = block_sum(l, red);
     rr = block_sum(rr, red);
     ac = block_sum(ac, red);
-    const float s = scratch[0];
+    const float s = SHARD ? scratch[0] / count + 1e-5f : scratch[0];     // (the same expression as in the samples kernel)
     const float inr = 1.0f / rr;                      // (no real sample: inf / nan, as the reference's 0 / 0)
     const float ds_all = -(ac * inr) / (s * s);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -673,11 +694,43 @@ extern "C" int fgc_loss_step(const float* y, int32_t n, const float* abs_partial
     FGC_CHECK_ARG(y && abs_partial && num_partials > 0 && gt && sample_ind && gacc && dy && loss_out && scratch && n > 0 &&
                   ns > 0, "fgc_loss_step: bad arguments");
     const int nblk = cdiv(ns, LOSS_SAMPLES_PER_BLOCK);
-    FGC_LAUNCH("loss_step_samples_kernel", ST, loss_step_samples_kernel, dim3(nblk), dim3(LOSS_SAMPLES_PER_BLOCK), 0, y,
+    FGC_LAUNCH("loss_step_samples_kernel", ST, loss_step_samples_kernel<false>, dim3(nblk), dim3(LOSS_SAMPLES_PER_BLOCK), 0, y,
                3.0f * (float)n, abs_partial, num_partials, gt, R, sample_ind, ns, gacc, scratch);
-    FGC_LAUNCH("loss_step_rows_kernel", ST, loss_step_rows_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, y, n, scratch, nblk,
-               1.0f / (3.0f * (float)n), gacc, dy, n_conv, loss_out);
+    FGC_LAUNCH("loss_step_rows_kernel", ST, loss_step_rows_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, y, n, scratch, nblk,
+               1.0f / (3.0f * (float)n), 3.0f * (float)n, gacc, dy, n_conv, loss_out);
     FGC_CHECK_LAUNCH("fgc_loss_step");
+    return FGC_OK;
+}
+
+extern "C" int32_t fgc_loss_shard_floats(int32_t ns_total) { return 4 + 3 * cdiv(ns_total, LOSS_SAMPLES_PER_BLOCK); }
+
+extern "C" int fgc_loss_shard_abs_sum(const float* abs_partial, int32_t num_partials, float* sums, void* stream) {
+    FGC_CHECK_ARG(abs_partial && num_partials > 0 && sums, "fgc_loss_shard_abs_sum: bad arguments");
+    FGC_LAUNCH("abs_sum_kernel", ST, abs_sum_kernel, dim3(1), dim3(256), 0, abs_partial, num_partials, sums);
+    FGC_CHECK_LAUNCH("fgc_loss_shard_abs_sum");
+    return FGC_OK;
+}
+
+extern "C" int fgc_loss_shard_samples(const float* y, float total_count, const float* gt, const float* R,
+                                      const int32_t* sample_local, int32_t ns_local, int32_t ns_total, float* gacc, float* sums,
+                                      void* stream) {
+    FGC_CHECK_ARG(y && gt && gacc && sums && total_count > 0 && ns_total > 0 && ns_local >= 0 && ns_local <= ns_total &&
+                  (sample_local || !ns_local), "fgc_loss_shard_samples: bad arguments (ns_local=%d ns_total=%d)", ns_local, ns_total);
+    // (the whole step's number of workgroups on every rank: the partial table has the same shape everywhere)
+    FGC_LAUNCH("loss_step_samples_kernel", ST, loss_step_samples_kernel<true>, dim3(cdiv(ns_total, LOSS_SAMPLES_PER_BLOCK)),
+               dim3(LOSS_SAMPLES_PER_BLOCK), 0, y, total_count, (const float*)nullptr, 0, gt, R, sample_local ? sample_local : (const int32_t*)sums,
+               ns_local, gacc, sums);
+    FGC_CHECK_LAUNCH("fgc_loss_shard_samples");
+    return FGC_OK;
+}
+
+extern "C" int fgc_loss_shard_rows(const float* y, int32_t n_local, float total_count, int32_t ns_total, float* sums, float* gacc,
+                                   float* n_conv, float* dy, float* loss_out, void* stream) {
+    FGC_CHECK_ARG(y && sums && gacc && dy && loss_out && n_local > 0 && total_count > 0 && ns_total > 0,
+                  "fgc_loss_shard_rows: bad arguments");
+    FGC_LAUNCH("loss_step_rows_kernel", ST, loss_step_rows_kernel<true>, dim3(ew_grid(n_local)), dim3(EW_THREADS), 0, y, n_local, sums,
+               cdiv(ns_total, LOSS_SAMPLES_PER_BLOCK), 1.0f / total_count, total_count, gacc, dy, n_conv, loss_out);
+    FGC_CHECK_LAUNCH("fgc_loss_shard_rows");
     return FGC_OK;
 }
 

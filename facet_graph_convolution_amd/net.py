@@ -110,6 +110,22 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_HIP = [None]
+
+
+def _graph_node_count(g):
+    """Nodes of a captured (not yet instantiated) torch.cuda.CUDAGraph(keep_graph=True), through hipGraphGetNodes; -1 if
+    the runtime cannot say."""
+    try:
+        if _HIP[0] is None:
+            _HIP[0] = C.CDLL("libamdhip64.so")
+        n = C.c_size_t(0)
+        rc = _HIP[0].hipGraphGetNodes(C.c_void_p(g.raw_cuda_graph()), None, C.byref(n))
+        return int(n.value) if rc == 0 else -1
+    except (OSError, AttributeError, RuntimeError):
+        return -1
+
+
 class _ConvLayer:
     """Static description of one conv: which buffers it reads/writes and its parameter slots."""
 
@@ -376,6 +392,8 @@ class FacetDenoiser:
         (set_step_inputs_packed)."""
         B["step_in"] = torch.zeros(ns + 12, dtype=torch.int32, device=self.device)
         B["loss_scratch"] = torch.zeros(self.L.fgc_loss_step_scratch_floats(ns), dtype=torch.float32, device=self.device)
+        # facet-sharded steps: [0] the all-reduced sum of |y|, [4:] the all-reduced per-256-samples partial table
+        B["loss_sums"] = torch.zeros(self.L.fgc_loss_shard_floats(ns), dtype=torch.float32, device=self.device)
         B["sample_ind"] = B["step_in"][:ns]
         B["R"] = B["step_in"][ns:ns + 9].view(torch.float32)
         B["R"].copy_(torch.eye(3, dtype=torch.float32).reshape(9))
@@ -509,7 +527,14 @@ class FacetDenoiser:
         _lib.check(self._mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
                                  _p(B["y0"]), _p(B["abs_part"]), _p(ws), ws.numel(), st), "head0")
         self._tag("fwd:normalize")
-        if defer_normalize and not self.sharded:
+        if defer_normalize and self.sharded:
+            # training: the global mean |y| (utils.py:1705 takes it over the whole tensor) is all that is needed here -
+            # one launch sums this rank's partials, one scalar all-reduce; the rows are normalised by fgc_loss_shard_rows
+            LS = B["loss_sums"]
+            _lib.check(L.fgc_loss_shard_abs_sum(_p(B["abs_part"]), B["abs_part"].numel(), _p(LS), st), "abs sum")
+            yield ("sum", LS[0:1])
+            return
+        if defer_normalize:
             return
         if not self.sharded:
             _lib.check(L.fgc_normalize_fwd(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(),
@@ -554,7 +579,25 @@ class FacetDenoiser:
             else:
                 B["g_nconv"].zero_()
 
-        if fused:
+        if fused and self.sharded:
+            # the same in three launches with the step's second scalar all-reduce (the partial table {sum of angles, real
+            # samples, sum(d xs . y)} per 256 samples) between them; every rank leaves with the loss of the whole step
+            LS = B["loss_sums"]
+            ns_total = B["sample_ind"].numel()
+            count = 3.0 * M["n_total"][0]
+
+            def shard_samples():
+                samp = B["sample_ind_local"]
+                _lib.check(L.fgc_loss_shard_samples(_p(B["y0"]), count, _p(B["gt"]), _p(B["R"]) if rotate else None,
+                                                    _p(samp) if samp.numel() else None, samp.numel(), ns_total,
+                                                    _p(B["g_nconv"]), _p(LS), self._st()), "loss samples")
+            # (a rank's own samples are a list of another length - and another tensor - every step: a request of its own,
+            #  served by an eager call also when the schedule is replayed from hipGraphs)
+            yield ("call", shard_samples)
+            yield ("sum", LS[4:])
+            _lib.check(L.fgc_loss_shard_rows(_p(B["y0"]), n0, count, ns_total, _p(LS), _p(B["g_nconv"]), _p(B["nconv"]),
+                                             _p(B["g_y0"]), _p(B["loss"]), st), "loss rows")
+        elif fused:
             # normalise + rotate the sampled ground-truth rows + loss + both gradients: two launches (g_nconv is the
             # zero-on-entry / zero-on-exit scratch of fgc_loss_step)
             samp = B["sample_ind"]
@@ -679,7 +722,8 @@ class FacetDenoiser:
         if self.sharded:
             # every rank summed its own facets: one flat all-reduce (gradient + the loss sum in the tail)
             yield ("sum", self.params.grad_ext)
-            B["loss"][0:1] = self.params.grad_ext[-4:-3] / B["loss"][1:2]
+            if not fused:
+                B["loss"][0:1] = self.params.grad_ext[-4:-3] / B["loss"][1:2]
 
     # ---- exchange items -> (send buffer, send counts, receive view, receive counts) ------------------------
     def _block(self, item):
@@ -742,13 +786,19 @@ class FacetDenoiser:
         gen = make_gen()
         segs = []
         while True:
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True)
             # (thread_local: the collective back end's watchdog thread may query its events while this thread captures)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 try:
                     req = next(gen)
                 except StopIteration:
                     req = None
+            # a stretch WITHOUT launches (two requests back to back, or nothing behind the last one) is no graph at all:
+            # an empty hipGraph is never instantiated or replayed
+            if _graph_node_count(g) == 0:
+                g = None
+            else:
+                g.instantiate()
             segs.append((g, req))
             if req is None:
                 return segs
@@ -756,12 +806,13 @@ class FacetDenoiser:
     def _replay_segments(self, segs):
         pending = {}
         for g, req in segs:
-            g.replay()
+            if g is not None:
+                g.replay()
             if req is not None:
                 self._serve(req, pending)
 
     def _fused_loss_now(self):
-        return self.fused_loss and not self.sharded
+        return self.fused_loss
 
     def _enqueue_forward(self, rotate, training=False):
         self._drain(self._forward_gen(rotate, defer_normalize=training and self._fused_loss_now()))
@@ -941,7 +992,7 @@ class FacetDenoiser:
                     self._enqueue_forward(rotate, training=True)
                     self._enqueue_loss_backward(rotate)
                     torch.cuda.synchronize()
-                    self._graph_fb = ((self._capture_segments(lambda: self._forward_gen(rotate)),
+                    self._graph_fb = ((self._capture_segments(lambda: self._forward_gen(rotate, self._fused_loss_now())),
                                        self._capture_segments(lambda: self._loss_backward_gen(rotate))), rotate)
                     return self._mesh["B"]["loss"]
                 if self._graph_fb[1] != rotate:

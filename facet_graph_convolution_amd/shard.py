@@ -439,7 +439,7 @@ def sim_run(nets, make_gen, poison=True):
 
 
 def sim_forward_backward(nets, rotate=True):
-    sim_run(nets, lambda n: n._forward_gen(rotate))
+    sim_run(nets, lambda n: n._forward_gen(rotate, n._fused_loss_now()))
     sim_run(nets, lambda n: n._loss_backward_gen(rotate))
 
 
@@ -454,12 +454,13 @@ def sim_forward_backward_captured(nets, rotate=True):
     Run one eager step first: one-time set-up inside the library must not happen under capture."""
     for n in nets:
         if n._graph_fb is None:
-            n._graph_fb = ((n._capture_segments(lambda: n._forward_gen(rotate)),
+            n._graph_fb = ((n._capture_segments(lambda: n._forward_gen(rotate, n._fused_loss_now())),
                             n._capture_segments(lambda: n._loss_backward_gen(rotate))), rotate)
 
     def replay(segs):
         for g, req in segs:
-            g.replay()
+            if g is not None:        # (a stretch without launches is no graph: net._capture_segments)
+                g.replay()
             if req is not None:
                 yield req
 

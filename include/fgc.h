@@ -402,6 +402,20 @@ int fgc_loss_step(const float* y, int32_t n, const float* abs_partial, int32_t n
                   const float* R, const int32_t* sample_ind, int32_t ns, float* gacc, float* n_conv, float* dy,
                   float* loss_out, float* scratch, void* stream);
 
+/* The same for a FACET-SHARDED step (the rows of y are split over ranks): three calls with the step's
+ * two scalar all-reduces between them.  sums: fgc_loss_shard_floats(ns_total) floats, ns_total = the number of samples of
+ * the WHOLE step (it sizes the partial table identically on every rank); total_count = 3 x the rows of the whole tensor.
+ *   1. fgc_loss_shard_abs_sum: sums[0] = this rank's sum of |y| (from fgc_mlp_fwd's partials)   -> ALL-REDUCE sums[0:1]
+ *   2. fgc_loss_shard_samples: this rank's samples (LOCAL row ids, ns_local may be 0) -> gacc rows and the partial table
+ *      sums[4 + 3 b] = {sum of angles, real samples, sum(d xs . y)} per 256 samples             -> ALL-REDUCE sums[4:]
+ *   3. fgc_loss_shard_rows: dy, n_conv for the local rows; loss_out = the loss of the whole step; gacc zero again */
+int32_t fgc_loss_shard_floats(int32_t ns_total);
+int fgc_loss_shard_abs_sum(const float* abs_partial, int32_t num_partials, float* sums, void* stream);
+int fgc_loss_shard_samples(const float* y, float total_count, const float* gt, const float* R, const int32_t* sample_local,
+                           int32_t ns_local, int32_t ns_total, float* gacc, float* sums, void* stream);
+int fgc_loss_shard_rows(const float* y, int32_t n_local, float total_count, int32_t ns_total, float* sums, float* gacc,
+                        float* n_conv, float* dy, float* loss_out, void* stream);
+
 /* random-rotation augmentation (train.py:439-451): every 3-vector v of every row becomes R v.
  * R: DEVICE pointer to 9 floats (row major; kept on the device so that a captured hipGraph can be
  * replayed with a new rotation).  vecs = channels / 3. */

@@ -57,7 +57,8 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert j["world_check"] == {"backend": "gloo", "ranks_in_all_reduce": 2, "get_world_size": 2}
     assert set(j["startup_s"]) == {"preprocess_s", "shard_plan_s", "bind_s"}
     # the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
-    assert j["hipgraph_replay"]["graphs_per_step"] > 17 and j["hipgraph_replay"]["eager_ms_per_step"] > 0
+    # (stretches WITH launches only: two requests back to back leave no graph; this small mesh splits no layer)
+    assert j["hipgraph_replay"]["graphs_per_step"] >= 12 and j["hipgraph_replay"]["eager_ms_per_step"] > 0
     assert j["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in j["config"]["parallelism"]
     e = _bench(["--gpus", "2", "--graph", "0"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
     assert "eager launches" in e["config"]["parallelism"] and e["hipgraph_replay"] is None

@@ -128,6 +128,28 @@ def test_forced_split_schedule_matches_the_unsharded_network(nu, nv, world, min_
     _eager_then_segments(ref, nets, dtype)
 
 
+def test_sharded_step_with_the_separate_loss_launches(monkeypatch):
+    """FGC_NO_FUSED_LOSS=1: the loss end of a sharded step through the separate entry points (normalise / rotate / loss /
+    gradients, torch glue for the scalars, the loss sum riding in the gradient all-reduce) instead of fgc_loss_shard_*:
+    same results, and a rank WITHOUT samples takes part in both forms."""
+    from facet_graph_convolution_amd.shard import sim_forward_backward
+    x, adjs, gt = _mesh(64, 48, seed=0)
+    n0 = x.shape[1]
+    hi0 = ((n0 // 16) // 2) * 16                                        # shard 0 owns rows [0, hi0) (shard._owner_ranges)
+    samp = np.random.RandomState(4).randint(hi0, size=4000)            # every sample in shard 0: shard 1 has none
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FGC_NO_FUSED_LOSS", mode)
+        ref, nets = _step_pair(x, adjs, gt, 2, "f32", samp, np.eye(3))
+        assert nets[0].fused_loss == (mode == "0")
+        sim_forward_backward(nets, rotate=True)
+        assert nets[1].buffers["sample_ind_local"].numel() == 0
+        _compare(ref, nets, *TOL["f32"])
+        out[mode] = (nets[0].params.grad.clone(), nets[0].buffers["loss"][0].item())
+    assert abs(out["0"][1] - out["1"][1]) < 1e-4 * abs(out["1"][1])
+    assert (out["0"][0] - out["1"][0]).abs().max().item() < 1e-5 * out["1"][0].abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_forced_split_schedule_on_an_irregular_mesh(dtype, monkeypatch):
     """Facet degrees up to K = 23 (24-slot kernels, the LONG d-logits form) under the split schedule, 3 shards."""

@@ -32,7 +32,7 @@ for it in range(3):       # first call: eager warm-up + capture; then two replay
     net.forward_backward(rotate=True, capture=True)
 torch.cuda.synchronize()
 assert net.buffers["loss"][0].item() == loss and torch.equal(net.params.grad, g_eager), "graph replay differs from eager"
-nseg = sum(len(s) for s in net._graph_fb[0])
+nseg = sum(1 for s in net._graph_fb[0] for g, _ in s if g is not None)
 if rank == 0:
     print("captured schedule: %d graphs per step" % nseg)
 if rank == 0:
