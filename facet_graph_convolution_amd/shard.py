@@ -214,7 +214,15 @@ class PackedExchange:
         self.send_splits = [int(sum(b[2][q] * w[i] for i, b in enumerate(blocks))) for q in range(world)]
         self.recv_splits = [int(sum(b[4][q] * w[i] for i, b in enumerate(blocks))) for q in range(world)]
         self.send_buf = torch.empty(sum(self.send_splits), dtype=torch.float32, device=dev)
-        self.recv_buf = torch.empty(sum(self.recv_splits), dtype=torch.float32, device=dev)
+        # ONE tensor: its halo tail IS the receive buffer - halo rows are stored in ascending global id, i.e. owner after
+        # owner, which is the peer-major order the all-to-all delivers - and there is nothing to unpack (five of the seven
+        # forward exchanges of a step).  Several tensors: a receive buffer and one unpack launch.
+        self.direct = len(blocks) == 1 and blocks[0][3].is_contiguous()
+        if self.direct:
+            self.recv_buf = blocks[0][3].reshape(-1)
+            assert self.recv_buf.data_ptr() == blocks[0][3].data_ptr() and self.recv_buf.numel() == sum(self.recv_splits)
+        else:
+            self.recv_buf = torch.empty(sum(self.recv_splits), dtype=torch.float32, device=dev)
         s_off = [np.cumsum([0] + list(b[2])) for b in blocks]
         r_off = [np.cumsum([0] + list(b[4])) for b in blocks]
         # pack job: rows idx[idx_off : idx_off + rows] of src -> send_buf[dst_off ...]; unpack job: recv_buf[src_off ...]
@@ -227,7 +235,7 @@ class PackedExchange:
                     self.pack_jobs.append(dict(src=src, idx=idx, idx_off=int(s_off[i][q]), dst=self.send_buf, dst_off=so,
                                                rows=int(sc[q]), width=w[i]))
                     so += int(sc[q]) * w[i]
-                if rc[q]:
+                if rc[q] and not self.direct:
                     self.unpack_jobs.append(dict(src=self.recv_buf, src_off=ro, dst=recv, dst_row=int(r_off[i][q]),
                                                  rows=int(rc[q]), width=w[i]))
                     ro += int(rc[q]) * w[i]
@@ -268,6 +276,8 @@ class PackedExchange:
 
     def poison_tails(self):
         """Tests only (shard.sim_run): NaN in every row this exchange is going to deliver."""
+        if self.direct:
+            self.recv_buf.fill_(float("nan"))
         for j in self.unpack_jobs:
             j["dst"][j["dst_row"]:j["dst_row"] + j["rows"]].fill_(float("nan"))
 
@@ -396,7 +406,11 @@ def sim_run(nets, make_gen, poison=True):
                 assert not pending[i], "a begun exchange was never awaited"
                 return None
             if r[0] == "wait":
-                pending[i].pop(r[1]).unpack()
+                px = pending[i].pop(r[1])
+                if getattr(px, "_sim_late", None) is not None:
+                    px.recv_buf.copy_(px._sim_late)
+                    px._sim_late = None
+                px.unpack()
                 continue
             return r
 
@@ -422,12 +436,17 @@ def sim_run(nets, make_gen, poison=True):
             px.pack()
         for dst, pd in enumerate(pxs):
             ro = np.cumsum([0] + pd.recv_splits)
+            # an overlapped exchange that receives straight into a halo tail (PackedExchange.direct) is held back in a
+            # staging buffer until the shard's wait, like the unpack of the others
+            late = pd.direct and reqs[dst][2] is not None
+            target = torch.empty_like(pd.recv_buf) if late else pd.recv_buf
             for src, ps in enumerate(pxs):
                 if src == dst or not pd.recv_splits[src]:
                     continue
                 so = np.cumsum([0] + ps.send_splits)
                 assert ps.send_splits[dst] == pd.recv_splits[src], (src, dst)
-                pd.recv_buf[ro[src]:ro[src + 1]].copy_(ps.send_buf[so[dst]:so[dst + 1]])
+                target[ro[src]:ro[src + 1]].copy_(ps.send_buf[so[dst]:so[dst + 1]])
+            pd._sim_late = target if late else None
         for i, (px, r) in enumerate(zip(pxs, reqs)):
             if r[2] is None:
                 px.unpack()

@@ -160,6 +160,8 @@ def test_sim_run_serves_waits_per_rank_and_delivers_at_the_wait():
     from facet_graph_convolution_amd import shard
 
     class FakePx:
+        direct = False
+
         def __init__(self, log, name):
             self.log, self.name = log, name
             self.send_splits = self.recv_splits = [0, 0]
