@@ -340,181 +340,6 @@ __global__ __launch_bounds__(NB) void conv_narrow_fwd_mma_kernel(NarrowFwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// FOUR LANES PER NODE (round 3).  One node per lane gives a 122k-node level 1 910 waves for 1 024 SIMDs, each walking its
-// 13 edges in two (forward) or seven (backward) batches of dependent gathers: the kernels waited, the chip was idle.  Here
-// lane `sub` of a node takes the edges e0 + sub, e0 + sub + 4, ... - ONE batch of four for degrees up to 16 - so a level
-// has four times the waves and a node's chain is rowptr -> col -> rows.  Forward: the four partial aggregates are summed
-// with two quad-permute DPP adds and parked in LDS for the same matrix-core product as above (one 16-node tile per wave).
-// Backward: du / dv / dc are sums over lanes anyway - the partial sums of the four lanes need no step of their own.
-// Loops run a wave-uniform trip count with unconditional loads from clamped indices (weights of absent edges are zero).
-// ---------------------------------------------------------------------------------------------
-constexpr int L4_NODES = 64;     // nodes per workgroup
-__device__ __forceinline__ int wave_max_i(int v) {
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-// edges e, e + 4, e + 8, e + 12 of a node with edges [e0, e1) (clamped into the list; a node without edges reads edge 0 of
-// the graph - fgc.h: col has at least one readable entry)
-template <int CIN>
-__device__ __forceinline__ void fetch_edges4(const int* __restrict__ col, const float* __restrict__ ag,
-                                             const float* __restrict__ x, int e, int e0, int e1, float (&g)[4][FGC_M],
-                                             float (&xj)[4][CIN]) {
-    int j[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) j[t] = col[e1 > e0 ? min(e + 4 * t, e1 - 1) : 0];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float* gr = ag + (size_t)j[t] * FGC_AG_LD + 12;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gr);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gr + 4);
-        g[t][0] = g0[0]; g[t][1] = g0[1]; g[t][2] = g0[2]; g[t][3] = g0[3];
-        g[t][4] = g1[0]; g[t][5] = g1[1]; g[t][6] = g1[2]; g[t][7] = g1[3];
-        g[t][8] = gr[8];
-        const float* xr = x + (size_t)j[t] * CIN;
-        if (CIN % 2 == 0) {
-#pragma unroll
-            for (int c = 0; c < CIN; c += 2) {
-                const f32x2n v = *reinterpret_cast<const f32x2n*>(xr + c);
-                xj[t][c] = v[0];
-                xj[t][c + 1] = v[1];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) xj[t][c] = xr[c];
-        }
-    }
-}
-
-template <int CIN, int OT>
-__global__ __launch_bounds__(256) void conv_narrow_fwd_l4_kernel(NarrowFwd p) {
-    constexpr int K9 = FGC_M * CIN;
-    constexpr int KZ = (K9 + 15) / 16 * 16;
-    constexpr int ZS = KZ + 4;
-    constexpr int COUT = OT * 16;
-    constexpr int WS = COUT + 4;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* zt = reinterpret_cast<float*>(smem_raw);            // [L4_NODES][ZS]
-    float* Wk = zt + L4_NODES * ZS;                            // [KZ][WS]
-    int* nodes = reinterpret_cast<int*>(Wk + KZ * WS);         // [L4_NODES] node of every row, -1 = none
-    int* degs = nodes + L4_NODES;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int ns = tid >> 2, sub = tid & 3;                    // node slot of the workgroup, lane of the node
-    // node of this slot: two 32-row tiles per workgroup
-    int i, active;
-    {
-        const int t = blockIdx.x * (L4_NODES / TILE) + (ns >> 5);
-        if (p.tile_list) {
-            active = t < p.n_tiles;
-            i = (active ? p.tile_list[t] : 0) * TILE + (ns & 31);
-        } else {
-            active = 1;
-            i = t * TILE + (ns & 31);
-        }
-        active = active && i < p.n;
-    }
-    for (int t = tid; t < KZ * COUT; t += 256) {
-        const int k = t / COUT, o = t % COUT;
-        Wk[k * WS + o] = k < K9 ? p.W0[((size_t)(k / CIN) * COUT + o) * CIN + k % CIN] : 0.f;
-    }
-    int e0 = 0, e1 = 0;
-    float a[FGC_M];
-#pragma unroll
-    for (int m = 0; m < FGC_M; ++m) a[m] = 0.f;
-    if (active) {
-        e0 = p.rowptr[i];
-        e1 = p.rowptr[i + 1];
-        const float* ar = p.ag + (size_t)i * FGC_AG_LD;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 4);
-        a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
-        a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
-        a[8] = ar[8];
-    }
-    float z[KZ];
-#pragma unroll
-    for (int k = 0; k < KZ; ++k) z[k] = 0.f;
-    const int rounds = (wave_max_i(e1 - e0) + 15) >> 4;        // 16 edges of a node per round (4 lanes x 4)
-    for (int r = 0; r < rounds; ++r) {
-        const int e = e0 + sub + 16 * r;
-        float g[4][FGC_M], xj[4][CIN];
-        fetch_edges4<CIN>(p.col, p.ag, p.x, e, e0, e1, g, xj);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float q[FGC_M];
-            softmax9(a, g[t], q);
-            const float w = e + 4 * t < e1 ? 1.f : 0.f;
-#pragma unroll
-            for (int m = 0; m < FGC_M; ++m) {
-                const float qm = q[m] * w;
-#pragma unroll
-                for (int c = 0; c < CIN; ++c) z[m * CIN + c] = fmaf(qm, xj[t][c], z[m * CIN + c]);
-            }
-        }
-    }
-    // sum of the four lanes of a node (quad permutes: xor 1, xor 2), every lane ends with the whole aggregate
-#pragma unroll
-    for (int k = 0; k < K9; ++k) {
-        z[k] += fgc_dpp_c<0xB1>(z[k]);
-        z[k] += fgc_dpp_c<0x4E>(z[k]);
-    }
-    if (sub == 0) {
-        // (every lane of the quad holds the whole aggregate now: one of them parks the row)
-        float* zr = zt + ns * ZS;
-#pragma unroll
-        for (int k = 0; k < KZ; k += 4) *reinterpret_cast<f32x4*>(zr + k) = f32x4{z[k], z[k + 1], z[k + 2], z[k + 3]};
-        nodes[ns] = active ? i : -1;
-        degs[ns] = e1 - e0;
-    }
-    __syncthreads();       // Wk is shared by the waves; the aggregate rows below are the wave's own 16 nodes
-    const int w0 = wave * 16;
-    if (p.z != nullptr) {
-        const int q4 = p.zld >> 2;
-        for (int f = lane; f < 16 * q4; f += 64) {
-            const int r = f / q4, c4 = f % q4;
-            const int node = nodes[w0 + r];
-            if (node >= 0)
-                *reinterpret_cast<f32x4*>(p.z + (size_t)node * p.zld + c4 * 4) =
-                    *reinterpret_cast<const f32x4*>(zt + (w0 + r) * ZS + c4 * 4);
-        }
-    }
-    f32x4 acc[OT];
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < KZ / 16; ++g) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(zt + (w0 + lr) * ZS + g * 16 + lq * 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot)
-                acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], Wk[(g * 16 + lq * 4 + t) * WS + ot * 16 + lr], acc[ot], 0, 0, 0);
-    }
-    // C layout: column = lr (output channel within the tile), rows = lq * 4 + t: one 4:1 pooling group per lane
-    int nd[4], dd[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        nd[t] = nodes[w0 + lq * 4 + t];
-        dd[t] = degs[w0 + lq * 4 + t];
-    }
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-        const int o = ot * 16 + lr;
-        const float bias_o = p.bias[o];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (nd[t] < 0) continue;
-            float val = acc[ot][t] * (dd[t] > 0 ? 1.0f / (float)dd[t] : 0.f);
-            if (!p.bias_mask || dd[t] > 0) val += bias_o;
-            if (p.act) val = fmaxf(val, 0.f) - p.alpha * fmaxf(-val, 0.f);
-            st_act(p.y, (size_t)nd[t] * COUT + o, val, p.out_bf16);
-            mx = fmaxf(mx, val);
-        }
-        if (p.y_pool && nd[0] >= 0) st_act(p.y_pool, (size_t)(nd[0] >> 2) * COUT + o, mx, p.out_bf16);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward of the first layer (no input gradient): du, dv, dc partial sums per workgroup
 // ---------------------------------------------------------------------------------------------
 struct NarrowBwd {
@@ -672,132 +497,6 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
     }
 }
 
-// four lanes per node (see conv_narrow_fwd_l4_kernel): cout == 32, dz on the matrix cores, one workgroup = 64 nodes
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_narrow_bwd_l4_kernel(NarrowBwd p) {
-    constexpr int K9 = FGC_M * CIN, KZ = (K9 + 15) / 16 * 16, ZS = KZ + 4;
-    __shared__ float red[4][NARROW_PART];
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* dzt = reinterpret_cast<float*>(smem_raw);      // [L4_NODES][ZS]
-    float* Wt = dzt + L4_NODES * ZS;                       // [32][ZS]: Wt[o][m * CIN + c] = W0[m][o][c]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int ns = tid >> 2, sub = tid & 3;
-    const int i = blockIdx.x * L4_NODES + ns;
-    const bool active = i < p.n;
-    int e0 = 0, e1 = 0;
-    float a[FGC_M], xi[CIN];
-#pragma unroll
-    for (int m = 0; m < FGC_M; ++m) a[m] = 0.f;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) xi[c] = 0.f;
-    if (active) {
-        e0 = p.rowptr[i];
-        e1 = p.rowptr[i + 1];
-        const float* ar = p.ag + (size_t)i * FGC_AG_LD;
-#pragma unroll
-        for (int m = 0; m < FGC_M; ++m) a[m] = ar[m];
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) xi[c] = p.x[(size_t)i * CIN + c];
-    }
-    for (int t = tid; t < 32 * KZ; t += 256) {
-        const int o = t / KZ, k = t % KZ;
-        Wt[o * ZS + k] = k < K9 ? p.W0[((size_t)(k / CIN) * 32 + o) * CIN + k % CIN] : 0.f;
-    }
-    __syncthreads();
-    {
-        // dz = W^T s of the wave's 16 nodes: [16 x 32] x [32 x KZ]
-        const int w0 = wave * 16;
-        const int row = min(blockIdx.x * L4_NODES + w0 + lr, p.n - 1);      // rows past n: never used (no edges there)
-        f32x4 av[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) av[g] = *reinterpret_cast<const f32x4*>(p.ds + (size_t)row * 32 + g * 16 + lq * 4);
-#pragma unroll
-        for (int kt = 0; kt < KZ / 16; ++kt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][t], Wt[(g * 16 + lq * 4 + t) * ZS + kt * 16 + lr], acc, 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dzt[(w0 + lq * 4 + t) * ZS + kt * 16 + lr] = acc[t];
-        }
-    }
-    __syncthreads();
-    float dz[FGC_M][CIN];
-    {
-        float dzf[KZ];
-#pragma unroll
-        for (int k = 0; k < KZ; k += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(dzt + ns * ZS + k);     // (the node's four lanes read one row)
-            dzf[k] = v[0]; dzf[k + 1] = v[1]; dzf[k + 2] = v[2]; dzf[k + 3] = v[3];
-        }
-#pragma unroll
-        for (int m = 0; m < FGC_M; ++m)
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) dz[m][c] = active ? dzf[m * CIN + c] : 0.f;
-    }
-    float da[FGC_M], wv[FGC_M][CIN];
-#pragma unroll
-    for (int m = 0; m < FGC_M; ++m) {
-        da[m] = 0.f;
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) wv[m][c] = 0.f;
-    }
-    const int rounds = (wave_max_i(e1 - e0) + 15) >> 4;
-    for (int r = 0; r < rounds; ++r) {
-        const int e = e0 + sub + 16 * r;
-        float g[4][FGC_M], xj[4][CIN];
-        fetch_edges4<CIN>(p.col, p.ag, p.x, e, e0, e1, g, xj);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float q[FGC_M];
-            softmax9(a, g[t], q);
-            float dq[FGC_M], dot = 0.f;
-#pragma unroll
-            for (int m = 0; m < FGC_M; ++m) {
-                float v = 0.f;
-#pragma unroll
-                for (int c = 0; c < CIN; ++c) v = fmaf(dz[m][c], xj[t][c], v);
-                dq[m] = v;
-                dot = fmaf(q[m], v, dot);
-            }
-            const float w = e + 4 * t < e1 ? 1.f : 0.f;
-#pragma unroll
-            for (int m = 0; m < FGC_M; ++m) {
-                const float dl = q[m] * (dq[m] - dot) * w;
-                da[m] += dl;
-#pragma unroll
-                for (int c = 0; c < CIN; ++c) wv[m][c] = fmaf(dl, xj[t][c], wv[m][c]);
-            }
-        }
-    }
-    // block sums in a fixed order: wave butterfly (over the four lanes of a node and the wave's 16 nodes), then the 4 waves
-    auto wave_sum = [](float v) {
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        return v;
-    };
-#pragma unroll
-    for (int m = 0; m < FGC_M; ++m) {
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) {
-            const float u = wave_sum(da[m] * xi[c]);
-            const float v = wave_sum(wv[m][c]);
-            if (lane == 0) {
-                red[wave][m * CIN + c] = u;
-                red[wave][FGC_M * CIN + m * CIN + c] = v;
-            }
-        }
-        const float cc = wave_sum(da[m]);
-        if (lane == 0) red[wave][2 * FGC_M * CIN + m] = cc;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < NARROW_PART; k += 256) {
-        const float v = k < 2 * FGC_M * CIN + FGC_M ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
-        p.part[(size_t)blockIdx.x * NARROW_PART + k] = v;
-    }
-}
-
 // du/dv from their [9][CIN] slots to [9][cin]; dW0[m][o][c] = T[(m * CIN + c) * cout + o]
 __global__ void narrow_finish_kernel(const float* __restrict__ uvc /* [NARROW_PART] */, const float* __restrict__ T,
                                      int CIN, int cin, int cout, float* __restrict__ du, float* __restrict__ dv,
@@ -819,15 +518,6 @@ __global__ void narrow_finish_kernel(const float* __restrict__ uvc /* [NARROW_PA
 // host side
 // ---------------------------------------------------------------------------------------------
 static int narrow_cin_pad(int cin) { return cin; }   // kernels are instantiated for the exact width 1..8
-
-// four lanes per node: the shapes of the matrix-core forms (FGC_NO_NARROW_L4=1: one node per lane)
-static bool narrow_l4_shape(const fgc_conv_desc* d) {
-    return d->cout == 32 && (d->c0 == 6 || d->c0 == 3) && !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') &&
-           !(getenv("FGC_NO_NARROW_L4") && getenv("FGC_NO_NARROW_L4")[0] == '1');
-}
-static bool narrow_bwd_l4(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
-    return narrow_l4_shape(d) && ((uintptr_t)io->ds % 16) == 0;
-}
 
 bool narrow_supported(const fgc_conv_desc* d) {
     if (getenv("FGC_NO_NARROW") && getenv("FGC_NO_NARROW")[0] == '1') return false;
@@ -884,17 +574,6 @@ int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* 
     // the network's first layer (6 -> 32) and its 3-channel sibling: per-node products on the matrix cores
     const bool mma = !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
                      ((uintptr_t)zsave % 16) == 0;
-    if (mma && narrow_l4_shape(d)) {
-        const int tiles = d->tile_list ? d->n_tiles : cdiv(d->n, TILE);
-        if (tiles == 0) return FGC_OK;
-        const int KZ = (FGC_M * d->c0 + 15) / 16 * 16;
-        const size_t smem = ((size_t)L4_NODES * (KZ + 4) + (size_t)KZ * (32 + 4)) * 4 + (size_t)2 * L4_NODES * 4;
-        const dim3 grid(cdiv(tiles, L4_NODES / TILE));
-        if (d->c0 == 6) FGC_LAUNCH("conv_narrow_kernel<fwd>", st, (conv_narrow_fwd_l4_kernel<6, 2>), grid, dim3(256), smem, p);
-        else FGC_LAUNCH("conv_narrow_kernel<fwd>", st, (conv_narrow_fwd_l4_kernel<3, 2>), grid, dim3(256), smem, p);
-        FGC_CHECK_LAUNCH("conv_narrow_fwd_l4_kernel");
-        return FGC_OK;
-    }
     if (mma && d->c0 == 6) return launch_narrow_fwd_mma_t<6, 2>(p, st);
     if (mma && d->c0 == 3) return launch_narrow_fwd_mma_t<3, 2>(p, st);
     return launch_narrow_fwd_z<false>(p, st);
@@ -903,7 +582,7 @@ int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* 
 int narrow_zld(int cin) { return (FGC_M * narrow_cin_pad(cin) + 3) / 4 * 4; }
 size_t narrow_bwd_floats(const fgc_conv_desc* d) {
     const int zld = narrow_zld(d->c0);
-    const size_t nblk = cdiv(d->n, narrow_l4_shape(d) ? L4_NODES : NB);   // (the larger of the two forms' partial counts)
+    const size_t nblk = cdiv(d->n, NB);
     const int splits = narrow_splits(d);
     return (size_t)d->n * zld + 64 + nblk * NARROW_PART + 64 + (size_t)splits * zld * d->cout + 64 +
            (size_t)zld * d->cout + NARROW_PART + 64 + reduce_tmp_floats((int)nblk, NARROW_PART) +
@@ -924,15 +603,6 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     int rc = io->z_saved ? FGC_OK : launch_narrow_fwd_z<true>(pz, st);   // forward left them (FGC_CONV_SAVE_Z)
     if (rc) return rc;
     NarrowBwd pb{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, io->ds, cin, d->cout, part};
-    if (narrow_bwd_l4(d, io)) {
-        const int KZ = (FGC_M * cin + 15) / 16 * 16;
-        const size_t smem = (size_t)(L4_NODES + 32) * (KZ + 4) * 4;
-        const dim3 g4(cdiv(d->n, L4_NODES));
-        if (cin == 6) FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_l4_kernel<6>), g4, dim3(256), smem, pb);
-        else FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_l4_kernel<3>), g4, dim3(256), smem, pb);
-        FGC_CHECK_LAUNCH("conv_narrow_bwd_l4_kernel");
-        return FGC_OK;
-    }
     const dim3 grid(cdiv(d->n, NB));
 #define FGC_NARROW_BWD(C_) \
     case C_: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<C_, false>), grid, dim3(NB), 0, pb); break;
@@ -965,12 +635,11 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
 int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
                       int nb_db, int parts, RedJob* jobs_out, hipStream_t st) {
     const int cin = d->c0, cout = d->cout, zld = narrow_zld(cin), CIN = narrow_cin_pad(cin);
-    const int nblk = cdiv(d->n, narrow_bwd_l4(d, io) ? L4_NODES : NB);            // partials the d-logits stage left
-    const int nblk_plan = cdiv(d->n, narrow_l4_shape(d) ? L4_NODES : NB);         // ... and what the plan reserved for them
+    const int nblk = cdiv(d->n, NB);
     const int splits = narrow_splits(d);
     float* zbuf = scratch;
     float* part = zbuf + (size_t)d->n * zld + 64;
-    float* slab = part + (size_t)nblk_plan * NARROW_PART + 64;
+    float* slab = part + (size_t)nblk * NARROW_PART + 64;
     float* T = slab + (size_t)splits * zld * cout + 64;
     float* uvc = T + (size_t)zld * cout;
     float* rtmp = uvc + NARROW_PART + 64;

@@ -298,7 +298,6 @@ def test_tiny_mesh_one_coarsest_node():
     {"FGC_NO_W8FAST": "1", "FGC_NO_K1M": "1"},                                               # 8-wave generic, VALU logits
     {"FGC_NO_BATCHED": "1", "FGC_NO_FUSED_DS": "1"},                                         # per-layer packs / reductions, ds_db launches
     {"FGC_NO_NARROW_MMA": "1", "FGC_NO_SAVE_Z": "1"},                                        # first layer: vector-ALU products, z recomputed
-    {"FGC_NO_NARROW_L4": "1"},                                                               # first layer: one node per lane instead of four lanes per node
     {"FGC_NO_FUSED_LOSS": "1"},                                                              # normalise / rotate / loss / gradients as seven launches
 ])
 def test_fallback_kernels_pass_the_smoke_check(switches):
