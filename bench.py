@@ -670,7 +670,7 @@ def main(argv=None):
                         "avg_kernel_us": d["avg_kernel_us"], "launch_bytes": d["algorithmic_bytes"],
                         "mfma_tflops": d["achieved"], "mfma_frac": d["frac"],
                         # what the counters say binds the bf16 kernels (the contract's `bound` is the roofline quoted):
-                        "binds": "neither roofline: vector-ALU issue (64-83 % busy, profiles/r2_i_pmc_sq_tables_bf16.txt) and the "
+                        "binds": "neither roofline: vector-ALU issue (64-83 % busy, profiles/r3_pmc_sq_tables_bf16.txt) and the "
                                  "number of resident workgroups (DESIGN.md section 10)",
                         "family_share_of_step": d["share_of_step"],
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
@@ -684,7 +684,7 @@ def main(argv=None):
                         "avg_kernel_us": d["avg_kernel_us"], "launch_flops": d["launch_flops"],
                         "family_share_of_step": d["share_of_step"], "family_frac": d["family_frac"],
                         "binds": "fp32 MFMA + vector ALU, which do not co-issue (71-92 % of the SIMD issue cycles together, "
-                                 "profiles/r2_h_pmc_sq_tables.txt), at five resident workgroups per CU (DESIGN.md section 10)",
+                                 "profiles/r3_pmc_sq_tables.txt), at five resident workgroups per CU (DESIGN.md section 10)",
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
                         "traffic_source": traffic_note,
