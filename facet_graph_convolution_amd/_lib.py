@@ -30,6 +30,10 @@ class ConvDesc(C.Structure):
         ("bias_mask", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("src_rows", C.c_int32), ("max_deg", C.c_int32),
         ("tile_list", C.c_void_p), ("n_tiles", C.c_int32), ("proj_row0", C.c_int32), ("proj_rows", C.c_int32),
         ("flags", C.c_int32),
+        # pair form of a convolution over a 4x-upsampled input (graph.FacetGraph.pairs, include/fgc.h)
+        ("pair_rowptr", C.c_void_p), ("pair_col", C.c_void_p), ("pair_mul", C.c_void_p),
+        ("n_pairs", C.c_int32), ("max_pair_deg", C.c_int32), ("max_pair_in_deg", C.c_int32),
+        ("hc", C.c_void_p),
     ]
 
 
@@ -48,6 +52,7 @@ class ConvBwdIO(C.Structure):
         ("dW0", C.c_void_p), ("db", C.c_void_p), ("du", C.c_void_p), ("dc", C.c_void_p), ("dv", C.c_void_p),
         ("data_tile_list", C.c_void_p), ("n_data_tiles", C.c_int32), ("flags", C.c_int32),
         ("z_saved", C.c_void_p), ("pool_y", C.c_void_p), ("pool_dy", C.c_void_p),
+        ("tpair_rowptr", C.c_void_p), ("tpair_col", C.c_void_p), ("tpair_edge", C.c_void_p), ("dt", C.c_void_p),
     ]
 
 
@@ -68,6 +73,7 @@ _SIGS = {
     "fgc_csr_from_klist": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgc_klist_from_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "fgc_csr_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fgc_pair_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fgc_face_features": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "fgc_faces_large_adj": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "fgc_graph_patch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
@@ -99,6 +105,7 @@ _SIGS = {
                                C.c_void_p]),
     "fgc_conv_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "fgc_conv_bwd_needs_exchange": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO)]),
+    "fgc_conv_uses_pairs": (C.c_int, [C.POINTER(ConvDesc)]),
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_conv_pack": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),

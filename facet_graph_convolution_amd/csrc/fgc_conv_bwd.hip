@@ -19,6 +19,7 @@
 
 #include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
+#include "fgc_conv_pair.h"
 #include "fgc_reduce.h"
 #include "fgc_pack.h"
 
@@ -1838,7 +1839,11 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     };
     w.Wq = take((size_t)g1.passes * opad * g1.kpass);
     w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
-    const int k1n = k1_nodes(d);
+    // pair form (fgc_conv_pair.hip): one db / dc partial per workgroup of its d-logits kernel (k1n fine nodes each), and the
+    // weight-gradient GEMM reduces over the n / 4 coarse rows
+    const bool pairs = pairs_ok(d);
+    const int k1n = pairs ? 4 * pair_blocks_per_wg(d->cout) : k1_nodes(d);
+    const int nred = pairs ? (d->n >> 2) : d->n;
     // one bias-gradient partial per d-logits tile at every size: the fused prologue of the d-logits kernel (which needs
     // exactly that) then also serves meshes beyond 131k nodes (it used to stop there: 4096 partials, ds_db launches)
     w.nb_db = cdiv(d->n, k1n);
@@ -1846,12 +1851,12 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.nb_db = cdiv(d->n, w.rows_per_db);
     w.db_part = take((size_t)w.nb_db * d->cout);
     w.dc_part = take((size_t)cdiv(d->n, k1n) * 12);
-    w.splitW = tn_splits(FGC_M * d->cout + 24, cin, d->n);
+    w.splitW = tn_splits(FGC_M * d->cout + 24, cin, nred);
     if ((d->flags & FGC_CONV_BF16) && tn_bf16_ok(FGC_M * d->cout + 24, d->c0, d->c1)) {
         // the bf16 kernel's workgroups own up to 320 x 64 of the product: one or two per CU in all
         static const int target = getenv("FGC_TNB_WGS") ? atoi(getenv("FGC_TNB_WGS")) : 256;   // (developer knob)
         const int tiles = cdiv(FGC_M * d->cout + 24, TNB_PC) * cdiv(cin, 64);
-        w.splitW = tn_balanced_splits(target / tiles, cdiv(d->n, 256), d->n);
+        w.splitW = tn_balanced_splits(target / tiles, cdiv(nred, 256), nred);
     }
     w.slab = take((size_t)w.splitW * (FGC_M * d->cout + 24) * cin);
     w.rtmp = take(reduce_tmp_floats(w.splitW, (size_t)FGC_M * d->cout * cin) + 2 * reduce_tmp_floats(w.splitW, (size_t)FGC_M * cin) +
@@ -1867,13 +1872,15 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
 static void conv_param_jobs(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, const BwdWorkspace& w, RedJob* jobs) {
     const int cin = d->c0 + d->c1, cout = d->cout;
     const int P = FGC_M * cout, PL = P + 24;
-    const int ns = cdiv(d->n, tn_rows_per_slab(d->n, w.splitW));
+    const bool pairs = pairs_ok(d);
+    const int nred = pairs ? (d->n >> 2) : d->n;
+    const int ns = cdiv(nred, tn_rows_per_slab(nred, w.splitW));
     const size_t sst = (size_t)PL * cin;
     jobs[0] = RedJob{w.slab, sst, ns, P * cin, cin, cin, io->dW0, w.rtmp};
     jobs[1] = RedJob{w.slab + (size_t)P * cin, sst, ns, FGC_M * cin, cin, cin, io->du};
     jobs[2] = RedJob{w.slab + (size_t)(P + 12) * cin, sst, ns, FGC_M * cin, cin, cin, io->dv};
     jobs[3] = RedJob{w.db_part, (size_t)cout, w.nb_db, cout, cout, cout, io->db};
-    jobs[4] = RedJob{w.dc_part, (size_t)12, cdiv(d->n, k1_nodes(d)), 12, 12, FGC_M, io->dc};
+    jobs[4] = RedJob{w.dc_part, (size_t)12, cdiv(d->n, pairs ? 4 * pair_blocks_per_wg(cout) : k1_nodes(d)), 12, 12, FGC_M, io->dc};
 }
 
 }  // namespace fgc
@@ -1946,6 +1953,57 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
 
     const int stages = io->stages ? io->stages : 15;
     const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
+    if (pairs_ok(d)) {
+        // pair form: B1 (s, db, dt, dl, da, dc) on the pair graph, then the data kernel and the weight-gradient GEMM of a
+        // convolution over the n / 4 coarse rows whose gathered operand is dt (one row per pair)
+        FGC_CHECK_ARG(io->tpair_rowptr && io->tpair_col && io->tpair_edge && io->dt && d->max_pair_in_deg > 0,
+                      "fgc_conv_bwd: the pair form needs the transposed pair graph, dt and max_pair_in_deg");
+        FGC_CHECK_ARG(!io->pool_dy && io->data_tile_list == nullptr, "fgc_conv_bwd: the pair form has no pooled output / tile list");
+        FGC_CHECK_ARG(((uintptr_t)io->dt | (uintptr_t)io->dy | (uintptr_t)io->dl | (uintptr_t)io->dag | (uintptr_t)io->r) % 16 == 0,
+                      "fgc_conv_bwd: the pair form needs 16-byte aligned buffers");
+        const int nc = d->n >> 2;
+        if ((stages & 4) && !(io->flags & FGC_CONV_PACKED)) {
+            const size_t tot2 = (size_t)g2.passes * g2.kpass * g2.npad;
+            FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot2, 1024)), dim3(256), 0, d->W0, w.Wpt, cin, cout, cout,
+                       cin, g2.npad, g2.kc, g2.kpass, g2.passes, 1);
+            FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
+        }
+        if (stages & 3) {
+            rc = launch_pair_bwd_logits(d, io, w.db_part, w.dc_part, st);
+            if (rc) return rc;
+        }
+        if (stages & 4) {
+            CoreParams p;
+            fill_core_params(p, g2, nc, io->tpair_rowptr, io->tpair_col, io->tpair_edge, io->dt, nullptr, cout, 0, 0, cin, io->ag,
+                             0, 12, 0, w.Wpt);
+            DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout + 24, d->u, d->v, cin, d->c0, 0, 0,
+                            io->dx0, nullptr, io->accumulate0, 0};
+            const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
+            FGC_CHECK_ARG(w8_erow_supported(p, d->max_pair_in_deg), "fgc_conv_bwd: pair form: unsupported shape (cin=%d cout=%d "
+                          "max_pair_in_deg=%d)", cin, cout, d->max_pair_in_deg);
+            rc = launch_data_w8_erow(p, ep, smem, d->max_pair_in_deg, st);
+            if (rc) return rc;
+        }
+        if (stages & 8) {
+            const int P = FGC_M * cout, PL = P + 24;
+            const int rps = tn_rows_per_slab(nc, w.splitW);
+            const int ns = cdiv(nc, rps);
+            if (cin <= 32)
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
+                           d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
+            else
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<4>, tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns), dim3(256), 0,
+                           io->r, PL, PL, d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
+            FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
+            if (!(io->flags & FGC_CONV_DEFER_REDUCE)) {
+                RedJob jobs[5];
+                conv_param_jobs(d, io, w, jobs);
+                rc = reduce_jobs("reduce:params", jobs, 5, nullptr, st);
+                if (rc) return rc;
+            }
+        }
+        return FGC_OK;
+    }
     FGC_CHECK_ARG(io->data_tile_list == nullptr || (io->n_data_tiles >= 0 && io->n_data_tiles <= cdiv(d->n, TILE)),
                   "fgc_conv_bwd: n_data_tiles=%d outside [0, %d]", io->n_data_tiles, cdiv(d->n, TILE));
     // The deep d-logits kernel of the 32- and 64-wide layers can compute s (and the db partials) in its prologue: one
@@ -2236,7 +2294,8 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
         const int cin = d->c0 + d->c1, cout = d->cout;
         const bool narrow = narrow_supported(d);
         const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
-        if (fwd_ws && fwd_ws[i] && !narrow) {
+        const bool pairs = pairs_ok(d);     // reads W0 / u / v in place: only the data-gradient operand is packed
+        if (fwd_ws && fwd_ws[i] && !narrow && !pairs) {
             const ConvGeom g = conv_geom(cin, cout);
             FGC_CHECK_ARG((uintptr_t)fwd_ws[i] % 16 == 0, "fgc_conv_pack: workspace %d misaligned", i);
             add(PackJob{d->W0, (float*)fwd_ws[i], bf16 ? 4 : 0, cin, cout, cin, cout, g.npad, g.kc, g.kpass, g.passes, 0, 0},
@@ -2254,6 +2313,7 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
                 add(PackJob{d->W0, w.Wpt, 5, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},
                     (size_t)g2.passes * 9 * (g2.npad >> 4) * 512);
             } else {
+            if (!pairs)
             add(PackJob{d->W0, w.Wq, 2, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
                 (size_t)g1.passes * opad * g1.kpass);
             add(PackJob{d->W0, w.Wpt, 1, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},

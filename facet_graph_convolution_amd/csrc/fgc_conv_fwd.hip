@@ -5,6 +5,7 @@
 
 #include "fgc_conv_w8.h"
 #include "fgc_conv_narrow.h"
+#include "fgc_conv_pair.h"
 #include "fgc_pack.h"
 
 namespace fgc {
@@ -277,6 +278,10 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FGC_CHECK_ARG(d->tile_list == nullptr || (d->n_tiles >= 0 && d->n_tiles <= cdiv(d->n, TILE)),
                   "fgc_conv_fwd: n_tiles=%d outside [0, %d]", d->n_tiles, cdiv(d->n, TILE));
 
+    if (pairs_ok(d)) {   // 4x-upsampled input, pair graph given: the layer on its coarse source rows (fgc_conv_pair.hip)
+        FGC_CHECK_ARG(y_pool == nullptr, "fgc_conv_fwd: the pair form has no pooled output");
+        return launch_pair_fwd(d, ag, y, st);
+    }
     const bool narrow = narrow_supported(d);   // cin <= 8: vector-ALU kernel, no packed operand (fgc_conv_narrow.hip)
     const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
     FGC_CHECK_ARG(!bf16 || narrow || (conv_vec4_ok(d) && cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) && d->cout % 32 == 0),

@@ -116,9 +116,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // soft assignment, the aggregation FMAs and every epilogue stay fp32.  FAST shapes only.
 // NT: nodes per workgroup, 32 (eight waves) or 16 (four waves: a half tile each; twice the workgroups, four instead of two
 // resident per CU at the same 16 waves, and twice the packed-weight traffic per node).  NT = 16 needs npad <= 64.
-template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32>
+// EROW (data gradient of the pair form, fgc_conv_pair.hip): the gathered operand has one row per EDGE of the forward graph
+// (the per-pair dt rows), so the row of slot k is the edge id p.eid[e], not the neighbour col[e] >> shift.
+template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32, bool EROW = false>
 __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     static_assert(!BF || FAST, "the bf16 form exists for the fast shapes only");
+    static_assert(!EROW || (DATA && FAST), "rows by edge id: the data-gradient kernel's fast shapes");
     static_assert(NT == 32 || (NT == 16 && FAST && QS == 16), "half tiles: the pipelined 16-slot form only");
     constexpr int TILE = NT, RT = NT / 16, NW = NT / 4, LW = NT == 32 ? 3 : 2, W8_THREADS = NT * 16;   // (shadow the 32-node constants)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             dwave = dmax;
         }
         const int dfill = (dwave + 7) & ~7;
-        int jj[SPL];
+        int jj[SPL], er[SPL];
         f32x4 g0[SPL], g1[SPL];
         float g8[SPL];
 #pragma unroll
@@ -233,8 +236,16 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             const int k = kl + 16 * t;
             // (unconditional, clamped into the node's list: no exec-masked load.  A node WITHOUT edges reads the entry in
             //  front of its empty list: for the padding nodes at the end of a level e0 == nnz, one past the array)
-            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, (unsigned)(d > 0 ? e0 + min(k, d - 1) : max(e0 - 1, 0)) * 4u, 0, 0);
+            const unsigned eo = (unsigned)(d > 0 ? e0 + min(k, d - 1) : max(e0 - 1, 0)) * 4u;
+            const int jv = __builtin_amdgcn_raw_buffer_load_b32(col_rs, eo, 0, 0);
             jj[t] = k < d ? jv : 0;
+            if constexpr (EROW) {
+                const __amdgpu_buffer_rsrc_t eid_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.eid), 0, -1, 0x00020000);
+                const int ev = __builtin_amdgcn_raw_buffer_load_b32(eid_rs, eo, 0, 0);
+                er[t] = k < d ? ev : 0;
+            } else {
+                er[t] = jj[t] >> p.shift;
+            }
         }
 #pragma unroll
         for (int t = 0; t < SPL; ++t) {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
         if constexpr (PIPE) {
             // the row ids go to the table first (slots past the degree: row 0 with weight zero), and the rows of pass 0
             // leave right behind the logit rows
-            s.qbuf[(size_t)node * qnode_stride(QS) + kl * QLD + 9] = __int_as_float(jj[0] >> p.shift);
+            s.qbuf[(size_t)node * qnode_stride(QS) + kl * QLD + 9] = __int_as_float(er[0]);
             wave_lds_sync();
             issue(0, dwave);
         }
@@ -290,10 +301,10 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             *reinterpret_cast<f32x4*>(q) = f32x4{l[0] * inv, l[1] * inv, l[2] * inv, l[3] * inv};
             *reinterpret_cast<f32x4*>(q + 4) = f32x4{l[4] * inv, l[5] * inv, l[6] * inv, l[7] * inv};
             q[8] = l[8] * inv;
-            if (!PIPE) q[9] = __int_as_float(jj[t] >> p.shift);
+            if (!PIPE) q[9] = __int_as_float(er[t]);
             if (DATA && !(FGC_KO & 256)) {
                 const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(de.dl), 0, -1, 0x00020000);
-                const unsigned dof = __umul24((unsigned)p.eid[e0 + k], FGC_DL_LD * 4u);
+                const unsigned dof = __umul24((unsigned)(EROW ? er[t] : p.eid[e0 + k]), FGC_DL_LD * 4u);
                 const f32x4 d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof, 0, 0));
                 const f32x4 d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dl_rs, dof + 16u, 0, 0));
                 dgsum[0] += d0[0]; dgsum[1] += d0[1]; dgsum[2] += d0[2]; dgsum[3] += d0[3];
@@ -623,11 +634,11 @@ static bool w8_half_tiles(const CoreParams& p) {
     return !DATA || mode >= 2 || p.n >= min_n;
 }
 
-template <bool DATA, bool FAST, int QS, bool BF = false>
+template <bool DATA, bool FAST, int QS, bool BF = false, bool EROW = false>
 static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST, QS, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)conv_w8_kernel<DATA, FAST, QS, BF, 32, EROW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
         attr = true;
     }
@@ -637,7 +648,7 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
             const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
             size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
             if (DATA && getenv("FGC_W8_DATA_SMEM_PAD")) smem16 += (size_t)atoi(getenv("FGC_W8_DATA_SMEM_PAD"));   // (developer knob: fewer resident workgroups)
-            FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT>),
+            FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT, EROW>),
                        dim3(2 * core_grid(p)), dim3(NT * 16), smem16, p, fe, de);
             FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles)");
             return FGC_OK;
@@ -645,7 +656,7 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
     }
     smem -= (size_t)TILE * (qnode_stride(KMAX) - qnode_stride(QS)) * 4;     // the caller sized the tile for KMAX slots
     if (BF) smem -= (size_t)TILE * (ZSTRIDE * 4 - ZSTRIDE_BF * 2);   // ... and for the fp32 aggregate tile
-    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF>),
+    FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, 32, EROW>),
                dim3(core_grid(p)), dim3(W8_THREADS), smem, p, fe, de);
     FGC_CHECK_LAUNCH("conv_w8_kernel");
     return FGC_OK;
@@ -675,6 +686,13 @@ int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int m
 int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16) {
     FwdEpilogue fe{};
     return launch_w8<true>(p, fe, ep, smem, max_deg, bf16, st);
+}
+// the gathered rows are indexed by the edge id p.eid (pair form); fast shapes only
+bool w8_erow_supported(const CoreParams& p, int max_deg) { return w8_supported(p, max_deg) && w8_fast(p) && p.eid != nullptr; }
+int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st) {
+    FwdEpilogue fe{};
+    return max_deg <= 16 ? launch_w8f<true, true, 16, false, true>(p, fe, ep, smem, st)
+                         : launch_w8f<true, true, KMAX, false, true>(p, fe, ep, smem, st);
 }
 
 }  // namespace fgc

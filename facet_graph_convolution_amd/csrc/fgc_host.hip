@@ -1,7 +1,9 @@
 // Host-side pieces of libfgc: error text, K-list <-> CSR, transposed CSR.
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "fgc_common.h"
@@ -153,6 +155,50 @@ extern "C" int fgc_csr_transpose(const int32_t* rowptr_h, const int32_t* col_h, 
             tedge_h[pos] = e;
         }
     }
+    return FGC_OK;
+}
+
+// Parent-compressed graph of a level whose conv reads a 4x-upsampled coarse tensor (custom_upsampling, model.py:817-825,
+// feeding custom_conv2d at model.py:905,926).  Every neighbour j of a fine node contributes x_(j >> 2), and the soft
+// assignment of edge (i, j) depends on (i >> 2, j >> 2) only, so the edges of the four siblings of block p = i >> 2 that
+// point into the same coarse row P collapse into ONE pair (p, P) carrying the four multiplicities.  Pairs of a block are
+// stored in ascending P.  Two calls: pcol_h == NULL counts.
+extern "C" int fgc_pair_graph(const int32_t* rowptr_h, const int32_t* col_h, int32_t n, int32_t* prow_h, int32_t* pcol_h,
+                              uint32_t* pmul_h, int64_t* n_pairs_out) {
+    FGC_CHECK_ARG(rowptr_h && col_h && prow_h && n >= 0 && n % 4 == 0, "fgc_pair_graph: bad arguments (n=%d must be a multiple of 4)", n);
+    FGC_CHECK_ARG((pcol_h == nullptr) == (pmul_h == nullptr), "fgc_pair_graph: pcol / pmul must come together");
+    const int32_t nc = n / 4;
+    int64_t np = 0;
+    prow_h[0] = 0;
+    std::vector<std::pair<int32_t, int32_t>> tmp;   // (P, child)
+    for (int32_t b = 0; b < nc; ++b) {
+        tmp.clear();
+        for (int32_t ch = 0; ch < 4; ++ch) {
+            const int32_t i = 4 * b + ch;
+            for (int32_t e = rowptr_h[i]; e < rowptr_h[i + 1]; ++e) {
+                const int32_t j = col_h[e];
+                FGC_CHECK_ARG(j >= 0 && j < n, "fgc_pair_graph: col[%d]=%d outside [0,%d)", e, j, n);
+                tmp.emplace_back(j >> 2, ch);
+            }
+        }
+        std::sort(tmp.begin(), tmp.end());
+        size_t t = 0;
+        while (t < tmp.size()) {
+            const int32_t P = tmp[t].first;
+            uint32_t cnt[4] = {0, 0, 0, 0};
+            for (; t < tmp.size() && tmp[t].first == P; ++t) cnt[tmp[t].second]++;
+            FGC_CHECK_ARG(cnt[0] < 256 && cnt[1] < 256 && cnt[2] < 256 && cnt[3] < 256,
+                          "fgc_pair_graph: more than 255 edges of one node into one coarse row (block %d)", b);
+            if (pcol_h) {
+                pcol_h[np] = P;
+                pmul_h[np] = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16) | (cnt[3] << 24);
+            }
+            ++np;
+        }
+        FGC_CHECK_ARG(np <= INT32_MAX, "fgc_pair_graph: more than 2^31 pairs");
+        prow_h[b + 1] = (int32_t)np;
+    }
+    if (n_pairs_out) *n_pairs_out = np;
     return FGC_OK;
 }
 

@@ -62,6 +62,44 @@ def csr_transpose(rowptr, col):
     return trow, tcol[:nnz], tedge[:nnz]
 
 
+def pair_graph(rowptr, col):
+    """Parent-compressed graph of a level read through a 4x upsampling (fgc_pair_graph, include/fgc.h):
+    (prow int32 [n/4+1], pcol int32 [np], pmul uint32 [np])."""
+    n = len(rowptr) - 1
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    if len(col) == 0:
+        col = np.zeros(1, np.int32)
+    L = _lib.lib()
+    prow = np.empty(n // 4 + 1, dtype=np.int32)
+    cnt = C.c_int64(0)
+    _lib.check(L.fgc_pair_graph(rowptr.ctypes.data, col.ctypes.data, n, prow.ctypes.data, None, None, C.byref(cnt)),
+               "pair_graph")
+    pcol = np.empty(max(cnt.value, 1), dtype=np.int32)
+    pmul = np.empty(max(cnt.value, 1), dtype=np.uint32)
+    _lib.check(L.fgc_pair_graph(rowptr.ctypes.data, col.ctypes.data, n, prow.ctypes.data, pcol.ctypes.data,
+                                pmul.ctypes.data, C.byref(cnt)), "pair_graph")
+    return prow, pcol[:cnt.value], pmul[:cnt.value]
+
+
+class PairGraph:
+    """The pair graph of a level and its transpose, resident in HBM."""
+
+    def __init__(self, rowptr_h, col_h, device):
+        prow, pcol, pmul = pair_graph(rowptr_h, col_h)
+        self.n_pairs = len(pcol)
+        nc = len(prow) - 1
+        self.max_deg = int(np.diff(prow).max()) if nc else 0
+        self.max_in_deg = int(np.bincount(pcol, minlength=1).max()) if self.n_pairs else 0
+        trow, tcol, tedge = csr_transpose(prow, pcol)
+        pad = (lambda a, dt: np.ascontiguousarray(a) if len(a) else np.zeros(1, dt))
+        self.host = dict(prow=prow, pcol=pcol, pmul=pmul, trow=trow, tcol=tcol, tedge=tedge)
+        up = lambda a: torch.from_numpy(a).to(device)
+        self.prow, self.pcol = up(prow), up(pad(pcol, np.int32))
+        self.pmul = up(pad(pmul, np.uint32).view(np.int32))
+        self.trow, self.tcol, self.tedge = up(trow), up(pad(tcol, np.int32)), up(pad(tedge, np.int32))
+
+
 class FacetGraph:
     """One adjacency level resident in HBM: CSR and (lazily) its transpose."""
 
@@ -78,6 +116,15 @@ class FacetGraph:
         self.col = torch.from_numpy(np.ascontiguousarray(self.col_h) if self.nnz else np.zeros(1, np.int32)).to(
             self.device)
         self._t = None
+        self._pairs = None
+
+    def pairs(self):
+        """The pair graph of this level (for a convolution whose input is a 4x-upsampled coarse tensor), built once."""
+        if self._pairs is None:
+            if self.n % 4:
+                raise ValueError("a pair graph needs a multiple of 4 nodes, got %d" % self.n)
+            self._pairs = PairGraph(self.rowptr_h, self.col_h, self.device)
+        return self._pairs
 
     def transposed(self):
         if self._t is None:

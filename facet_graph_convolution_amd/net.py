@@ -166,6 +166,8 @@ class FacetDenoiser:
         # the loss end of an unsharded training step (normalise, rotate the ground truth, sampled loss, both gradients) in
         # two launches instead of seven (fgc_loss_step); FGC_NO_FUSED_LOSS=1: the separate entry points
         self.fused_loss = os.environ.get("FGC_NO_FUSED_LOSS", "0") != "1"
+        # the two up-convolutions on their coarse source rows (pair form, include/fgc.h); FGC_NO_PAIRS=1: the fine form
+        self.pairs = os.environ.get("FGC_NO_PAIRS", "0") != "1"
         # parameter slots
         k = 0
         self.slot = {}
@@ -300,6 +302,7 @@ class FacetDenoiser:
         # descriptors + workspace
         vals, grads = self.params.values, self.params.grads
         descs, ios, ws_f, ws_b = {}, {}, 0, 0
+        pair_ios = []
         layer_flags = {}
         wsf, wsb = {}, {}    # a workspace of its own per layer: packed operands and partial sums stay put for the step
         for lay in self.layers:
@@ -324,6 +327,21 @@ class FacetDenoiser:
                 d.flags |= _lib.CONV_BF16
             layer_flags[lay.name] = d.flags
             descs[lay.name] = d
+            # a layer over a 4x-upsampled input (the two up-convolutions) runs on its COARSE source rows: the pair graph
+            # of its level + the table of transformed coarse rows (include/fgc.h: fgc_conv_desc.pair_rowptr)
+            pg = None
+            if lay.shift == 2 and plan is None and self.pairs:
+                pg = g.pairs()
+                hc = torch.empty(B[lay.x0].shape[0], FGC_M * d.cout, **f)
+                d.pair_rowptr, d.pair_col, d.pair_mul = pg.prow.data_ptr(), pg.pcol.data_ptr(), pg.pmul.data_ptr()
+                d.n_pairs, d.max_pair_deg, d.max_pair_in_deg = pg.n_pairs, pg.max_deg, pg.max_in_deg
+                d.hc = hc.data_ptr()
+                if self.L.fgc_conv_uses_pairs(C.byref(d)):
+                    B["hc_" + lay.name] = hc
+                else:
+                    d.pair_rowptr = d.pair_col = d.pair_mul = d.hc = None
+                    d.n_pairs = d.max_pair_deg = d.max_pair_in_deg = 0
+                    pg = None
             wsf[lay.name] = torch.empty(self.L.fgc_conv_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
             if gt is not None:
                 wsb[lay.name] = torch.empty(self.L.fgc_conv_bwd_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8,
@@ -337,7 +355,16 @@ class FacetDenoiser:
             io.ds, io.dl, io.dag, io.r = (B[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
             gW0, gb, gu, gc, gv = grads[lay.pidx:lay.pidx + 5]
             io.dW0, io.db, io.du, io.dc, io.dv = (t.data_ptr() for t in (gW0, gb, gu, gc, gv))
+            if pg is not None:
+                io.tpair_rowptr, io.tpair_col, io.tpair_edge = pg.trow.data_ptr(), pg.tcol.data_ptr(), pg.tedge.data_ptr()
+                if gt is not None:
+                    need = max(pg.n_pairs, 1) * d.cout
+                    if "dt" not in B or B["dt"].numel() < need:
+                        B["dt"] = torch.empty(need, **f)
+                pair_ios.append(io)
             ios[lay.name] = io
+        for io in pair_ios:
+            io.dt = B["dt"].data_ptr() if "dt" in B else None
         # who writes each activation gradient first (write) / second (accumulate): fixed backward order
         #   g_h1: dconv1 (x1, write) then pool1 backward (accumulate);  g_h2: dconv2 (x1) then pool2 backward
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2"]:

@@ -57,8 +57,21 @@ def make_conv_desc(graph, x0, x1, shift, params, bias_mask, act, alpha):
     return d
 
 
-def conv_fwd(graph, x0, x1, shift, params, bias_mask=True, act=0, alpha=0.1, want_pool=False):
-    """Returns (y [n,cout], y_pool [n/4,cout] or None, ag [(n>>shift),24])."""
+def attach_pairs(d, graph, hc):
+    """Give a descriptor of a layer over a 4x-upsampled input its pair graph and the table of transformed coarse rows
+    hc [(n >> 2), 9 * cout]: the library then runs the layer in the pair form if it qualifies (fgc_conv_uses_pairs)."""
+    pg = graph.pairs()
+    d.pair_rowptr, d.pair_col, d.pair_mul = pg.prow.data_ptr(), pg.pcol.data_ptr(), pg.pmul.data_ptr()
+    d.n_pairs, d.max_pair_deg, d.max_pair_in_deg = pg.n_pairs, pg.max_deg, pg.max_in_deg
+    d.hc = hc.data_ptr()
+    return pg
+
+
+def conv_fwd(graph, x0, x1, shift, params, bias_mask=True, act=0, alpha=0.1, want_pool=False, pairs=None):
+    """Returns (y [n,cout], y_pool [n/4,cout] or None, ag [(n>>shift),24]).
+
+    pairs: a dict - the layer (shift == 2) is described with its pair graph; on return pairs["hc"] holds the transformed
+    coarse rows (pass the same dict to conv_bwd) and pairs["used"] whether the library took the pair form."""
     _req_cuda(x0, x1, *params)
     x0, x1 = _f32c(x0), _f32c(x1)
     params = [_f32c(p) for p in params]
@@ -72,6 +85,10 @@ def conv_fwd(graph, x0, x1, shift, params, bias_mask=True, act=0, alpha=0.1, wan
     d = make_conv_desc(graph, x0, x1, shift, params, bias_mask, act, alpha)
     L = _lib.lib()
     dev = x0.device
+    if pairs is not None:
+        pairs["hc"] = torch.empty(rows, FGC_M * d.cout, dtype=torch.float32, device=dev)
+        attach_pairs(d, graph, pairs["hc"])
+        pairs["used"] = bool(L.fgc_conv_uses_pairs(C.byref(d)))
     ws_bytes = L.fgc_conv_workspace_bytes(C.byref(d))
     ws = _workspace(ws_bytes, dev)
     ag = torch.empty(rows, AG_LD, dtype=torch.float32, device=dev)
@@ -82,7 +99,7 @@ def conv_fwd(graph, x0, x1, shift, params, bias_mask=True, act=0, alpha=0.1, wan
 
 
 def conv_bwd(graph, x0, x1, shift, params, ag, y, dy, bias_mask=True, act=0, alpha=0.1, need_dx=True,
-             dx0=None, dx1=None, acc0=False, acc1=False):
+             dx0=None, dx1=None, acc0=False, acc1=False, pairs=None):
     """Gradient of conv_fwd.  Returns (dx0, dx1, [dW0, db, du, dc, dv]).
 
     dx0/dx1 may be passed in (with acc flags) so that a tensor consumed by two layers
@@ -121,6 +138,14 @@ def conv_bwd(graph, x0, x1, shift, params, ag, y, dy, bias_mask=True, act=0, alp
     io.dx1 = dx1.data_ptr() if dx1 is not None else None
     io.accumulate0, io.accumulate1 = int(bool(acc0)), int(bool(acc1))
     io.dW0, io.db, io.du, io.dc, io.dv = [g.data_ptr() for g in grads]
+    if pairs is not None:
+        pg = attach_pairs(d, graph, pairs["hc"])
+        io.tpair_rowptr, io.tpair_col, io.tpair_edge = pg.trow.data_ptr(), pg.tcol.data_ptr(), pg.tedge.data_ptr()
+        dt = torch.empty(max(pg.n_pairs, 1), cout, **f32)
+        if dl.shape[0] < pg.n_pairs:
+            dl = torch.empty(pg.n_pairs, DL_LD, **f32)
+            io.dl = dl.data_ptr()
+        io.dt = dt.data_ptr()
     ws_bytes = L.fgc_conv_bwd_workspace_bytes(C.byref(d))
     ws = _workspace(ws_bytes, dev, "bwd")
     check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "fgc_conv_bwd")

@@ -67,6 +67,15 @@ int fgc_klist_from_csr(const int32_t* rowptr_h, const int32_t* col_h, int32_t n,
  * edge e = (i -> j); in-edges ordered by e.  trowptr_h [n+1], tcol_h [nnz] (= i), tedge_h [nnz] (= e). */
 int fgc_csr_transpose(const int32_t* rowptr_h, const int32_t* col_h, int32_t n, int32_t* trowptr_h,
                       int32_t* tcol_h, int32_t* tedge_h);
+/* Parent-compressed ("pair") graph of a level whose convolution reads a 4x-upsampled coarse tensor
+ * (custom_upsampling model.py:817-825 feeding custom_conv2d at model.py:905,926; n % 4 == 0).  Neighbour j of a fine
+ * node contributes the coarse row j >> 2, and the soft assignment of edge (i, j) (model.py:74-95) depends on
+ * (i >> 2, j >> 2) only: all edges of the four siblings of block p = i >> 2 into one coarse row P are ONE pair (p, P)
+ * with four multiplicities.  prow_h [n/4 + 1]; pcol_h [n_pairs] = P, ascending inside a block; pmul_h [n_pairs] =
+ * multiplicity of P in the list of child 0 | child 1 << 8 | child 2 << 16 | child 3 << 24 (each < 256).
+ * pcol_h = pmul_h = NULL: count only.  The transposed pair graph is fgc_csr_transpose(prow, pcol, n/4). */
+int fgc_pair_graph(const int32_t* rowptr_h, const int32_t* col_h, int32_t n, int32_t* prow_h, int32_t* pcol_h,
+                   uint32_t* pmul_h, int64_t* n_pairs_out);
 
 /* ------------------------------------------------------------------------------------
  * Host-side mesh preprocessing (CPU, native C++; HOST pointers).  These replace the Python loops that
@@ -184,6 +193,19 @@ typedef struct fgc_conv_desc {
     int32_t proj_row0;        /* assignment logits are computed for source rows [proj_row0, proj_row0 + proj_rows) */
     int32_t proj_rows;        /* 0 = all src_rows (proj_row0 must be 0), < 0 = none */
     int32_t flags;            /* FGC_CONV_PACKED */
+    /* Optional, shift == 2 only: the pair graph of this level (fgc_pair_graph).  With it (and hc) the layer runs on its
+     * COARSE source rows: h_P = W0 x_P once per coarse row (one [n/4, cin] x [cin, M*cout] product instead of a tile
+     * product per fine node), y_i = (1/deg_i) sum_P mult_iP sum_m q_pPm h_Pm - the same sums as the fine form in another
+     * order; fgc_conv_uses_pairs tells whether a descriptor qualifies.  All NULL / 0: the fine form. */
+    const int32_t* pair_rowptr;  /* [n/4 + 1] */
+    const int32_t* pair_col;     /* [n_pairs] */
+    const uint32_t* pair_mul;    /* [n_pairs] */
+    int32_t n_pairs;
+    int32_t max_pair_deg;        /* largest number of pairs of a block */
+    int32_t max_pair_in_deg;     /* largest number of in-pairs of a coarse row (transposed pair graph); 0 = not known:
+                                    forward only.  fgc_conv_bwd needs 1 .. 24 */
+    float* hc;                   /* [src_rows (or n/4), M*cout]: the transformed coarse rows, written by fgc_conv_fwd and
+                                    read again by fgc_conv_bwd (bf16 with FGC_CONV_BF16) */
 } fgc_conv_desc;
 
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
@@ -259,6 +281,13 @@ typedef struct fgc_conv_bwd_io {
      * pool_y, pool_dy: [n / 4, cout], the pooled output and its gradient (bf16 with FGC_CONV_BF16). */
     const float* pool_y;
     const float* pool_dy;
+    /* pair form (fgc_conv_desc.pair_rowptr): the transposed pair graph and scratch for the per-pair output gradients
+     * dt_pP = sum_children mult_iP dy_i / deg_i.  dl then holds one row per PAIR, r one row per COARSE row
+     * ([n/4, M*cout + 24]); ds is not used. */
+    const int32_t* tpair_rowptr; /* [n/4 + 1] */
+    const int32_t* tpair_col;    /* [n_pairs]: block p of the in-pair */
+    const int32_t* tpair_edge;   /* [n_pairs]: its pair id */
+    float* dt;                   /* [n_pairs, cout] (bf16 with FGC_CONV_BF16) */
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
@@ -266,6 +295,10 @@ size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
  * cross-shard edges between its stages; 0 for a first layer over a narrow input (dx0 == NULL, cin <= 8), whose
  * parameter gradients are sums over the owned nodes only (stages 1, 2, 8; stage 4 is empty). */
 int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* io);
+/* 1 if fgc_conv_fwd / fgc_conv_bwd run this descriptor in the pair form: pair graph and hc given, shift == 2, one
+ * source, cin 32, 64 or 128, cout 32 or 64, fp32 storage, max_pair_in_deg <= 24, no partial (tile_list / proj_rows) call.
+ * fgc_conv_bwd then REQUIRES the transposed pair graph and dt in its io.  FGC_NO_PAIRS=1 in the environment: never. */
+int fgc_conv_uses_pairs(const fgc_conv_desc* d);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);
 

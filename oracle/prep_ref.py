@@ -361,3 +361,24 @@ def mesh_patch(vIn, fIn, fAdjIn, faceNum, seed):
     return (vIn[v_old].astype(np.float32), np.asarray(f_out, dtype=np.int64),
             np.asarray([adj_out.get(r, [0] * K) for r in range(nf)], dtype=np.int64), np.asarray(v_old, dtype=np.int64),
             np.asarray(f_old, dtype=np.int64))
+
+
+def pair_graph_ref(rowptr, col):
+    """numpy restatement of the parent-compressed graph (libfgc fgc_pair_graph) of a level whose convolution reads a
+    4x-upsampled coarse tensor (custom_upsampling model.py:817-825 feeding custom_conv2d model.py:905,926): neighbour j
+    contributes coarse row j >> 2 and the soft assignment (model.py:74-95) of edge (i, j) depends on (i >> 2, j >> 2)
+    only, so per block of four siblings the edges collapse to distinct parents with one multiplicity per child.
+    Returns (prow [n/4+1], pcol, pmul uint32 = mult of child 0 | child 1 << 8 | ...), pairs of a block in ascending P."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    n = len(rowptr) - 1
+    nc = n // 4
+    src = np.repeat(np.arange(n), np.diff(rowptr))
+    key = (src >> 2) * max(nc, 1) + (col >> 2)
+    uk, inv = np.unique(key, return_inverse=True)
+    mul = np.zeros((len(uk), 4), dtype=np.uint32)
+    np.add.at(mul, (inv, src & 3), 1)
+    prow = np.zeros(nc + 1, dtype=np.int32)
+    np.cumsum(np.bincount(uk // max(nc, 1), minlength=nc), out=prow[1:])
+    pmul = mul[:, 0] | (mul[:, 1] << 8) | (mul[:, 2] << 16) | (mul[:, 3] << 24)
+    return prow, (uk % max(nc, 1)).astype(np.int32), pmul.astype(np.uint32)
