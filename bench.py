@@ -161,6 +161,23 @@ def kernel_flops(kind, n, nnz, cin, cout, M=9):
     raise ValueError(kind)
 
 
+def pair_kernel_flops(kern, nc, npairs, cin, cout, M=9):
+    """EXECUTED FLOPs of one launch of a layer in the pair form (csrc/fgc_conv_pair.hip): the layer runs on its nc = n / 4
+    coarse rows and npairs (block, parent) pairs, so these are about a quarter of kernel_flops of the same layer - the
+    SURVEY-convention figure, which the line reports beside them (`pair_form`) and never divides a pair launch's time by."""
+    if "pair_transform" in kern:      # h = W0 xc and the two logit tiles
+        return 2.0 * nc * cin * (M * cout + 2 * M)
+    if "pair_fwd" in kern:            # t = sum_m q h, y += mult t
+        return 2.0 * npairs * cout * (M + 4)
+    if "pair_bwd_logits" in kern:     # dt = sum mult s, dq = <dt, h>
+        return 2.0 * npairs * cout * (M + 4)
+    if "conv_w8_kernel<data>" in kern:
+        return kernel_flops("bwd_data", nc, npairs, cin, cout)
+    if "gemm_tn" in kern:
+        return kernel_flops("bwd_weight", nc, npairs, cin, cout)
+    return None
+
+
 def kernel_bytes(kind, layer, n, nnz, cin, cout, elem):
     """Algorithmic HBM bytes of one conv launch (SURVEY.md section 8d convention: every tensor of the layer once, the CSR
     once; weights, logit tables and per-edge scratch are not algorithmic).  An up-convolution reads the coarse tensor:
@@ -576,6 +593,7 @@ def main(argv=None):
 
     roofline = None
     families = None
+    pair_form = None
     kernels = {}
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
     traffic_note = None
@@ -592,6 +610,12 @@ def main(argv=None):
             net.adam_step()
         prof = net.profile_stop()
         dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net.layer_dims()}
+        pdims = net.pair_dims()
+        pair_form = {name: {"coarse_rows": nc, "pairs": npairs, "executed_gflop": 0.0, "us_per_step": 0.0,
+                            # what the SURVEY convention counts for the layer (forward + d-logits + data + weight gradient)
+                            "survey_gflop": round(sum(kernel_flops(k, *dims[name]) for k in
+                                                      ("fwd", "bwd_logits", "bwd_data", "bwd_weight")) / 1e9, 3)}
+                     for name, (nc, npairs) in pdims.items()}
         total_ms = sum(ms for _, ms in prof.values())
         rows = []
         abytes = {}
@@ -613,6 +637,11 @@ def main(argv=None):
                 avg_us = ms / args.steps * 1e3        # interior + boundary launches of one layer: their sum
             fl = kernel_flops(kind, *dims[layer]) if kind else None
             by = kernel_bytes(kind, layer, *dims[layer], 2 if args.dtype == "bf16" else 4) if kind else None
+            if layer in pdims:      # pair form: the FLOPs the launch executes, not the fine-form convention
+                fl = pair_kernel_flops(kern, pdims[layer][0], pdims[layer][1], dims[layer][2], dims[layer][3])
+                by = None
+                pair_form[layer]["executed_gflop"] += (fl or 0.0) * cnt / args.steps / 1e9
+                pair_form[layer]["us_per_step"] += ms / args.steps * 1e3
             if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern):
                 # 32 -> 1024 -> 3 per padded node; the backward recomputes the hidden layer and adds dW and dx
                 fl = 2.0 * dims["conv1"][0] * 1024 * (32 + 3) * (3 if "mlp_bwd_kernel" in kern else 1)
@@ -749,6 +778,9 @@ def main(argv=None):
             "exchange": exchange,
             "roofline": roofline,
             "families": families,
+            # layers run on their coarse source rows (pair form): executed vs SURVEY-convention FLOPs, summed kernel time
+            "pair_form": ({k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                           for k, v in pair_form.items()} if pair_form else None),
             "kernels": kernels,
             "cpu_baseline": cpu,
         }

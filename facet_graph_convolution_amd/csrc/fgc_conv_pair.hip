@@ -53,7 +53,17 @@ int pair_blocks_per_wg(int cout) { return 4 * (64 / (cout / 4)); }
 // load per lane and four k-steps, nothing is packed, and a lane ends up with four CONSECUTIVE columns of one row: one
 // 16-byte store.
 // ---------------------------------------------------------------------------------------------
-template <int CIN>
+// RT: 16-row tiles per wave (they share the weight fragments; RT independent accumulator chains)
+#ifndef FGC_PT_RT
+#define FGC_PT_RT 2
+#endif
+#ifndef FGC_PT_KO
+#define FGC_PT_KO 0   // developer knock-outs: 1 = no stores, 2 = no MFMAs
+#endif
+#ifndef FGC_PT_CG
+#define FGC_PT_CG 10  // column tiles per wave
+#endif
+template <int CIN, int RT>
 __global__ __launch_bounds__(256) void pair_transform_kernel(const float* __restrict__ x, int rows,
                                                             const float* __restrict__ W0, const float* __restrict__ u,
                                                             const float* __restrict__ c, const float* __restrict__ v,
@@ -63,15 +73,17 @@ __global__ __launch_bounds__(256) void pair_transform_kernel(const float* __rest
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
     const int rt = item / ngroups, cg = item - rt * ngroups;
-    if (rt * 16 >= rows) return;
+    if (rt * (16 * RT) >= rows) return;
     const int th = (FGC_M * cout) >> 4;       // column tiles of h; then the a tile and the g tile
     const int tc = th + 2;
     const int ct0 = __builtin_amdgcn_readfirstlane(tc * cg / ngroups), ct1 = __builtin_amdgcn_readfirstlane(tc * (cg + 1) / ngroups);
-    const int row = rt * 16 + lr;
-    const float* xr = x + (size_t)min(row, rows - 1) * CIN + lq * 4;
-    f32x4 xa[KG];
+    f32x4 xa[RT][KG];
 #pragma unroll
-    for (int g = 0; g < KG; ++g) xa[g] = *reinterpret_cast<const f32x4*>(xr + g * 16);
+    for (int r = 0; r < RT; ++r) {
+        const float* xr = x + (size_t)min(rt * (16 * RT) + r * 16 + lr, rows - 1) * CIN + lq * 4;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) xa[r][g] = *reinterpret_cast<const f32x4*>(xr + g * 16);
+    }
     auto loadw = [&](int ct, f32x4 (&w)[KG]) {
         const int cc = min(ct, ct1 - 1);
         const float* wr = cc < th ? W0 + (size_t)(cc * 16 + lr) * CIN : (cc == th ? u : v) + (size_t)min(lr, FGC_M - 1) * CIN;
@@ -80,24 +92,37 @@ __global__ __launch_bounds__(256) void pair_transform_kernel(const float* __rest
         for (int g = 0; g < KG; ++g) w[g] = *reinterpret_cast<const f32x4*>(wr + g * 16);
     };
     const size_t ldh = (size_t)FGC_M * cout;
+    // the logit bias of this lane's four columns of the a tile
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cb[t] = c[min(lq * 4 + t, FGC_M - 1)];
     auto tile = [&](int ct, const f32x4 (&w)[KG]) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < KG; ++g)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][t], xa[g][t], acc, 0, 0, 0);
-        // D[i = column 4 lq + t][j = row lr]
-        if (row >= rows) return;
-        if (ct < th) {
-            *reinterpret_cast<f32x4*>(hc + (size_t)row * ldh + ct * 16 + lq * 4) = acc;
-        } else if (lq < 3) {
-            f32x4 o;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int m = lq * 4 + t;
-                o[t] = m < FGC_M ? acc[t] + (ct == th ? c[m] : 0.f) : 0.f;
+                for (int r = 0; r < RT; ++r) {
+                    if (FGC_PT_KO & 2) asm volatile("" ::"v"(w[g][t]), "v"(xa[r][g][t]));
+                    else acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][t], xa[r][g][t], acc[r], 0, 0, 0);
+                }
+        // D[i = column 4 lq + t][j = row lr]
+        if (FGC_PT_KO & 1) { if (acc[0][0] == 123.f) hc[0] = 1.f; return; }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int row = rt * (16 * RT) + r * 16 + lr;
+            if (row >= rows) continue;
+            if (ct < th) {
+                *reinterpret_cast<f32x4*>(hc + (size_t)row * ldh + ct * 16 + lq * 4) = acc[r];
+            } else if (lq < 3) {
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = lq * 4 + t < FGC_M ? acc[r][t] + (ct == th ? cb[t] : 0.f) : 0.f;
+                *reinterpret_cast<f32x4*>(ag + (size_t)row * FGC_AG_LD + (ct == th ? 0 : 12) + lq * 4) = o;
             }
-            *reinterpret_cast<f32x4*>(ag + (size_t)row * FGC_AG_LD + (ct == th ? 0 : 12) + lq * 4) = o;
         }
     };
     f32x4 w0[KG], w1[KG];
@@ -413,10 +438,10 @@ int launch_pair_fwd(const fgc_conv_desc* d, float* ag, float* y, hipStream_t st)
     const int cin = d->c0, cout = d->cout;
     const int rows = d->src_rows > 0 ? d->src_rows : (d->n >> 2);
     const int tc = (FGC_M * cout) / 16 + 2;
-    const int ngroups = cdiv(tc, 10);
-    const int items = cdiv(rows, 16) * ngroups;
+    const int ngroups = cdiv(tc, FGC_PT_CG);
+    const int items = cdiv(rows, 16 * FGC_PT_RT) * ngroups;
 #define FGC_PT(CIN_)                                                                                                   \
-    FGC_LAUNCH("pair_transform_kernel", st, (pair_transform_kernel<CIN_>), dim3(cdiv(items, 4)), dim3(256), 0, d->x0, rows,  \
+    FGC_LAUNCH("pair_transform_kernel", st, (pair_transform_kernel<CIN_, FGC_PT_RT>), dim3(cdiv(items, 4)), dim3(256), 0, d->x0, rows,  \
                d->W0, d->u, d->c, d->v, cout, d->hc, ag, ngroups)
     if (cin == 32) FGC_PT(32);
     else if (cin == 64) FGC_PT(64);

@@ -1125,3 +1125,8 @@ class FacetDenoiser:
             d = M["descs"][lay.name]
             out.append((lay.name, g.n, g.nnz, d.c0 + d.c1, d.cout))
         return out
+
+    def pair_dims(self):
+        """{layer: (coarse rows, pairs)} of the layers that run in the pair form (include/fgc.h: fgc_conv_uses_pairs)."""
+        M = self._mesh
+        return {name: (d.n >> 2, d.n_pairs) for name, d in M["descs"].items() if self.L.fgc_conv_uses_pairs(C.byref(d))}

@@ -96,3 +96,63 @@ def test_parameter_count_matches_reference():
     assert (len(R.param_spec(False)), n) == (44, 474199)
     nms = sum(int(np.prod(s)) for _, s in R.param_spec(True))
     assert (len(R.param_spec(True)), nms - n) == (52, 204806)
+
+
+# ---- the memory-lean float64 closed form (oracle/model_csr_ref.py): gradient oracle at 100k / 200k facets --------------
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_csr_oracle_conv_matches_the_float64_reference_run(golden_dir, case):
+    """Aggregate-first closed form vs the reference op sequence executed in float64 (conv_*_f64.npz): summation order only."""
+    from oracle import model_csr_ref as C
+    z = _load(golden_dir, "conv_%s_f64.npz" % case)
+    x = torch.tensor(z["x"][0], dtype=torch.float64, requires_grad=True)
+    params = [p.to(torch.float64).requires_grad_(True) for p in R.conv_params(x.shape[1], int(z["cout"]), int(z["seed"]))]
+    y = C.custom_conv2d(x, C.pad_klist(z["adj"]), params, biasMask=(case != "rand_nomask"))
+    np.testing.assert_allclose(y.detach().numpy(), z["y"][0], rtol=0, atol=1e-13)
+    (y * torch.tensor(z["dy"][0], dtype=torch.float64)).sum().backward()
+    for key, t in zip(["dW0", "db", "du", "dc", "dv", "dx"], params + [x]):
+        ref = z[key].reshape(t.shape)
+        # (the float64 fixtures keep their gradients rounded once to fp32: 6e-8 relative)
+        np.testing.assert_allclose(t.grad.numpy(), ref, rtol=0, atol=1.2e-7 * max(1.0, np.abs(ref).max()), err_msg=key)
+
+
+def test_csr_oracle_net_matches_the_float64_reference_run(golden_dir):
+    from oracle import model_csr_ref as C
+    z = _load(golden_dir, "net_ico3_f64.npz")
+    prep = _load(golden_dir, "prep_ico3.npz")
+    params = C.init_params(int(z["seed"]))
+    loss, n_conv = C.train_loss(prep["x"].astype(np.float32), [prep["adj%d" % l] for l in range(3)],
+                                prep["gt"].astype(np.float32), params, z["sample_ind"], z["R"].astype(np.float32))
+    np.testing.assert_allclose(n_conv.detach().numpy(), z["n_conv"], rtol=0, atol=1e-11)
+    assert abs(loss.item() - float(z["loss"])) < 1e-9 * float(z["loss"])
+    loss.backward()
+    for i, p in enumerate(params):
+        ref = z["g%02d" % i]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=0, atol=1.2e-7 * max(np.abs(ref).max(), 1e-3), err_msg="grad %d" % i)
+
+
+def test_csr_oracle_matches_the_reference_shaped_oracle_at_39k_facets():
+    """Both oracles on the 39 200-facet torus of tests/test_gpu_scale.py: the fp32 reference-shaped run sits within its
+    fp32 budget of the float64 closed form (normals 2e-5, loss 1e-4 rel, gradients 2e-3 of each tensor's largest entry -
+    the bounds the GPU tests use)."""
+    from oracle import model_csr_ref as C
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import torus, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = torus(140, 140)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F, 0.2, seed=8), F, V, seed=7)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3)).astype(np.float32)
+    p32 = [p.requires_grad_(True) for p in R.init_params(0)]
+    l32, n32 = R.train_loss(torch.tensor(x.astype(np.float32)), [torch.tensor(a.astype(np.int32)) for a in adjs],
+                            torch.tensor(gt.astype(np.float32)), p32, samp, torch.tensor(Rm))
+    l32.backward()
+    p64 = C.init_params(0)
+    l64, n64 = C.train_loss(x.astype(np.float32), adjs, gt.astype(np.float32), p64, samp, Rm)
+    l64.backward()
+    assert (n32.detach().double() - n64.detach()).abs().max().item() < 2e-5
+    assert abs(l32.item() - l64.item()) < 1e-4 * l64.item()
+    for i, (a, b) in enumerate(zip(p32, p64)):
+        scale = max(b.grad.abs().max().item(), 1e-3)
+        assert (a.grad.double() - b.grad).abs().max().item() < 2e-3 * scale, i
