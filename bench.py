@@ -37,6 +37,7 @@ import socket
 import subprocess
 import sys
 import time
+import faulthandler
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see facet_graph_convolution_amd/__init__.py
 
@@ -70,12 +71,12 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
                     help="storage of the activations: f32 (default, the headline) or bf16 (default of --config c3)")
     ap.add_argument("--graph", type=int, default=-1,
-                    help="1: replay the step from hipGraphs, 0: eager launches, -1 (default): eager on one GPU (the step "
-                         "is GPU-bound, replay is 1 %% faster), hipGraph segments between the exchanges on a facet-sharded "
-                         "run (there the ~110 launches + 17 collective calls of a step are close to its GPU time on the "
-                         "host; falls back to eager if capture fails).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which "
-                         "the package sets at import: with the runtime's pre-built graph packets a replay after a stream "
-                         "synchronise computes garbage on this ROCm stack (DESIGN.md section 6)")
+                    help="1: replay the step from hipGraphs (one GPU: the whole step as one graph; facet-sharded: one graph "
+                         "per stretch of launches between two exchanges, falling back to eager if capture raises), 0 / -1 "
+                         "(default): eager launches - the step is GPU-bound, replay is 1 %% faster on one GPU and 3 - 5 %% on "
+                         "two gloo ranks.  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
+                         "the runtime's pre-built graph packets a replay after a stream synchronise computes garbage on "
+                         "this ROCm stack (DESIGN.md section 6)")
     ap.add_argument("--repeats", type=int, default=5, help="untimed-extra repeats of the K-step block (min / median)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -124,16 +125,29 @@ def self_launch(args, argv):
     cmd = launcher_command(args.gpus, argv, _free_port())
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", FGC_BENCH_ARGV=json.dumps(list(argv)))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for l in proc.stdout.splitlines():
-        if l.startswith("{") and '"metric"' in l:
-            line = l
-        else:
-            print(l, file=sys.stderr)
+    def run_group(cmd, env):
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = None
+        for l in proc.stdout.splitlines():
+            if l.startswith("{") and '"metric"' in l:
+                line = l
+            else:
+                print(l, file=sys.stderr)
+        return proc.returncode, line
+
+    rc, line = run_group(cmd, env)
+    if line is None and args.graph == 1:
+        # The rank group died without a line (a rank killed by a signal leaves nothing to catch in-process).  If the step
+        # was being replayed from hipGraph segments, ONE fresh child group - new processes, never a re-exec - runs the same
+        # bench with eager launches, and the line says so.
+        print("bench: the rank group ended with code %d and no result line; one more group with --graph 0" % rc, file=sys.stderr)
+        argv2 = [a for i, a in enumerate(argv) if a != "--graph" and (i == 0 or argv[i - 1] != "--graph")] + ["--graph", "0"]
+        env2 = dict(env, FGC_BENCH_ARGV=json.dumps(argv2), FGC_BENCH_RETRY_NOTE="first rank group ended with code %d and no "
+                    "result line; this line is from a second, fresh group with --graph 0 (eager launches)" % rc)
+        rc, line = run_group(launcher_command(args.gpus, argv2, _free_port()), env2)
     if line:
         print(line)
-    return proc.returncode if (proc.returncode or line) else 1
+    return rc if (rc or line) else 1
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -412,6 +426,8 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, argv))
 
+    # a rank that dies by a signal (SIGABRT from the runtime, SIGSEGV) leaves its Python stack on stderr
+    faulthandler.enable(file=sys.stderr, all_threads=True)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -481,8 +497,14 @@ def main(argv=None):
     counter = [0]
     auto_graph = args.graph < 0
     args.graph = 0 if auto_graph else args.graph
-    # a facet-sharded training run replays the stretches between its exchanges from hipGraphs unless told otherwise
-    graph_mode = [bool(shard and train and auto_graph)]
+    # A facet-sharded training run times EAGER launches unless --graph 1 asks for hipGraph segments between the exchanges
+    # (3 - 5 % less host time per step on two gloo ranks; the GPU time of a step exceeds the host's either way).  Round 3
+    # made segments the default of N > 1; one full-suite run of that round aborted for a reason its lost output no longer
+    # tells, a rank that dies by a signal takes the driver's whole scaling run with it, and RCCL
+    # next to graph replays has never run on a real node: the default is the path with nothing unknown in it.
+    graph_mode = [bool(shard and train and args.graph == 1)]
+    if graph_mode[0]:
+        args.graph = 0          # (segments, not the whole-step graph of the single-GPU --graph 1)
 
     def step():
         k = counter[0] % nsteps_total
@@ -771,6 +793,7 @@ def main(argv=None):
             "ms_per_step_min": min(rep_ms),
             "ms_per_step_median": float(np.median(rep_ms)),
             "hipgraph_replay": hipgraph,
+            "retry_note": os.environ.get("FGC_BENCH_RETRY_NOTE"),
             "forward_only_ms": fwd_ms,
             "forward_only_facets_per_s": F_total / (fwd_ms * 1e-3),
             "hbm_roofline_frac_whole_step": step_bytes / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),

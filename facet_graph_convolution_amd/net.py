@@ -114,16 +114,15 @@ _HIP = [None]
 
 
 def _graph_node_count(g):
-    """Nodes of a captured (not yet instantiated) torch.cuda.CUDAGraph(keep_graph=True), through hipGraphGetNodes; -1 if
-    the runtime cannot say."""
-    try:
-        if _HIP[0] is None:
-            _HIP[0] = C.CDLL("libamdhip64.so")
-        n = C.c_size_t(0)
-        rc = _HIP[0].hipGraphGetNodes(C.c_void_p(g.raw_cuda_graph()), None, C.byref(n))
-        return int(n.value) if rc == 0 else -1
-    except (OSError, AttributeError, RuntimeError):
-        return -1
+    """Nodes of a captured (not yet instantiated) torch.cuda.CUDAGraph(keep_graph=True), through hipGraphGetNodes.  Raises
+    when the runtime cannot say: whether a stretch of the schedule is a graph at all must not be a guess."""
+    if _HIP[0] is None:
+        _HIP[0] = C.CDLL("libamdhip64.so")
+    n = C.c_size_t(0)
+    rc = _HIP[0].hipGraphGetNodes(C.c_void_p(g.raw_cuda_graph()), None, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("hipGraphGetNodes failed (%d): cannot tell whether a schedule segment has launches" % rc)
+    return int(n.value)
 
 
 class _ConvLayer:
@@ -812,6 +811,7 @@ class FacetDenoiser:
         tile lists, same message sizes every step), so the requests recorded with the graphs are replayed as they are."""
         gen = make_gen()
         segs = []
+        self.segment_nodes = getattr(self, "segment_nodes", [])
         while True:
             g = torch.cuda.CUDAGraph(keep_graph=True)
             # (thread_local: the collective back end's watchdog thread may query its events while this thread captures)
@@ -821,11 +821,13 @@ class FacetDenoiser:
                 except StopIteration:
                     req = None
             # a stretch WITHOUT launches (two requests back to back, or nothing behind the last one) is no graph at all:
-            # an empty hipGraph is never instantiated or replayed
-            if _graph_node_count(g) == 0:
+            # an empty hipGraph is never instantiated or replayed (segment_nodes keeps the counts for the tests)
+            nodes = _graph_node_count(g)
+            if nodes == 0:
                 g = None
             else:
                 g.instantiate()
+            self.segment_nodes.append(nodes)
             segs.append((g, req))
             if req is None:
                 return segs

@@ -265,3 +265,31 @@ def test_config5_multiscale_500k_facets_in_eight_shards():
                 assert np.isfinite(got).all()
                 np.testing.assert_allclose(got, full[P.lo:P.hi], rtol=0, atol=1e-6, err_msg="head of level %d" % lvl)
         g.check("500k facets multi-scale, 8 shards")
+
+
+def test_no_schedule_segment_is_an_empty_graph_and_back_to_back_requests_run(golden_dir, monkeypatch):
+    """The invariant the segment replay rests on (net._capture_segments): the runtime answers how many nodes a captured
+    stretch holds (hipGraphGetNodes - a failure raises, nothing is guessed), a stretch without launches - the fused sharded
+    loss end issues ("call", samples) and ("sum", table) back to back, and nothing follows the last all-reduce - is
+    recorded as no graph at all, and every graph that IS instantiated and replayed holds at least one node.  The schedule
+    with those back-to-back requests then replays twice, bit-identical to eager."""
+    from facet_graph_convolution_amd import net as netmod
+    monkeypatch.setenv("FGC_SPLIT_MIN_TILES", "0")
+    x, adjs, gt = _prep(golden_dir, "ico3")
+    z = np.load(os.path.join(golden_dir, "net_ico3.npz"))
+    ref, nets = _step_pair(x, adjs, gt, 2, "f32", z["sample_ind"], z["R"])
+    assert all(n.fused_loss for n in nets)
+    _eager_then_segments(ref, nets, "f32")
+    for n in nets:
+        fwd, bwd = n._graph_fb[0]
+        segs = fwd + bwd
+        assert len(n.segment_nodes) == len(segs) and min(n.segment_nodes) >= 0
+        for (g, req), nodes in zip(segs, n.segment_nodes):
+            assert (g is None) == (nodes == 0), "a segment with %d nodes was %s" % (nodes, "kept" if g is not None else "dropped")
+            if g is not None:
+                assert netmod._graph_node_count(g) == nodes >= 1
+        # the back-to-back pair of the fused sharded loss end is there, as a stretch without a graph
+        kinds = [(req[0] if req else None, g is None) for g, req in bwd]
+        i = kinds.index(("call", False)) if ("call", False) in kinds else kinds.index(("call", True))
+        assert kinds[i + 1] == ("sum", True), kinds[i:i + 2]
+        assert bwd[-1][1] is None and bwd[-1][0] is None, "nothing is launched behind the last all-reduce"
