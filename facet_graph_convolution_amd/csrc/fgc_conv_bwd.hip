@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
 // i.e. MFMA e owns output rows p0 + 4*i + e (i = MFMA row index).  One dwordx4 of A and one of X per lane feed
 // 16 MFMAs (a 64 x 64 tile per wave, 4 rows of K per step); no LDS staging, no barrier in the loop.
 // grid (P tiles * Q tiles, row splits); the 4 waves of a workgroup interleave the k-steps of their split and are
-// summed through LDS in a fixed order; partials go to slab[split][P][Q], reduced by reduce_slabs.
+// summed through LDS in a fixed order; partials go to slab[split][P][Q], reduced by reduce_jobs.
 // ---------------------------------------------------------------------------------------------
 template <bool VEC4>
 __device__ __forceinline__ void tn_load(const float* __restrict__ A, int lda, int P, const float* __restrict__ x0,

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(LinOperand A, LinOperand 
     __shared__ float As[LIN_BK][LIN_BM + 4];   // k-major: the MFMA A fragment reads 16 consecutive rows of one k
     __shared__ float Bs[LIN_BK][LIN_BN + 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int m0 = blockIdx.y * LIN_BM, n0 = blockIdx.x * LIN_BN;
+    const int m0 = blockIdx.x * LIN_BM, n0 = blockIdx.y * LIN_BN;   // (row tiles on x: up to 2^31 of them)
     const int split = blockIdx.z;
     const int kper = ((K + ksplit - 1) / ksplit + LIN_BK - 1) / LIN_BK * LIN_BK;
     const int k0 = split * kper, k1 = min(K, k0 + kper);
@@ -117,7 +117,7 @@ extern "C" int fgc_lin_fwd(const float* x, int32_t n, int32_t cin, int32_t cout,
     FGC_CHECK_ARG(x && W && y && n > 0 && cin > 0 && cout > 0, "fgc_lin_fwd: bad arguments (n=%d cin=%d cout=%d)", n, cin, cout);
     hipStream_t st = (hipStream_t)stream;
     const LinOperand A{x, cin, 1, n, cin, 0}, B{W, cout, 1, cin, cout, 0};
-    FGC_LAUNCH("lin_gemm_kernel:fwd", st, lin_gemm_kernel, dim3(cdiv(cout, LIN_BN), cdiv(n, LIN_BM), 1), dim3(256), 0, A, B, n,
+    FGC_LAUNCH("lin_gemm_kernel:fwd", st, lin_gemm_kernel, dim3(cdiv(n, LIN_BM), cdiv(cout, LIN_BN), 1), dim3(256), 0, A, B, n,
                cout, cin, 1, b, y, (long)cout, 0L);
     FGC_CHECK_LAUNCH("fgc_lin_fwd");
     return FGC_OK;
@@ -133,7 +133,7 @@ extern "C" int fgc_lin_bwd(const float* x, const float* dy, int32_t n, int32_t c
     hipStream_t st = (hipStream_t)stream;
     if (dx) {   // dx = dy . W^T: B(k = output channel, j = input channel) = W[j, k]
         const LinOperand A{dy, cout, 1, n, cout, 0}, B{W, 1, cout, cout, cin, 0};
-        FGC_LAUNCH("lin_gemm_kernel:dx", st, lin_gemm_kernel, dim3(cdiv(cin, LIN_BN), cdiv(n, LIN_BM), 1), dim3(256), 0, A, B, n,
+        FGC_LAUNCH("lin_gemm_kernel:dx", st, lin_gemm_kernel, dim3(cdiv(n, LIN_BM), cdiv(cin, LIN_BN), 1), dim3(256), 0, A, B, n,
                    cin, cout, 1, (const float*)nullptr, dx, (long)cin, 0L);
     }
     // [dW; db] = [x | 1]^T . dy: A(i = input channel or the ones row, k = node) = x[k, i]
@@ -142,7 +142,7 @@ extern "C" int fgc_lin_bwd(const float* x, const float* dy, int32_t n, int32_t c
     float* slab = (float*)workspace;
     float* tmp = slab + (size_t)ns * count;
     const LinOperand A{x, 1, cin, cin, n, 1}, B{dy, cout, 1, n, cout, 0};
-    FGC_LAUNCH("lin_gemm_kernel:dW", st, lin_gemm_kernel, dim3(cdiv(cout, LIN_BN), cdiv(cin + 1, LIN_BM), ns), dim3(256), 0, A, B,
+    FGC_LAUNCH("lin_gemm_kernel:dW", st, lin_gemm_kernel, dim3(cdiv(cin + 1, LIN_BM), cdiv(cout, LIN_BN), ns), dim3(256), 0, A, B,
                cin + 1, cout, n, ns, (const float*)nullptr, slab, (long)cout, (long)count);
     FGC_CHECK_LAUNCH("fgc_lin_bwd");
     const RedJob jobs[2] = {

@@ -87,8 +87,12 @@ __global__ void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c;
         const float* p = x + (r * group) * c + (int)(i % c);
+        // tf.reduce_max propagates NaN (fmaxf would drop it): a NaN entry makes the group's maximum NaN
         float m = p[0];
-        for (int k = 1; k < group; ++k) m = fmaxf(m, p[(int64_t)k * c]);
+        for (int k = 1; k < group; ++k) {
+            const float v = p[(int64_t)k * c];
+            m = (v > m || v != v) ? v : m;
+        }
         y[i] = m;
     }
 }
@@ -100,7 +104,9 @@ __global__ void pool_bwd_kernel(const float* __restrict__ x, const float* __rest
         const float m = y[i];
         float ne = 0.f;
         for (int k = 0; k < group; ++k) ne += x[b + (int64_t)k * c] == m ? 1.f : 0.f;
-        const float g = dy[i] / ne;      // tf.reduce_max: the gradient is split evenly over the entries equal to the maximum
+        // tf.reduce_max: the gradient is split evenly over the entries equal to the maximum (none equals a NaN maximum:
+        // no entry gets a gradient, like tf's equal() mask - and no 0 / 0)
+        const float g = ne > 0.f ? dy[i] / ne : 0.f;
         for (int k = 0; k < group; ++k) {
             const int64_t o = b + (int64_t)k * c;
             const float v = x[o] == m ? g : 0.f;

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(MLP_THREADS, CO <= 3 ? 4 : 3) void mlp_fwd_kernel(c
 //   dhid = (dy W2^T) * lrelu'(h);  dW2 = hact^T dy;  db1 = sum dhid;  dW1 = x^T dhid;  dx = dhid W1^T
 // Each workgroup owns the hidden-column range [hc0, hc0+hcw) (blockIdx.y) and walks row tiles
 // blockIdx.x, +gridDim.x, ...; parameter-gradient partials stay in registers over the walk and are
-// written once per workgroup as slabs (reduced in fixed order by reduce_slabs_kernel).
+// written once per workgroup as slabs (reduced in fixed order by reduce_jobs).
 // ---------------------------------------------------------------------------------------------
 // MLP_BWD_MT = cin tiles of 16, MLP_BWD_CTW = column tiles per wave per workgroup (hcw = 4 waves * CTW * 16 columns).
 // <2,4> serves the 32-wide head of the network; <4,2> and <8,1> the 64/128-wide multi-scale heads (model.py:894-899,

@@ -5,7 +5,7 @@
 namespace fgc {
 constexpr int RED_GROUP = 64;  // slabs summed by one workgroup
 constexpr int RED_MAX_JOBS = 48;  // one launch pair covers the parameter gradients of a whole network (5 per layer)
-// floats of scratch reduce_slabs needs
+// floats of scratch a job of reduce_jobs with this many slabs may need
 static inline size_t reduce_tmp_floats(int nslabs, size_t count) {
     size_t tot = 0;
     int g = nslabs;
@@ -15,21 +15,18 @@ static inline size_t reduce_tmp_floats(int nslabs, size_t count) {
     }
     return tot;
 }
-// out[(j / in_ld) * out_ld + j % in_ld] = sum_s slab[s * count + j]   for j % in_ld < out_ld
-int reduce_slabs(const char* what, const float* slab, int nslabs, size_t count, int in_ld, int out_ld, float* out,
-                 float* tmp, hipStream_t st);
-
-// Several independent reductions in (at most) two launches: stage 1 sums groups of RED_GROUP slabs of every job, stage
-// 2 sums the group results (jobs with a single group finish in stage 1).  Same summation order as reduce_slabs, so the
-// results are bit-identical to one reduce_slabs call per job for nslabs <= RED_GROUP (lists of up to 2 * RED_GROUP slabs are
-// summed by ONE workgroup per column block in a single stage, longer than RED_GROUP^2 in proportionally larger groups:
-// still a fixed order, a different one).
+// Several independent reductions in (at most) two launches:
+//   out[(j / in_ld) * out_ld + j % in_ld] = sum_s slab[s * stride + j]   for j % in_ld < out_ld
+// Stage 1 sums groups of RED_GROUP slabs of every job, stage 2 sums the group results (jobs with a single group finish in
+// stage 1; lists of up to 2 * RED_GROUP slabs are summed by ONE workgroup per column block in a single stage, longer than
+// RED_GROUP^2 in proportionally larger groups).  One entry point, one fixed order per (nslabs, count): the per-layer and the
+// whole-network calls of a parameter gradient agree bit for bit.
 struct RedJob {
     const float* slab;   // element j of slab s at slab[s * stride + j]
     size_t stride;
     int nslabs;
     int count;           // elements per slab that are reduced (j < count)
-    int in_ld, out_ld;   // as in reduce_slabs
+    int in_ld, out_ld;   // row lengths of the slab and of `out` (see above)
     float* out;
     float* tmp = nullptr;   // when set: this job's (and the following jobs') stage-1 results go here instead of
                             // continuing in the scratch of the job before

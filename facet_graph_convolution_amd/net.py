@@ -281,6 +281,7 @@ class FacetDenoiser:
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
         B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
         B["loss"] = torch.zeros(2, **f)
+        B["loss_gacc"] = torch.zeros(n0, 3, **f)     # scatter accumulator of the fused loss end (zero between steps)
         self._alloc_step_inputs(B, COST_SAMPLES)
         if gtt is not None:
             B["gt"] = gtt.contiguous().to(dev)
@@ -616,19 +617,20 @@ class FacetDenoiser:
                 samp = B["sample_ind_local"]
                 _lib.check(L.fgc_loss_shard_samples(_p(B["y0"]), count, _p(B["gt"]), _p(B["R"]) if rotate else None,
                                                     _p(samp) if samp.numel() else None, samp.numel(), ns_total,
-                                                    _p(B["g_nconv"]), _p(LS), self._st()), "loss samples")
+                                                    _p(B["loss_gacc"]), _p(LS), self._st()), "loss samples")
             # (a rank's own samples are a list of another length - and another tensor - every step: a request of its own,
             #  served by an eager call also when the schedule is replayed from hipGraphs)
             yield ("call", shard_samples)
             yield ("sum", LS[4:])
-            _lib.check(L.fgc_loss_shard_rows(_p(B["y0"]), n0, count, ns_total, _p(LS), _p(B["g_nconv"]), _p(B["nconv"]),
+            _lib.check(L.fgc_loss_shard_rows(_p(B["y0"]), n0, count, ns_total, _p(LS), _p(B["loss_gacc"]), _p(B["nconv"]),
                                              _p(B["g_y0"]), _p(B["loss"]), st), "loss rows")
         elif fused:
-            # normalise + rotate the sampled ground-truth rows + loss + both gradients: two launches (g_nconv is the
-            # zero-on-entry / zero-on-exit scratch of fgc_loss_step)
+            # normalise + rotate the sampled ground-truth rows + loss + both gradients: two launches (loss_gacc is the
+            # zero-on-entry / zero-on-exit scratch of fgc_loss_step: a buffer of its own, never the g_nconv that the
+            # separate-launch path fills with real gradients)
             samp = B["sample_ind"]
             _lib.check(L.fgc_loss_step(_p(B["y0"]), n0, _p(B["abs_part"]), B["abs_part"].numel(), _p(B["gt"]),
-                                       _p(B["R"]) if rotate else None, _p(samp), samp.numel(), _p(B["g_nconv"]),
+                                       _p(B["R"]) if rotate else None, _p(samp), samp.numel(), _p(B["loss_gacc"]),
                                        _p(B["nconv"]), _p(B["g_y0"]), _p(B["loss"]), _p(B["loss_scratch"]), st), "loss step")
         elif self.sharded:
             # a rank's own samples are a list of another length (and another tensor) every step: these few launches are

@@ -50,6 +50,19 @@ def test_self_launch_without_a_gpu_fails_loudly():
                        timeout=300, cwd=REPO)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "one more group" not in r.stderr          # eager launches are the default of N > 1: nothing to retry without
+
+
+def test_self_launch_retries_once_with_eager_launches_when_a_graph_run_dies_without_a_line():
+    """--graph 1 (hipGraph segments between the exchanges): a rank group that ends without a result line is followed by ONE
+    fresh child group with --graph 0.  Here both groups die (no GPU): the parent says what it did and fails."""
+    env = dict(os.environ, FGC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--nu", "12", "--nv", "10", "--no-cpu-baseline", "--graph", "1"], env=env, capture_output=True,
+                       text=True, timeout=600, cwd=REPO)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.stderr.count("one more group with --graph 0") == 1
 
 
 def test_algorithmic_bytes_match_the_survey_formula():

@@ -56,12 +56,13 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert [c["kind"] for c in per].count("all_reduce") == 3 and all(c["ms"] > 0 for c in per)
     assert j["world_check"] == {"backend": "gloo", "ranks_in_all_reduce": 2, "get_world_size": 2}
     assert set(j["startup_s"]) == {"preprocess_s", "shard_plan_s", "bind_s"}
-    # the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
+    # the default of N > 1 is eager launches (bench.py: graph_mode); no retry happened
+    assert "eager launches" in j["config"]["parallelism"] and j["hipgraph_replay"] is None and j["retry_note"] is None
+    # --graph 1: the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
     # (stretches WITH launches only: two requests back to back leave no graph; this small mesh splits no layer)
-    assert j["hipgraph_replay"]["graphs_per_step"] >= 12 and j["hipgraph_replay"]["eager_ms_per_step"] > 0
-    assert j["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in j["config"]["parallelism"]
-    e = _bench(["--gpus", "2", "--graph", "0"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
-    assert "eager launches" in e["config"]["parallelism"] and e["hipgraph_replay"] is None
+    e = _bench(["--gpus", "2", "--graph", "1"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
+    assert e["hipgraph_replay"]["graphs_per_step"] >= 12 and e["hipgraph_replay"]["eager_ms_per_step"] > 0
+    assert e["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in e["config"]["parallelism"]
     # weak scaling: the mesh has twice the facets of the single-GPU run
     assert "%d facets" % (2 * 48 * 40 * 2) in j["config"]["workload"]
 
