@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
     const PackJob& j = J.job[q];
     const int bid = blockIdx.x - j.block0;
     const int nb = (q + 1 < J.njobs ? J.job[q + 1].block0 : J.nblocks) - j.block0;
-    if (j.kind == 6) pack_logit_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);
+    if (j.kind == 7) pack_plain_bf16_body(j.W0, (unsigned short*)j.dst, j.kdim, bid, nb);
+    else if (j.kind == 6) pack_logit_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);
     else if (j.kind >= 4) pack_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.kdim, j.ncols, j.npad, j.passes,
                                                 j.kind - 4, bid, nb);
     else if (j.kind == 2) pack_logit_weight_body(j.W0, j.dst, j.cin, j.cout, j.opad, j.kc, j.kpass, j.passes, bid, nb);
@@ -1962,7 +1963,15 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         FGC_CHECK_ARG(((uintptr_t)io->dt | (uintptr_t)io->dy | (uintptr_t)io->dl | (uintptr_t)io->dag | (uintptr_t)io->r) % 16 == 0,
                       "fgc_conv_bwd: the pair form needs 16-byte aligned buffers");
         const int nc = d->n >> 2;
-        if ((stages & 4) && !(io->flags & FGC_CONV_PACKED)) {
+        if ((stages & 4) && !(io->flags & FGC_CONV_PACKED) && bf16) {
+            PackJobs J;
+            J.njobs = 1;
+            const size_t t2 = (size_t)g2.passes * 9 * (g2.npad >> 4) * 512;
+            J.job[0] = PackJob{d->W0, w.Wpt, 5, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0};
+            J.nblocks = cdiv((int)t2, 1024);
+            FGC_LAUNCH("pack_many_kernel", st, pack_many_kernel, dim3(J.nblocks), dim3(256), 0, J);
+            FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
+        } else if ((stages & 4) && !(io->flags & FGC_CONV_PACKED)) {
             const size_t tot2 = (size_t)g2.passes * g2.kpass * g2.npad;
             FGC_LAUNCH("pack_weight_kernel", st, pack_weight_kernel, dim3(cdiv((int)tot2, 1024)), dim3(256), 0, d->W0, w.Wpt, cin, cout, cout,
                        cin, g2.npad, g2.kc, g2.kpass, g2.passes, 1);
@@ -1979,16 +1988,30 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout + 24, d->u, d->v, cin, d->c0, 0, 0,
                             io->dx0, nullptr, io->accumulate0, 0};
             const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
-            FGC_CHECK_ARG(w8_erow_supported(p, d->max_pair_in_deg), "fgc_conv_bwd: pair form: unsupported shape (cin=%d cout=%d "
-                          "max_pair_in_deg=%d)", cin, cout, d->max_pair_in_deg);
-            rc = launch_data_w8_erow(p, ep, smem, d->max_pair_in_deg, st);
+            FGC_CHECK_ARG(w8_erow_supported(p, d->max_pair_in_deg) && (!bf16 || w8_bf16_supported(p, d->max_pair_in_deg)),
+                          "fgc_conv_bwd: pair form: unsupported shape (cin=%d cout=%d max_pair_in_deg=%d)", cin, cout,
+                          d->max_pair_in_deg);
+            rc = launch_data_w8_erow(p, ep, smem, d->max_pair_in_deg, st, bf16);
             if (rc) return rc;
         }
         if (stages & 8) {
             const int P = FGC_M * cout, PL = P + 24;
             const int rps = tn_rows_per_slab(nc, w.splitW);
             const int ns = cdiv(nc, rps);
-            if (cin <= 32)
+            if (bf16 && tn_bf16_ok(PL, d->c0, 0)) {
+                const unsigned short* r16 = (const unsigned short*)io->r;
+                const unsigned short* h0 = (const unsigned short*)d->x0;
+                const int npc = cdiv(PL, TNB_PC);
+                if (cin % 64 == 0)
+                    FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<4>), tn_grid(npc * (cin / 64), ns), dim3(TNB_THREADS), 0, r16, PL,
+                               PL, h0, (const unsigned short*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
+                else
+                    FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<2>), tn_grid(npc * (cin / 32), ns), dim3(TNB_THREADS), 0, r16, PL,
+                               PL, h0, (const unsigned short*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
+            } else if (bf16) {
+                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<4, true>), tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns), dim3(256), 0,
+                           io->r, PL, PL, d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
+            } else if (cin <= 32)
                 FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
                            d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
             else
@@ -2294,7 +2317,10 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
         const int cin = d->c0 + d->c1, cout = d->cout;
         const bool narrow = narrow_supported(d);
         const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
-        const bool pairs = pairs_ok(d);     // reads W0 / u / v in place: only the data-gradient operand is packed
+        const bool pairs = pairs_ok(d);     // reads W0 / u / v in place (bf16 storage: a bf16 copy of W0); backward packs only
+                                            // the data-gradient operand
+        if (fwd_ws && fwd_ws[i] && pairs && bf16)
+            add(PackJob{d->W0, (float*)fwd_ws[i], 7, cin, cout, FGC_M * cout * cin, 0, 0, 0, 0, 0, 0, 0}, (size_t)FGC_M * cout * cin);
         if (fwd_ws && fwd_ws[i] && !narrow && !pairs) {
             const ConvGeom g = conv_geom(cin, cout);
             FGC_CHECK_ARG((uintptr_t)fwd_ws[i] % 16 == 0, "fgc_conv_pack: workspace %d misaligned", i);
@@ -2308,6 +2334,7 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
             const ConvGeom g1 = conv_geom(cin, cout), g2 = conv_geom(cout, cin);
             const int opad = (cout + 15) / 16 * 16;
             if (bf16) {
+                if (!pairs)
                 add(PackJob{d->W0, w.Wq, 6, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
                     (size_t)g1.passes * (cout >> 5) * 18 * 512);
                 add(PackJob{d->W0, w.Wpt, 5, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},

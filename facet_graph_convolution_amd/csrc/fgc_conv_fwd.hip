@@ -280,7 +280,7 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
 
     if (pairs_ok(d)) {   // 4x-upsampled input, pair graph given: the layer on its coarse source rows (fgc_conv_pair.hip)
         FGC_CHECK_ARG(y_pool == nullptr, "fgc_conv_fwd: the pair form has no pooled output");
-        return launch_pair_fwd(d, ag, y, st);
+        return launch_pair_fwd(d, ag, y, workspace, st);
     }
     const bool narrow = narrow_supported(d);   // cin <= 8: vector-ALU kernel, no packed operand (fgc_conv_narrow.hip)
     const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;

@@ -12,8 +12,9 @@ static inline int pair_num_wgs(const fgc_conv_desc* d) {
     const int bpg = pair_blocks_per_wg(d->cout);
     return ((d->n >> 2) + bpg - 1) / bpg;
 }
-// h = W0 x and the logit table for source rows [0, rows), then y for all blocks
-int launch_pair_fwd(const fgc_conv_desc* d, float* ag, float* y, hipStream_t st);
+// h = W0 x and the logit table for source rows [0, rows), then y for all blocks.  FGC_CONV_BF16: the forward workspace
+// holds a bf16 copy of W0 (M * cout * cin elements; written here unless FGC_CONV_PACKED, else by fgc_conv_pack)
+int launch_pair_fwd(const fgc_conv_desc* d, float* ag, float* y, void* workspace, hipStream_t st);
 // s, db partials, per-pair dt and dl, da, dc partials
 int launch_pair_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* db_part, float* dc_part,
                            hipStream_t st);

@@ -36,8 +36,9 @@ bool pairs_ok(const fgc_conv_desc* d) {
     // (cin: the column count of the data-gradient product, whose kernel wants 2, 4 or 8 column tiles)
     if (!(d->c0 == 32 || d->c0 == 64 || d->c0 == 128) || !(d->cout == 32 || d->cout == 64)) return false;
     if (d->n_pairs <= 0 || d->max_pair_deg <= 0 || d->max_pair_in_deg < 0 || d->max_pair_in_deg > KMAX) return false;
-    if (d->tile_list || d->proj_rows != 0 || d->proj_row0 != 0) return false;
-    if (d->flags & FGC_CONV_BF16) return false;
+    // partial forward calls of a facet-sharded caller: "transform + logits of these source rows only" (a tile list of no
+    // tiles) and "the rest of the rows, then every block" (no tile list); there is no interior / boundary split of blocks
+    if (d->tile_list && d->n_tiles != 0) return false;
     const size_t rows = d->src_rows > 0 ? (size_t)d->src_rows : (size_t)(d->n >> 2);
     if (rows * FGC_M * d->cout * 4 >= 0xFFFFFFFFull || (size_t)d->n_pairs * d->cout * 4 >= 0xFFFFFFFFull) return false;
     if (((uintptr_t)d->x0 | (uintptr_t)d->hc) % 16) return false;
@@ -135,6 +136,107 @@ __global__ __launch_bounds__(256) void pair_transform_kernel(const float* __rest
     }
 }
 
+// bf16 storage (FGC_CONV_BF16): x and hc are bf16, the weights a bf16 copy of W0 in its native [9 cout, cin] layout
+// (pair_weight_bf16_floats of the forward workspace, written by the pack launch), the product on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The two logit tiles stay on the fp32 MFMA with fp32 u / v against
+// the widened x (the logit table is fp32 in the bf16 network, include/fgc.h): a lane's eight consecutive k of a 32-deep
+// step are eight 4-deep fp32 steps whose k assignment (k = 32 ks + 8 lq + j) is the same in both operands.
+template <int CIN, int RT>
+__global__ __launch_bounds__(256) void pair_transform_bf16_kernel(const unsigned short* __restrict__ x, int rows,
+                                                                 const unsigned short* __restrict__ Wb,
+                                                                 const float* __restrict__ u, const float* __restrict__ c,
+                                                                 const float* __restrict__ v, int cout,
+                                                                 unsigned short* __restrict__ hc, float* __restrict__ ag,
+                                                                 int ngroups) {
+    constexpr int KS = CIN / 32;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    const int rt = item / ngroups, cg = item - rt * ngroups;
+    if (rt * (16 * RT) >= rows) return;
+    const int th = (FGC_M * cout) >> 4;
+    const int tc = th + 2;
+    const int ct0 = __builtin_amdgcn_readfirstlane(tc * cg / ngroups), ct1 = __builtin_amdgcn_readfirstlane(tc * (cg + 1) / ngroups);
+    const int hend = min(ct1, th);            // h tiles of this wave: [ct0, hend)
+    u32x4 xb[RT][KS];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const unsigned short* xr = x + (size_t)min(rt * (16 * RT) + r * 16 + lr, rows - 1) * CIN + lq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xb[r][ks] = *reinterpret_cast<const u32x4*>(xr + ks * 32);
+    }
+    auto loadw = [&](int ct, u32x4 (&w)[KS]) {
+        const int cc = max(min(ct, hend - 1), 0);
+        const unsigned short* wr = Wb + (size_t)(cc * 16 + lr) * CIN + lq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = *reinterpret_cast<const u32x4*>(wr + ks * 32);
+    };
+    const size_t ldh = (size_t)FGC_M * cout;
+    auto tile = [&](int ct, const u32x4 (&w)[KS]) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[ks]), __builtin_bit_cast(bf16x8, xb[r][ks]),
+                                                                acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int row = rt * (16 * RT) + r * 16 + lr;
+            if (row < rows) *reinterpret_cast<u32x2*>(hc + (size_t)row * ldh + ct * 16 + lq * 4) = f4_to_bf4(acc[r]);
+        }
+    };
+    if (ct0 < hend) {
+        u32x4 w0[KS], w1[KS];
+        loadw(ct0, w0);
+        for (int ct = ct0; ct < hend; ct += 2) {
+            loadw(ct + 1, w1);
+            tile(ct, w0);
+            loadw(ct + 2, w0);
+            if (ct + 1 < hend) tile(ct + 1, w1);
+        }
+    }
+    // the logit tiles of this wave's column group (fp32 MFMA)
+    for (int ct = max(ct0, th); ct < ct1; ++ct) {
+        const float* wr = (ct == th ? u : v) + (size_t)min(lr, FGC_M - 1) * CIN + lq * 8;
+        f32x4 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(wr + ks * 32), wb = *reinterpret_cast<const f32x4*>(wr + ks * 32 + 4);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const f32x4 xlo = bf4_to_f4(u32x2{xb[r][ks][0], xb[r][ks][1]}), xhi = bf4_to_f4(u32x2{xb[r][ks][2], xb[r][ks][3]});
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xlo[j], acc[r], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j], xhi[j], acc[r], 0, 0, 0);
+            }
+        }
+        if (lq < 3) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int row = rt * (16 * RT) + r * 16 + lr;
+                if (row >= rows) continue;
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = lq * 4 + t;
+                    o[t] = m < FGC_M ? acc[r][t] + (ct == th ? c[min(m, FGC_M - 1)] : 0.f) : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(ag + (size_t)row * FGC_AG_LD + (ct == th ? 0 : 12) + lq * 4) = o;
+            }
+        }
+    }
+}
+
+// bf16 copy of W0 [9 cout, cin] for pair_transform_bf16_kernel (workgroup `bid` of `nb`, 256 threads each)
+__global__ __launch_bounds__(256) void pair_weight_bf16_kernel(const float* __restrict__ W0, unsigned short* __restrict__ Wb, int count) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) Wb[i] = f_to_bf(W0[i]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // block kernels: LPB = cout / 4 lanes per block (four channels each), 64 / LPB blocks per wave, four waves
 // ---------------------------------------------------------------------------------------------
@@ -220,12 +322,32 @@ __device__ __forceinline__ void pair_softmax_chunk(const PairParams& p, float* q
 }
 
 // the nine 16-byte pieces (four channels of every m) of coarse row P for this lane
-template <int COUT>
-__device__ __forceinline__ void pair_load_h(__amdgpu_buffer_rsrc_t h_rs, const float* qk, unsigned laneoff, f32x4 (&h)[FGC_M]) {
-    const unsigned off = __umul24((unsigned)__float_as_int(qk[9]), (unsigned)(FGC_M * COUT * 4)) + laneoff;
+// (BF: the table is bf16, FGC_CONV_BF16 - eight bytes per piece, kept as loaded and widened where they are used)
+template <bool BF> struct PairH { typedef f32x4 T; };
+template <> struct PairH<true> { typedef u32x2 T; };
+template <int COUT, bool BF>
+__device__ __forceinline__ void pair_load_h(__amdgpu_buffer_rsrc_t h_rs, const float* qk, unsigned laneoff,
+                                            typename PairH<BF>::T (&h)[FGC_M]) {
+    constexpr unsigned ESZ = BF ? 2u : 4u;
+    const unsigned off = __umul24((unsigned)__float_as_int(qk[9]), (unsigned)(FGC_M * COUT) * ESZ) + laneoff;
 #pragma unroll
-    for (int m = 0; m < FGC_M; ++m)
-        h[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, off + (unsigned)(m * COUT * 4), 0, 0));
+    for (int m = 0; m < FGC_M; ++m) {
+        if constexpr (BF) h[m] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(h_rs, off + (unsigned)(m * COUT) * ESZ, 0, 0));
+        else h[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, off + (unsigned)(m * COUT * 4), 0, 0));
+    }
+}
+__device__ __forceinline__ f32x4 pair_h(const f32x4& v) { return v; }
+__device__ __forceinline__ f32x4 pair_h(const u32x2& v) { return bf4_to_f4(v); }
+// four channels of an activation row: fp32 (16 bytes) or bf16 (8 bytes)
+template <bool BF>
+__device__ __forceinline__ f32x4 pair_ld4(const float* base, size_t idx) {
+    if constexpr (BF) return bf4_to_f4(*reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx));
+    else return *reinterpret_cast<const f32x4*>(base + idx);
+}
+template <bool BF>
+__device__ __forceinline__ void pair_st4(float* base, size_t idx, const f32x4& v) {
+    if constexpr (BF) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) = f4_to_bf4(v);
+    else *reinterpret_cast<f32x4*>(base + idx) = v;
 }
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -234,7 +356,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int COUT>
+template <int COUT, bool BF>
 __global__ __launch_bounds__(256) void pair_fwd_kernel(PairParams p) {
     constexpr int LPB = COUT / 4, BPW = 64 / LPB, BPG = 4 * BPW;
     __shared__ __attribute__((aligned(16))) float qs[BPG * PQ_STRIDE];
@@ -257,18 +379,19 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(PairParams p) {
     const int dmax = wave_max_i32(d);
     float* qb = qs + (wave * BPW + bl) * PQ_STRIDE;
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hc), 0, -1, 0x00020000);
-    const unsigned laneoff = (unsigned)kl * 16u;
+    const unsigned laneoff = (unsigned)kl * (BF ? 8u : 16u);
+    typedef typename PairH<BF>::T HT;
     f32x4 yv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto consume = [&](const float* qk, const f32x4 (&h)[FGC_M]) {
+    auto consume = [&](const float* qk, const HT (&h)[FGC_M]) {
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk), q1 = *reinterpret_cast<const f32x4*>(qk + 4);
         const float q8 = qk[8];
         const unsigned mu = __float_as_uint(qk[10]);
-        f32x4 t = q0[0] * h[0];
-        t += q0[1] * h[1]; t += q0[2] * h[2]; t += q0[3] * h[3];
-        t += q1[0] * h[4]; t += q1[1] * h[5]; t += q1[2] * h[6]; t += q1[3] * h[7];
-        t += q8 * h[8];
+        f32x4 t = q0[0] * pair_h(h[0]);
+        t += q0[1] * pair_h(h[1]); t += q0[2] * pair_h(h[2]); t += q0[3] * pair_h(h[3]);
+        t += q1[0] * pair_h(h[4]); t += q1[1] * pair_h(h[5]); t += q1[2] * pair_h(h[6]); t += q1[3] * pair_h(h[7]);
+        t += q8 * pair_h(h[8]);
         yv[0] += (float)(mu & 0xffu) * t;
         yv[1] += (float)((mu >> 8) & 0xffu) * t;
         yv[2] += (float)((mu >> 16) & 0xffu) * t;
@@ -279,13 +402,13 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(PairParams p) {
         pair_softmax_chunk<LPB>(p, qb, kl, e0, d, k0, bc, a);
         pair_wave_sync();
         const int cnt = min(dmax - k0, PQ_SLOTS);
-        f32x4 ha[FGC_M], hb[FGC_M];
-        pair_load_h<COUT>(h_rs, qb, laneoff, ha);
+        HT ha[FGC_M], hb[FGC_M];
+        pair_load_h<COUT, BF>(h_rs, qb, laneoff, ha);
         int k = 0;
         for (; k + 2 <= cnt; k += 2) {
-            pair_load_h<COUT>(h_rs, qb + (k + 1) * PQ_LD, laneoff, hb);
+            pair_load_h<COUT, BF>(h_rs, qb + (k + 1) * PQ_LD, laneoff, hb);
             consume(qb + k * PQ_LD, ha);
-            pair_load_h<COUT>(h_rs, qb + min(k + 2, PQ_SLOTS - 1) * PQ_LD, laneoff, ha);
+            pair_load_h<COUT, BF>(h_rs, qb + min(k + 2, PQ_SLOTS - 1) * PQ_LD, laneoff, ha);
             consume(qb + (k + 1) * PQ_LD, hb);
         }
         if (k < cnt) consume(qb + k * PQ_LD, ha);
@@ -301,7 +424,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(PairParams p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f) - p.alpha * fmaxf(-o[t], 0.f);
         }
-        *reinterpret_cast<f32x4*>(p.y + (size_t)(4 * b + i) * COUT + kl * 4) = o;
+        pair_st4<BF>(p.y, (size_t)(4 * b + i) * COUT + kl * 4, o);
     }
 }
 
@@ -315,7 +438,7 @@ __device__ __forceinline__ float pair_block_sum(float v) {
     return v;
 }
 
-template <int COUT>
+template <int COUT, bool BF>
 __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
     constexpr int LPB = COUT / 4, BPW = 64 / LPB, BPG = 4 * BPW;
     constexpr int RED_LD = COUT + 12;
@@ -342,9 +465,9 @@ __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
     for (int i = 0; i < 4; ++i) {
         const int dg = p.rowptr[4 * bc + i + 1] - p.rowptr[4 * bc + i];
         const size_t o = (size_t)(4 * bc + i) * COUT + kl * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(p.dy + o);
+        f32x4 g = pair_ld4<BF>(p.dy, o);
         if (p.act) {
-            const f32x4 yy = *reinterpret_cast<const f32x4*>(p.yact + o);
+            const f32x4 yy = pair_ld4<BF>(p.yact, o);
 #pragma unroll
             for (int t = 0; t < 4; ++t) g[t] *= yy[t] > 0.f ? 1.f : (yy[t] < 0.f ? p.alpha : 0.f);
         }
@@ -355,11 +478,12 @@ __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
     const int dmax = wave_max_i32(d);
     float* qb = qs + (wave * BPW + bl) * PQ_STRIDE;
     const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hc), 0, -1, 0x00020000);
-    const unsigned laneoff = (unsigned)kl * 16u;
+    const unsigned laneoff = (unsigned)kl * (BF ? 8u : 16u);
+    typedef typename PairH<BF>::T HT;
     float da[FGC_M];
 #pragma unroll
     for (int m = 0; m < FGC_M; ++m) da[m] = 0.f;
-    auto consume = [&](int kk, const float* qk, const f32x4 (&h)[FGC_M]) {
+    auto consume = [&](int kk, const float* qk, const HT (&hh)[FGC_M]) {
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk), q1 = *reinterpret_cast<const f32x4*>(qk + 4);
         const float q[FGC_M] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], qk[8]};
         const unsigned mu = __float_as_uint(qk[10]);
@@ -368,14 +492,16 @@ __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
         dt += (float)((mu >> 16) & 0xffu) * sv[2];
         dt += (float)(mu >> 24) * sv[3];
         const bool live = kk < d;
-        if (live) *reinterpret_cast<f32x4*>(p.dt + (size_t)(e0 + kk) * COUT + kl * 4) = dt;
+        if (live) pair_st4<BF>(p.dt, (size_t)(e0 + kk) * COUT + kl * 4, dt);
+        if constexpr (BF) dt = bf4_to_f4(f4_to_bf4(dt));      // (the data kernel gathers the stored, rounded rows)
         float dq[FGC_M], sum = 0.f;
 #pragma unroll
         for (int m = 0; m < FGC_M; ++m) {
-            float v = dt[0] * h[m][0];
-            v = fmaf(dt[1], h[m][1], v);
-            v = fmaf(dt[2], h[m][2], v);
-            v = fmaf(dt[3], h[m][3], v);
+            const f32x4 h = pair_h(hh[m]);
+            float v = dt[0] * h[0];
+            v = fmaf(dt[1], h[1], v);
+            v = fmaf(dt[2], h[2], v);
+            v = fmaf(dt[3], h[3], v);
             dq[m] = pair_block_sum<LPB>(v);
             sum = fmaf(q[m], dq[m], sum);
         }
@@ -397,13 +523,13 @@ __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
         pair_softmax_chunk<LPB>(p, qb, kl, e0, d, k0, bc, a);
         pair_wave_sync();
         const int cnt = min(dmax - k0, PQ_SLOTS);
-        f32x4 ha[FGC_M], hb[FGC_M];
-        pair_load_h<COUT>(h_rs, qb, laneoff, ha);
+        HT ha[FGC_M], hb[FGC_M];
+        pair_load_h<COUT, BF>(h_rs, qb, laneoff, ha);
         int k = 0;
         for (; k + 2 <= cnt; k += 2) {
-            pair_load_h<COUT>(h_rs, qb + (k + 1) * PQ_LD, laneoff, hb);
+            pair_load_h<COUT, BF>(h_rs, qb + (k + 1) * PQ_LD, laneoff, hb);
             consume(k0 + k, qb + k * PQ_LD, ha);
-            pair_load_h<COUT>(h_rs, qb + min(k + 2, PQ_SLOTS - 1) * PQ_LD, laneoff, ha);
+            pair_load_h<COUT, BF>(h_rs, qb + min(k + 2, PQ_SLOTS - 1) * PQ_LD, laneoff, ha);
             consume(k0 + k + 1, qb + (k + 1) * PQ_LD, hb);
         }
         if (k < cnt) consume(k0 + k, qb + k * PQ_LD, ha);
@@ -434,20 +560,49 @@ __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
     }
 }
 
-int launch_pair_fwd(const fgc_conv_desc* d, float* ag, float* y, hipStream_t st) {
+int launch_pair_fwd(const fgc_conv_desc* d, float* ag, float* y, void* workspace, hipStream_t st) {
     const int cin = d->c0, cout = d->cout;
-    const int rows = d->src_rows > 0 ? d->src_rows : (d->n >> 2);
+    const int all_rows = d->src_rows > 0 ? d->src_rows : (d->n >> 2);
+    // source rows this call transforms (fgc_conv_desc.proj_row0 / proj_rows, as for the logit table of the fine form)
+    const int row0 = d->proj_rows ? d->proj_row0 : 0;
+    const int rows = d->proj_rows ? (d->proj_rows < 0 ? 0 : d->proj_rows) : all_rows;
+    FGC_CHECK_ARG(row0 >= 0 && row0 + rows <= all_rows, "fgc_conv_fwd: pair form: rows [%d, %d) outside the %d source rows", row0,
+                  row0 + rows, all_rows);
+    const bool blocks = !(d->tile_list && d->n_tiles == 0);
+    const size_t esz = (d->flags & FGC_CONV_BF16) ? 2 : 4;
+    const float* x0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->x0) + (size_t)row0 * cin * esz);
+    float* hc0 = reinterpret_cast<float*>(reinterpret_cast<char*>(d->hc) + (size_t)row0 * FGC_M * cout * esz);
+    float* ag0 = ag + (size_t)row0 * FGC_AG_LD;
     const int tc = (FGC_M * cout) / 16 + 2;
     const int ngroups = cdiv(tc, FGC_PT_CG);
     const int items = cdiv(rows, 16 * FGC_PT_RT) * ngroups;
+    const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
+    if (rows == 0) {
+        // nothing to transform in this call
+    } else if (bf16) {
+        unsigned short* Wb = (unsigned short*)workspace;
+        if (!(d->flags & FGC_CONV_PACKED)) {
+            const int count = FGC_M * cout * cin;
+            FGC_LAUNCH("pair_weight_bf16_kernel", st, pair_weight_bf16_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, d->W0, Wb, count);
+        }
+#define FGC_PTB(CIN_)                                                                                                  \
+    FGC_LAUNCH("pair_transform_kernel", st, (pair_transform_bf16_kernel<CIN_, FGC_PT_RT>), dim3(cdiv(items, 4)), dim3(256), 0,      \
+               (const unsigned short*)x0, rows, Wb, d->u, d->c, d->v, cout, (unsigned short*)hc0, ag0, ngroups)
+        if (cin == 32) FGC_PTB(32);
+        else if (cin == 64) FGC_PTB(64);
+        else FGC_PTB(128);
+#undef FGC_PTB
+    } else {
 #define FGC_PT(CIN_)                                                                                                   \
-    FGC_LAUNCH("pair_transform_kernel", st, (pair_transform_kernel<CIN_, FGC_PT_RT>), dim3(cdiv(items, 4)), dim3(256), 0, d->x0, rows,  \
-               d->W0, d->u, d->c, d->v, cout, d->hc, ag, ngroups)
+    FGC_LAUNCH("pair_transform_kernel", st, (pair_transform_kernel<CIN_, FGC_PT_RT>), dim3(cdiv(items, 4)), dim3(256), 0, x0, rows,  \
+               d->W0, d->u, d->c, d->v, cout, hc0, ag0, ngroups)
     if (cin == 32) FGC_PT(32);
     else if (cin == 64) FGC_PT(64);
     else FGC_PT(128);
 #undef FGC_PT
+    }
     FGC_CHECK_LAUNCH("fgc_conv_fwd/pair_transform");
+    if (!blocks) return FGC_OK;
     PairParams p{};
     p.nb = d->n >> 2;
     p.prow = d->pair_rowptr;
@@ -462,8 +617,13 @@ int launch_pair_fwd(const fgc_conv_desc* d, float* ag, float* y, hipStream_t st)
     p.alpha = d->alpha;
     p.y = y;
     const int grid = pair_num_wgs(d);
-    if (cout == 32) FGC_LAUNCH("pair_fwd_kernel", st, (pair_fwd_kernel<32>), dim3(grid), dim3(256), 0, p);
-    else FGC_LAUNCH("pair_fwd_kernel", st, (pair_fwd_kernel<64>), dim3(grid), dim3(256), 0, p);
+    if (bf16) {
+        if (cout == 32) FGC_LAUNCH("pair_fwd_kernel", st, (pair_fwd_kernel<32, true>), dim3(grid), dim3(256), 0, p);
+        else FGC_LAUNCH("pair_fwd_kernel", st, (pair_fwd_kernel<64, true>), dim3(grid), dim3(256), 0, p);
+    } else {
+        if (cout == 32) FGC_LAUNCH("pair_fwd_kernel", st, (pair_fwd_kernel<32, false>), dim3(grid), dim3(256), 0, p);
+        else FGC_LAUNCH("pair_fwd_kernel", st, (pair_fwd_kernel<64, false>), dim3(grid), dim3(256), 0, p);
+    }
     FGC_CHECK_LAUNCH("fgc_conv_fwd/pair_fwd");
     return FGC_OK;
 }
@@ -488,8 +648,13 @@ int launch_pair_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, fl
     p.db_part = db_part;
     p.dc_part = dc_part;
     const int grid = pair_num_wgs(d);
-    if (d->cout == 32) FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<32>), dim3(grid), dim3(256), 0, p);
-    else FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<64>), dim3(grid), dim3(256), 0, p);
+    if (d->flags & FGC_CONV_BF16) {
+        if (d->cout == 32) FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<32, true>), dim3(grid), dim3(256), 0, p);
+        else FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<64, true>), dim3(grid), dim3(256), 0, p);
+    } else {
+        if (d->cout == 32) FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<32, false>), dim3(grid), dim3(256), 0, p);
+        else FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<64, false>), dim3(grid), dim3(256), 0, p);
+    }
     FGC_CHECK_LAUNCH("fgc_conv_bwd/pair_logits");
     return FGC_OK;
 }

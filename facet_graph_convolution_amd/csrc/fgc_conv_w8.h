@@ -33,8 +33,8 @@ bool w8_supported(const CoreParams& p, int max_deg);
 bool w8_bf16_supported(const CoreParams& p, int max_deg);
 int launch_fwd_w8(const CoreParams& p, const FwdEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
 int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
-// pair form: rows of the gathered operand by edge id (p.eid); fp32
+// pair form: rows of the gathered operand by edge id (p.eid)
 bool w8_erow_supported(const CoreParams& p, int max_deg);
-int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st);
+int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
 
 }  // namespace fgc

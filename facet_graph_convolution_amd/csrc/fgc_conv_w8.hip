@@ -689,8 +689,11 @@ int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int
 }
 // the gathered rows are indexed by the edge id p.eid (pair form); fast shapes only
 bool w8_erow_supported(const CoreParams& p, int max_deg) { return w8_supported(p, max_deg) && w8_fast(p) && p.eid != nullptr; }
-int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st) {
+int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16) {
     FwdEpilogue fe{};
+    if (bf16)
+        return max_deg <= 16 ? launch_w8f<true, true, 16, true, true>(p, fe, ep, smem, st)
+                             : launch_w8f<true, true, KMAX, true, true>(p, fe, ep, smem, st);
     return max_deg <= 16 ? launch_w8f<true, true, 16, false, true>(p, fe, ep, smem, st)
                          : launch_w8f<true, true, KMAX, false, true>(p, fe, ep, smem, st);
 }

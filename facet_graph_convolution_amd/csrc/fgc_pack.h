@@ -87,11 +87,18 @@ __device__ __forceinline__ void pack_logit_weight_bf16_body(const float* __restr
     }
 }
 
+// pair form, bf16 storage: a plain bf16 copy of W0 [9 cout, cin] (the transform kernel reads it in its native layout)
+__device__ __forceinline__ void pack_plain_bf16_body(const float* __restrict__ W0, unsigned short* __restrict__ Wb, int count,
+                                                     int bid, int nb) {
+    for (int i = bid * blockDim.x + threadIdx.x; i < count; i += nb * blockDim.x) Wb[i] = f_to_bf(W0[i]);
+}
+
 // every packed operand of several layers in one launch (fgc_conv_pack)
 struct PackJob {
     const float* W0;
     float* dst;
-    int kind;   // 0: forward operand, 1: data-gradient operand (transposed), 2: d-logits operand; +4: the bf16 forms
+    int kind;   // 0: forward operand, 1: data-gradient operand (transposed), 2: d-logits operand; +4: the bf16 forms;
+                // 7: plain bf16 copy of W0 (pair form; kdim = element count)
     int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
     int block0;
 };

@@ -222,12 +222,16 @@ class FacetDenoiser:
             if len(graphs) != 3:
                 raise ValueError("the network needs exactly 3 adjacency levels (model.py:858-931)")
             nh = [0, 0, 0]
+            nhp = [0, 0]
             n_total = [g.n for g in graphs]
             own_lo = 0
         else:
             from .shard import LocalGraph
             graphs = [LocalGraph(P, dev) for P in plan.levels]
             nh = [g.n_halo for g in graphs]
+            # tail rows of the coarse tensors read 4x-upsampled by the level above: one per UNIQUE parent of that level's
+            # halo nodes (shard.ShardPlan)
+            nhp = [graphs[0].pair.n_halo, graphs[1].pair.n_halo]
             n_total = list(plan.n_total)
             own_lo = plan.levels[0].lo
             xt = xt[torch.from_numpy(plan.local_rows(0))]
@@ -248,7 +252,7 @@ class FacetDenoiser:
         # rows: owned + the halo rows a consumer gathers (d3 / d2 are read 4x-upsampled by the level above, their tail
         # rows hold the parents of THAT level's halo nodes)
         shapes = {"h1": (n0 + nh[0], 32), "p1": (n1 + nh[1], 32), "h2": (n1 + nh[1], 64), "p2": (n2 + nh[2], 64),
-                  "h3": (n2 + nh[2], 128), "d3": (n2 + nh[1], 128), "u2": (n1 + nh[1], 64), "d2": (n1 + nh[0], 64),
+                  "h3": (n2 + nh[2], 128), "d3": (n2 + nhp[1], 128), "u2": (n1 + nh[1], 64), "d2": (n1 + nhp[0], 64),
                   "u1": (n0 + nh[0], 32), "d1": (n0, 32), "y0": (n0, 3), "nconv": (n0, 3)}
         # dtype "bf16": every activation that crosses a layer boundary (and its gradient) is STORED as bf16; the network
         # input, the 3-channel outputs, logit tables, per-edge d-logits and all parameters stay fp32 (include/fgc.h:
@@ -273,7 +277,8 @@ class FacetDenoiser:
         # shared backward scratch, sized for the largest user
         max_ds = max((ns[l.level] + nh[l.level]) * self._cout(l) for l in self.layers)
         max_r = max(ns[l.level] * (FGC_M * self._cout(l) + 24) for l in self.layers)
-        max_dl = max(g.nnz + getattr(g, "n_cross_in", 0) for g in graphs)
+        max_dl = max(max(g.nnz + getattr(g, "n_cross_in", 0) for g in graphs),
+                     max((g.pair.n_pairs + g.pair.n_cross_in for g in graphs[:2] if getattr(g, "pair", None) is not None), default=0))
         B["ds"] = torch.zeros(max_ds, **f)
         B["dl"] = torch.zeros(max(max_dl, 1) * DL_LD, **f)
         B["dag"] = torch.empty(max(ns) * AG_LD, **f)
@@ -330,9 +335,10 @@ class FacetDenoiser:
             # a layer over a 4x-upsampled input (the two up-convolutions) runs on its COARSE source rows: the pair graph
             # of its level + the table of transformed coarse rows (include/fgc.h: fgc_conv_desc.pair_rowptr)
             pg = None
-            if lay.shift == 2 and plan is None and self.pairs:
-                pg = g.pairs()
-                hc = torch.empty(B[lay.x0].shape[0], FGC_M * d.cout, **f)
+            if lay.shift == 2 and self.pairs:
+                # (facet-sharded: the level's LOCAL pair graph, whose columns address [owned coarse rows | unique halo parents])
+                pg = g.pairs() if plan is None else g.pair
+                hc = torch.empty(B[lay.x0].shape[0], FGC_M * d.cout, **act)      # (bf16 storage: a bf16 table)
                 d.pair_rowptr, d.pair_col, d.pair_mul = pg.prow.data_ptr(), pg.pcol.data_ptr(), pg.pmul.data_ptr()
                 d.n_pairs, d.max_pair_deg, d.max_pair_in_deg = pg.n_pairs, pg.max_deg, pg.max_in_deg
                 d.hc = hc.data_ptr()
@@ -358,9 +364,10 @@ class FacetDenoiser:
             if pg is not None:
                 io.tpair_rowptr, io.tpair_col, io.tpair_edge = pg.trow.data_ptr(), pg.tcol.data_ptr(), pg.tedge.data_ptr()
                 if gt is not None:
-                    need = max(pg.n_pairs, 1) * d.cout
+                    # (one row per owned pair, then the incoming cross-shard pairs of a facet-sharded rank)
+                    need = max(pg.n_pairs + getattr(pg, "n_cross_in", 0), 1) * d.cout
                     if "dt" not in B or B["dt"].numel() < need:
-                        B["dt"] = torch.empty(need, **f)
+                        B["dt"] = torch.empty(need, **act)
                 pair_ios.append(io)
             ios[lay.name] = io
         for io in pair_ios:
@@ -519,7 +526,26 @@ class FacetDenoiser:
             args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(lws),
                     lws.numel(), st)
             need = wait_before.get(lay.name) if self.sharded else None
-            if split and need and M["graphs"][lay.level].tiles["tiles_int"][1] >= self.split_min_tiles:
+            if self.sharded and need and L.fgc_conv_uses_pairs(C.byref(d)):
+                # pair form: the owned coarse rows are transformed while the halo parents travel; then the tail rows and
+                # every block (include/fgc.h: partial forward calls)
+                g = M["graphs"][lay.level]
+                own_src = d.n >> 2
+                self._tag("fwd:" + lay.name)
+                if split:
+                    d.tile_list, d.n_tiles = g.tiles["tiles_int"][0].data_ptr(), 0
+                    d.proj_row0, d.proj_rows = 0, own_src
+                    _lib.check(L.fgc_conv_fwd(*args), lay.name)
+                    yield ("wait", need)
+                    d.tile_list, d.n_tiles = None, 0
+                    d.proj_row0, d.proj_rows = own_src, (d.src_rows - own_src) or -1
+                    d.flags = _lib.CONV_PACKED | lflags
+                    _lib.check(L.fgc_conv_fwd(*args), lay.name)
+                    d.proj_row0, d.proj_rows, d.flags = 0, 0, packed | lflags
+                else:
+                    yield ("wait", need)
+                    _lib.check(L.fgc_conv_fwd(*args), lay.name)
+            elif split and need and M["graphs"][lay.level].tiles["tiles_int"][1] >= self.split_min_tiles:
                 # interior tiles (they gather owned rows only) run while the halo rows travel; then the rest
                 g = M["graphs"][lay.level]
                 own_src = d.n >> d.shift
@@ -718,6 +744,20 @@ class FacetDenoiser:
                 io.stages = 1 | 2 | 8
                 call("params")
                 continue
+            if L.fgc_conv_uses_pairs(C.byref(d)):
+                # pair form: dt and the d-logits of the owned pairs; the rows of the pairs whose parent a peer owns travel to it
+                # (ONE grouped exchange, no rows of s), then the data kernel over the owned coarse rows and the weight gradients
+                pg = g.pair
+                npl = pg.n_pairs + pg.n_cross_in
+                io.stages = 1 | 2
+                call("pair logits")
+                dtb = B["dt"][:npl * cout].view(npl, cout)
+                dlb = B["dl"][:npl * DL_LD].view(npl, DL_LD)
+                yield ("xchg", [("pedges", lay.level, dtb), ("pedges", lay.level, dlb)], None)
+                io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
+                call("pair data")
+                io.flags = 0
+                continue
             # s = dy * lrelu'(y) / deg on owned rows and the d-logits of owned edges, in one call (the deep d-logits kernel
             # computes s in its prologue; packs the operands of stages 2 and 4 when the network did not)
             io.stages = 1 | 2
@@ -765,9 +805,18 @@ class FacetDenoiser:
                 # a row of C bf16 channels travels as C / 2 dwords (every exchanged width is even): the copies and the
                 # collective only move bytes
                 t = t.view(torch.float32)
+            if parent:
+                # a coarse tensor read 4x-upsampled by this level: its tail holds the unique parents of the level's halo nodes
+                pg = g.pair
+                return (t, pg.send_rows, pg.send_counts, t[t.shape[0] - pg.n_halo:], pg.recv_counts)
             tail = t.shape[0] - g.n_halo
-            idx = g.send_parent_rows if parent else g.send_rows
-            return (t, idx, g.send_counts, t[tail:], g.recv_counts)
+            return (t, g.send_rows, g.send_counts, t[tail:], g.recv_counts)
+        if item[0] == "pedges":
+            # per-pair rows (dt, d-logits) of the pairs whose parent another rank owns: they land behind the owned pairs
+            t, pg = item[2], g.pair
+            if t.dtype == torch.bfloat16:
+                t = t.view(torch.float32)
+            return (t, pg.send_edges, pg.cross_send_counts, t[pg.n_pairs:], pg.cross_recv_counts)
         if item[0] == "edges":
             dl = M["B"]["dl"][:(g.nnz + g.n_cross_in) * DL_LD].view(-1, DL_LD)
             return (dl, g.send_edges, g.cross_send_counts, dl[g.nnz:], g.cross_recv_counts)
@@ -777,7 +826,8 @@ class FacetDenoiser:
         """The PackedExchange of an ("xchg", items, key) request; built at its first use, the same every step."""
         from .shard import PackedExchange
         cache = self._mesh.setdefault("packed", {})
-        key = tuple((it[0], it[1]) + ((it[2].data_ptr(), tuple(it[2].shape), bool(it[3])) if it[0] == "rows" else ())
+        key = tuple((it[0], it[1]) + ((it[2].data_ptr(), tuple(it[2].shape), bool(it[3])) if it[0] == "rows" else
+                                      ((it[2].data_ptr(), tuple(it[2].shape)) if it[0] == "pedges" else ()))
                     for it in req[1])
         px = cache.get(key)
         if px is None:

@@ -85,12 +85,10 @@ def build_level_plan(rowptr, col, lo_hi, rank):
     P.rowptr = (rowptr[lo:hi + 1] - e0).astype(np.int32)
     loc = to_local(out_dst)
     P.col = loc.astype(np.int32)
-    # variant for 4x-upsampled sources: owned j keeps j (j >> 2 = its parent's local row because n_own % 4 == 0),
-    # halo h becomes 4 * (n_own / 4 + h): row (n_own/4 + h) of the coarse tensor holds that halo node's parent
-    up = loc.copy()
-    is_h = loc >= P.n_own
-    up[is_h] = 4 * (P.n_own // 4 + (loc[is_h] - P.n_own))
-    P.col_up = up.astype(np.int32)
+    # (the variant for 4x-upsampled sources, col_up, is filled in by ShardPlan: owned j keeps j - j >> 2 is its parent's local
+    #  row because n_own % 4 == 0 -, a halo node becomes 4 * (n_own / 4 + slot of its parent among the unique halo parents))
+    P.col_up = None
+    P.pair = None
     P.max_deg = int(np.diff(P.rowptr).max()) if P.n_own else 0
     # 32-row tiles (the conv kernels' workgroup granule) that gather owned rows only / that touch the halo: the first
     # kind runs while the halo rows are still travelling
@@ -164,11 +162,49 @@ class ShardPlan:
             self.ranges.append([(cuts[r] * f, cuts[r + 1] * f) for r in range(world)])
         self.levels = [build_level_plan(graphs_h[l][0], graphs_h[l][1], self.ranges[l], rank) for l in range(3)]
         self.n_total = n
+        # Levels 0 and 1 are read through a 4x upsampling by the two up-convolutions (model.py:902-905,923-926): their PAIR
+        # graph (graph.pair_graph: a CSR over the coarse nodes of the level above) is sharded by the same routine over the
+        # coarse ranges.  Its halo is the set of UNIQUE parents of the level's halo nodes: the tail rows of the coarse source
+        # tensor (d3 / d2) hold one row per such parent (not one per halo node: 2-4x fewer rows to exchange), `col_up` points
+        # at them, and its transposed graph / cross-pair send lists drive the backward exchange of the pair form.
+        from .graph import pair_graph
+        for l in (0, 1):
+            prow, pcol, pmul = pair_graph(graphs_h[l][0], graphs_h[l][1])
+            PP = build_level_plan(prow, pcol, self.ranges[l + 1], rank)
+            e0 = int(prow[self.ranges[l + 1][rank][0]])
+            PP.pmul = np.ascontiguousarray(pmul[e0:e0 + PP.nnz])
+            L = self.levels[l]
+            assert np.array_equal(PP.halo_ids, np.unique(L.halo_ids >> 2)), "pair halo != parents of the level's halo"
+            loc = L.col.astype(np.int64)
+            is_h = loc >= L.n_own
+            slot = np.searchsorted(PP.halo_ids, L.halo_ids >> 2)
+            up = loc.copy()
+            up[is_h] = 4 * (L.n_own // 4 + slot[loc[is_h] - L.n_own])
+            L.col_up = up.astype(np.int32)
+            L.pair = PP
 
     def local_rows(self, level):
         """Global ids of the local rows [owned | halo] of a level."""
         P = self.levels[level]
         return np.concatenate([np.arange(P.lo, P.hi, dtype=np.int64), P.halo_ids])
+
+
+class LocalPairGraph:
+    """Device-resident local pair graph of a level (graph.PairGraph's attributes) with its halo of unique parents: which
+    coarse rows go to / come from every peer, and which pairs' dt / d-logit rows cross shards in the backward pass."""
+
+    def __init__(self, PP, device):
+        pad = (lambda a: a if len(a) else np.zeros(1, a.dtype))
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(pad(a))).to(device)
+        self.n_pairs, self.n_halo, self.n_cross_in = PP.nnz, PP.n_halo, PP.n_cross_in
+        self.max_deg, self.max_in_deg = PP.max_deg, PP.max_in_deg
+        self.prow, self.pcol = up(PP.rowptr), up(PP.col)
+        self.pmul = up(PP.pmul.view(np.int32))
+        self.trow, self.tcol, self.tedge = up(PP.trowptr), up(PP.tcol), up(PP.tedge)
+        self.send_rows = up(np.concatenate(PP.send_rows).astype(np.int32))
+        self.send_counts, self.recv_counts = list(PP.send_counts), list(PP.recv_counts)
+        self.send_edges = up(np.concatenate(PP.send_edges).astype(np.int32))
+        self.cross_send_counts, self.cross_recv_counts = list(PP.cross_send_counts), list(PP.cross_recv_counts)
 
 
 class LocalGraph:
@@ -182,12 +218,12 @@ class LocalGraph:
         dev = torch.device(device)
         self.rowptr = torch.from_numpy(P.rowptr.copy()).to(dev)
         self.col = torch.from_numpy(pad(P.col).copy()).to(dev)
-        self.col_up = torch.from_numpy(pad(P.col_up).copy()).to(dev)
+        self.col_up = torch.from_numpy(pad(P.col_up).copy()).to(dev) if P.col_up is not None else None
+        self.pair = LocalPairGraph(P.pair, dev) if P.pair is not None else None
         self._t = tuple(torch.from_numpy(pad(a).copy()).to(dev) for a in (P.trowptr, P.tcol, P.tedge))
         self.tiles = {k: (torch.from_numpy(pad(getattr(P, k)).copy()).to(dev), len(getattr(P, k)))
                       for k in ("tiles_int", "tiles_bnd", "ttiles_int", "ttiles_bnd")}
         self.send_rows = torch.from_numpy(pad(np.concatenate(P.send_rows)).astype(np.int32)).to(dev)
-        self.send_parent_rows = torch.from_numpy(pad(np.concatenate(P.send_rows) // 4).astype(np.int32)).to(dev)
         self.send_counts, self.recv_counts = list(P.send_counts), list(P.recv_counts)
         self.send_edges = torch.from_numpy(pad(np.concatenate(P.send_edges)).astype(np.int32)).to(dev)
         self.cross_send_counts, self.cross_recv_counts = list(P.cross_send_counts), list(P.cross_recv_counts)

@@ -217,8 +217,9 @@ def test_bf16_rejects_what_it_does_not_cover(golden_dir):
         FacetDenoiser("cuda:0", dtype="fp8")
 
 
-def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act):
+def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act, pairs=False):
     """One conv layer with FGC_CONV_BF16 straight through the C ABI: bf16 x / y / dy / ds / r / dx, fp32 everything else.
+    pairs: the layer (shift == 2) gets its pair graph, a bf16 hc table and a bf16 dt scratch (include/fgc.h).
     Returns (y bf16, dx0, dx1, [dW0, db, du, dc, dv])."""
     import ctypes as C
     from facet_graph_convolution_amd import _lib, ops
@@ -231,6 +232,11 @@ def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act):
     n, cout = g.n, d.cout
     bf = dict(dtype=torch.bfloat16, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
+    pg = None
+    if pairs:
+        hc = torch.empty(x0.shape[0], FGC_M * cout, **bf)
+        pg = ops.attach_pairs(d, g, hc)
+        assert L.fgc_conv_uses_pairs(C.byref(d)) == 1, (pg.max_deg, pg.max_in_deg)
     ws = torch.empty(L.fgc_conv_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
     ag = torch.empty(x0.shape[0], AG_LD, **f32)
     y = torch.empty(n, cout, **bf)
@@ -250,6 +256,10 @@ def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act):
     io.ds, io.dl, io.dag, io.r = ds.data_ptr(), dl.data_ptr(), dag.data_ptr(), r.data_ptr()
     io.dx0, io.dx1 = dx0.data_ptr(), (dx1.data_ptr() if dx1 is not None else None)
     io.dW0, io.db, io.du, io.dc, io.dv = [t.data_ptr() for t in grads]
+    if pg is not None:
+        io.tpair_rowptr, io.tpair_col, io.tpair_edge = pg.trow.data_ptr(), pg.tcol.data_ptr(), pg.tedge.data_ptr()
+        dt = torch.empty(pg.n_pairs, cout, **bf)
+        io.dt = dt.data_ptr()
     wsb = torch.empty(L.fgc_conv_bwd_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
     check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(wsb), wsb.numel(), stream_ptr()), "fgc_conv_bwd bf16")
     torch.cuda.synchronize()
@@ -257,7 +267,8 @@ def _bf16_conv_fwd_bwd(g, x0, x1, shift, params, dy, act):
 
 
 @pytest.mark.parametrize("mode,cin,cout", [("plain", 32, 64), ("plain", 64, 128), ("concat", 128, 64), ("upsample", 128, 64),
-                                           ("plain", 128, 128), ("plain", 64, 32), ("concat", 64, 32)])
+                                           ("plain", 128, 128), ("plain", 64, 32), ("concat", 64, 32),
+                                           ("upsample_pairs", 128, 64), ("upsample_pairs", 64, 32)])
 def test_bf16_conv_kernels_against_float64_on_the_same_rounded_operands(mode, cin, cout):
     """Kernel error isolated from storage error: one conv layer, forward and backward, through the bf16 kernels against
     the float64 oracle fed the SAME bf16-rounded x and dy (and, for lrelu', the bf16 kernel's own stored y).  What is
@@ -276,8 +287,12 @@ def test_bf16_conv_kernels_against_float64_on_the_same_rounded_operands(mode, ci
     for i in range(n):
         deg = rs.randint(3, 13)
         adj[i, 0] = i + 1
-        adj[i, 1:1 + deg] = rs.randint(max(1, i - 60), min(n, i + 60) + 1, size=deg)
+        win = 24 if mode == "upsample_pairs" else 60      # (pair form: at most 24 in-pairs per coarse row)
+        adj[i, 1:1 + deg] = rs.randint(max(1, i - win), min(n, i + win) + 1, size=deg)
     g = FacetGraph(adj, dev)
+    pairs = mode == "upsample_pairs"
+    if pairs:
+        mode = "upsample"       # the same layer, run on its coarse source rows: bf16 hc and dt are its extra roundings
     rows = n // 4 if mode == "upsample" else n
     widths = [cin // 2, cin // 2] if mode == "concat" else [cin]
     xs = [torch.tensor(rs.normal(size=(rows, w)).astype(np.float32)).to(torch.bfloat16) for w in widths]
@@ -286,7 +301,7 @@ def test_bf16_conv_kernels_against_float64_on_the_same_rounded_operands(mode, ci
     p[0] = p[0].to(torch.bfloat16).float()       # the kernels pack W0 as a bf16 MFMA operand: exact for these values
     xd = [t.to(dev).contiguous() for t in xs]
     y, dx0, dx1, grads = _bf16_conv_fwd_bwd(g, xd[0], xd[1] if len(xd) > 1 else None, 2 if mode == "upsample" else 0,
-                                            [t.to(dev) for t in p], dy.to(dev).contiguous(), act=1)
+                                            [t.to(dev) for t in p], dy.to(dev).contiguous(), act=1, pairs=pairs)
     # float64 oracle on the rounded operands
     X = [t.double().requires_grad_(True) for t in xs]
     P = [t.double().requires_grad_(True) for t in p]

@@ -153,3 +153,20 @@ def test_network_uses_the_pair_form_for_both_up_convolutions():
         assert ("hc_" + name) in M["B"]
     for name in ("conv2", "dconv1"):
         assert net.L.fgc_conv_uses_pairs(C.byref(M["descs"][name])) == 0
+
+
+def test_facet_sharded_network_uses_the_pair_form_too(golden_dir):
+    """A facet-sharded rank runs its up-convolutions on the LOCAL pair graph (columns = [owned coarse rows | unique halo
+    parents], shard.ShardPlan), fp32 and bf16 storage."""
+    import ctypes as C
+    from facet_graph_convolution_amd.shard import make_sim_shards
+    prep = np.load(os.path.join(golden_dir, "prep_torus640.npz"))
+    adjs = [prep["adj0"], prep["adj1"], prep["adj2"]]
+    for dtype in ("f32", "bf16"):
+        nets = make_sim_shards(prep["x"], adjs, prep["gt"], 3, "cuda:0", 0, dtype=dtype)
+        for n in nets:
+            for name in ("upconv1", "upconv2"):
+                d = n._mesh["descs"][name]
+                assert n.L.fgc_conv_uses_pairs(C.byref(d)) == 1
+                g = n._mesh["graphs"][0 if name == "upconv1" else 1]
+                assert d.src_rows == d.n // 4 + g.pair.n_halo and g.pair.n_halo <= g.n_halo

@@ -34,10 +34,13 @@ def test_plan_is_consistent(golden_dir, world):
                 glob = col[rowptr[P.lo + i]:rowptr[P.lo + i + 1]]
                 loc = P.col[P.rowptr[i]:P.rowptr[i + 1]]
                 assert np.array_equal(ids[loc], glob)
-                up = P.col_up[P.rowptr[i]:P.rowptr[i + 1]]
-                own = loc < P.n_own
-                assert np.array_equal(up[own], loc[own])
-                assert np.array_equal(up[~own] // 4, P.n_own // 4 + (loc[~own] - P.n_own))
+                if l < 2:
+                    # the variant for a 4x-upsampled coarse source: an owned node keeps its id (id >> 2 = its parent's local
+                    # row), a halo node points at the tail row of its parent among the UNIQUE halo parents
+                    up = P.col_up[P.rowptr[i]:P.rowptr[i + 1]]
+                    own = loc < P.n_own
+                    assert np.array_equal(up[own], loc[own]) and (up[~own] % 4 == 0).all()
+                    assert np.array_equal(P.pair.halo_ids[up[~own] // 4 - P.n_own // 4], ids[loc[~own]] >> 2)
             # interior / boundary tiles: a partition of the 32-row tiles; interior ones touch owned rows only
             for rp, cc, ti, tb in ((P.rowptr, P.col, P.tiles_int, P.tiles_bnd),
                                    (P.trowptr, P.tcol, P.ttiles_int, P.ttiles_bnd)):
@@ -54,6 +57,23 @@ def test_plan_is_consistent(golden_dir, world):
                 got.append(Q.send_rows[p.rank] + Q.lo)
                 assert len(Q.send_rows[p.rank]) == P.recv_counts[q]
             assert np.array_equal(np.concatenate(got), P.halo_ids)
+            if l < 2:
+                # the level's pair graph, sharded over the coarse ranges: local pairs = the global pairs of the owned blocks
+                # (columns renamed), tail = the unique parents of the halo, and what peers send is exactly that tail
+                from facet_graph_convolution_amd.graph import pair_graph
+                prow, pcol, pmul = pair_graph(rowptr, col)
+                PP = P.pair
+                assert PP.n_own == P.n_own // 4 and np.array_equal(PP.halo_ids, np.unique(P.halo_ids >> 2))
+                cids = np.concatenate([np.arange(PP.lo, PP.hi), PP.halo_ids])
+                e0 = prow[PP.lo]
+                assert np.array_equal(cids[PP.col], pcol[e0:e0 + PP.nnz]) and np.array_equal(PP.pmul, pmul[e0:e0 + PP.nnz])
+                gotp = np.concatenate([plans[q].levels[l].pair.send_rows[p.rank] + plans[q].levels[l].pair.lo
+                                       for q in range(world)])
+                assert np.array_equal(gotp, PP.halo_ids)
+                # every in-pair of an owned coarse row is there, the cross ones behind the owned pairs in the senders' order
+                assert len(PP.tedge) == int(((pcol >= PP.lo) & (pcol < PP.hi)).sum())
+                sent = sum(len(plans[q].levels[l].pair.send_edges[p.rank]) for q in range(world))
+                assert sent == PP.n_cross_in and PP.tedge.max(initial=-1) < PP.nnz + PP.n_cross_in
             # transposed CSR: every in-edge of an owned node, in global edge order, owned or cross
             gl_in = np.where((col >= P.lo) & (col < P.hi))[0]
             assert len(P.tedge) == len(gl_in)
