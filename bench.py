@@ -403,6 +403,21 @@ def load_traffic_db(dtype, nu, nv):
     return db, "%s (commit %s, kernel sources %s)" % (os.path.basename(cands[0]), meta.get("commit"), have)
 
 
+def load_binds(dtype):
+    """What the SQ counter passes found binding the dominant kernels (tools/pmc_sq.sh): a sentence kept next to the counter
+    tables under profiles/ (r*_binds.json: {"csrc_sha16", "f32", "bf16"}) and quoted only when those passes were taken on THIS
+    build's kernel sources; None otherwise - counter findings do not outlive the kernels they were measured on."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_binds.json")), reverse=True)
+    if not cands:
+        return None
+    try:
+        b = json.load(open(cands[0]))
+    except (OSError, ValueError):
+        return None
+    return b.get(dtype) if b.get("csrc_sha16") == csrc_sha16() else None
+
+
 # kernel name -> family (the kernel FUNCTION, all template instances and both directions of the shared core together)
 def family_of(kern):
     if "conv_w8_kernel" in kern or "conv_fwd_kernel" in kern or "conv_bwd_data_kernel" in kern:
@@ -720,9 +735,8 @@ def main(argv=None):
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": d["traffic"],
                         "avg_kernel_us": d["avg_kernel_us"], "launch_bytes": d["algorithmic_bytes"],
                         "mfma_tflops": d["achieved"], "mfma_frac": d["frac"],
-                        # what the counters say binds the bf16 kernels (the contract's `bound` is the roofline quoted):
-                        "binds": "neither roofline: vector-ALU issue (64-83 % busy, profiles/r3_pmc_sq_tables_bf16.txt) and the "
-                                 "number of resident workgroups (DESIGN.md section 10)",
+                        # what the counters say binds the bf16 kernels (the contract's `bound` is the roofline quoted)
+                        "binds": load_binds("bf16"),
                         "family_share_of_step": d["share_of_step"],
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
@@ -734,8 +748,7 @@ def main(argv=None):
                         "peak": peak, "unit": "TFLOP/s", "frac": d["frac"], "traffic": d["traffic"],
                         "avg_kernel_us": d["avg_kernel_us"], "launch_flops": d["launch_flops"],
                         "family_share_of_step": d["share_of_step"], "family_frac": d["family_frac"],
-                        "binds": "fp32 MFMA + vector ALU, which do not co-issue (71-92 % of the SIMD issue cycles together, "
-                                 "profiles/r3_pmc_sq_tables.txt), at five resident workgroups per CU (DESIGN.md section 10)",
+                        "binds": load_binds("f32"),
                         "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
                         "traffic_source": traffic_note,
