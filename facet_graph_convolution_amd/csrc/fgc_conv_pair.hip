@@ -261,6 +261,7 @@ struct PairParams {
     float* dag;              // [n/4, 24]: writes 0..11
     float* db_part;          // [workgroups, cout]
     float* dc_part;          // [workgroups, 12]
+    unsigned dt_bytes, dl_bytes;   // sizes of dt / dl (stores past them are dropped by the buffer descriptor)
 };
 
 __device__ __forceinline__ void pair_wave_sync() {
@@ -336,6 +337,16 @@ __device__ __forceinline__ void pair_load_h(__amdgpu_buffer_rsrc_t h_rs, const f
         else h[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, off + (unsigned)(m * COUT * 4), 0, 0));
     }
 }
+// piece m of the row whose byte offset (lane part included) is `off`
+template <int COUT, bool BF>
+__device__ __forceinline__ typename PairH<BF>::T pair_load_piece(__amdgpu_buffer_rsrc_t h_rs, unsigned off, int m) {
+    if constexpr (BF) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(h_rs, off + (unsigned)(m * COUT * 2), 0, 0));
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, off + (unsigned)(m * COUT * 4), 0, 0));
+}
+template <int COUT, bool BF>
+__device__ __forceinline__ unsigned pair_row_off(const float* qk, unsigned laneoff) {
+    return __umul24((unsigned)__float_as_int(qk[9]), (unsigned)(FGC_M * COUT) * (BF ? 2u : 4u)) + laneoff;
+}
 __device__ __forceinline__ f32x4 pair_h(const f32x4& v) { return v; }
 __device__ __forceinline__ f32x4 pair_h(const u32x2& v) { return bf4_to_f4(v); }
 // four channels of an activation row: fp32 (16 bytes) or bf16 (8 bytes)
@@ -356,8 +367,22 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+#ifndef FGC_PAIR_UNROLL1
+#define FGC_PAIR_UNROLL1 0
+#endif
+#if FGC_PAIR_UNROLL1
+#define FGC_PAIR_KLOOP_PRAGMA _Pragma("unroll 1")
+#else
+#define FGC_PAIR_KLOOP_PRAGMA
+#endif
+#ifndef FGC_PAIR_LB_FWD
+#define FGC_PAIR_LB_FWD 1
+#endif
+#ifndef FGC_PAIR_LB_BWD
+#define FGC_PAIR_LB_BWD 1
+#endif
 template <int COUT, bool BF>
-__global__ __launch_bounds__(256) void pair_fwd_kernel(PairParams p) {
+__global__ __launch_bounds__(256, FGC_PAIR_LB_FWD) void pair_fwd_kernel(PairParams p) {
     constexpr int LPB = COUT / 4, BPW = 64 / LPB, BPG = 4 * BPW;
     __shared__ __attribute__((aligned(16))) float qs[BPG * PQ_STRIDE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, bl = lane / LPB, kl = lane % LPB;
@@ -384,34 +409,34 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(PairParams p) {
     f32x4 yv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto consume = [&](const float* qk, const HT (&h)[FGC_M]) {
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk), q1 = *reinterpret_cast<const f32x4*>(qk + 4);
-        const float q8 = qk[8];
-        const unsigned mu = __float_as_uint(qk[10]);
-        f32x4 t = q0[0] * pair_h(h[0]);
-        t += q0[1] * pair_h(h[1]); t += q0[2] * pair_h(h[2]); t += q0[3] * pair_h(h[3]);
-        t += q1[0] * pair_h(h[4]); t += q1[1] * pair_h(h[5]); t += q1[2] * pair_h(h[6]); t += q1[3] * pair_h(h[7]);
-        t += q8 * pair_h(h[8]);
-        yv[0] += (float)(mu & 0xffu) * t;
-        yv[1] += (float)((mu >> 8) & 0xffu) * t;
-        yv[2] += (float)((mu >> 16) & 0xffu) * t;
-        yv[3] += (float)(mu >> 24) * t;
-    };
+    // ONE buffer of nine pieces, refilled piece by piece: piece m of pair k + 1 is requested right behind the use of piece m
+    // of pair k, so nine loads stay in flight at a constant wait count (8) with half the registers of two whole-row buffers
     for (int k0 = 0; k0 < dmax; k0 += PQ_SLOTS) {
         if (k0) pair_wave_sync();
         pair_softmax_chunk<LPB>(p, qb, kl, e0, d, k0, bc, a);
         pair_wave_sync();
         const int cnt = min(dmax - k0, PQ_SLOTS);
-        HT ha[FGC_M], hb[FGC_M];
-        pair_load_h<COUT, BF>(h_rs, qb, laneoff, ha);
-        int k = 0;
-        for (; k + 2 <= cnt; k += 2) {
-            pair_load_h<COUT, BF>(h_rs, qb + (k + 1) * PQ_LD, laneoff, hb);
-            consume(qb + k * PQ_LD, ha);
-            pair_load_h<COUT, BF>(h_rs, qb + min(k + 2, PQ_SLOTS - 1) * PQ_LD, laneoff, ha);
-            consume(qb + (k + 1) * PQ_LD, hb);
+        HT h[FGC_M];
+        pair_load_h<COUT, BF>(h_rs, qb, laneoff, h);
+        FGC_PAIR_KLOOP_PRAGMA
+        for (int k = 0; k < cnt; ++k) {
+            const float* qk = qb + k * PQ_LD;
+            const unsigned noff = pair_row_off<COUT, BF>(qb + min(k + 1, PQ_SLOTS - 1) * PQ_LD, laneoff);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk), q1 = *reinterpret_cast<const f32x4*>(qk + 4);
+            const f32x2c q8m = *reinterpret_cast<const f32x2c*>(qk + 8), mm = *reinterpret_cast<const f32x2c*>(qk + 10);
+            const float q[FGC_M] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q8m[0]};
+            const unsigned mu = __float_as_uint(mm[0]);
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                t += q[m] * pair_h(h[m]);
+                h[m] = pair_load_piece<COUT, BF>(h_rs, noff, m);
+            }
+            yv[0] += (float)(mu & 0xffu) * t;
+            yv[1] += (float)((mu >> 8) & 0xffu) * t;
+            yv[2] += (float)((mu >> 16) & 0xffu) * t;
+            yv[3] += (float)(mu >> 24) * t;
         }
-        if (k < cnt) consume(qb + k * PQ_LD, ha);
     }
     if (b >= p.nb) return;
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + kl * 4);
@@ -439,7 +464,7 @@ __device__ __forceinline__ float pair_block_sum(float v) {
 }
 
 template <int COUT, bool BF>
-__global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
+__global__ __launch_bounds__(256, FGC_PAIR_LB_BWD) void pair_bwd_logits_kernel(PairParams p) {
     constexpr int LPB = COUT / 4, BPW = 64 / LPB, BPG = 4 * BPW;
     constexpr int RED_LD = COUT + 12;
     __shared__ __attribute__((aligned(16))) float qs[BPG * PQ_STRIDE];
@@ -483,56 +508,65 @@ __global__ __launch_bounds__(256) void pair_bwd_logits_kernel(PairParams p) {
     float da[FGC_M];
 #pragma unroll
     for (int m = 0; m < FGC_M; ++m) da[m] = 0.f;
-    auto consume = [&](int kk, const float* qk, const HT (&hh)[FGC_M]) {
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk), q1 = *reinterpret_cast<const f32x4*>(qk + 4);
-        const float q[FGC_M] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], qk[8]};
-        const unsigned mu = __float_as_uint(qk[10]);
-        f32x4 dt = (float)(mu & 0xffu) * sv[0];
-        dt += (float)((mu >> 8) & 0xffu) * sv[1];
-        dt += (float)((mu >> 16) & 0xffu) * sv[2];
-        dt += (float)(mu >> 24) * sv[3];
-        const bool live = kk < d;
-        if (live) pair_st4<BF>(p.dt, (size_t)(e0 + kk) * COUT + kl * 4, dt);
-        if constexpr (BF) dt = bf4_to_f4(f4_to_bf4(dt));      // (the data kernel gathers the stored, rounded rows)
-        float dq[FGC_M], sum = 0.f;
-#pragma unroll
-        for (int m = 0; m < FGC_M; ++m) {
-            const f32x4 h = pair_h(hh[m]);
-            float v = dt[0] * h[0];
-            v = fmaf(dt[1], h[1], v);
-            v = fmaf(dt[2], h[2], v);
-            v = fmaf(dt[3], h[3], v);
-            dq[m] = pair_block_sum<LPB>(v);
-            sum = fmaf(q[m], dq[m], sum);
-        }
-        float dlv[FGC_M];
-#pragma unroll
-        for (int m = 0; m < FGC_M; ++m) {
-            dlv[m] = q[m] * (dq[m] - sum);
-            da[m] += dlv[m];
-        }
-        if (live && kl == 0) {
-            float* o = p.dl + (size_t)(e0 + kk) * FGC_DL_LD;
-            *reinterpret_cast<f32x4*>(o) = f32x4{dlv[0], dlv[1], dlv[2], dlv[3]};
-            *reinterpret_cast<f32x4*>(o + 4) = f32x4{dlv[4], dlv[5], dlv[6], dlv[7]};
-            *reinterpret_cast<f32x4*>(o + 8) = f32x4{dlv[8], 0.f, 0.f, 0.f};
-        }
-    };
+    // dt / dl rows through bounded buffer descriptors: a slot past the block's degree stores at an offset beyond the
+    // buffer, which the hardware drops - no exec-masked store in the loop
+    const __amdgpu_buffer_rsrc_t dt_rs = __builtin_amdgcn_make_buffer_rsrc(p.dt, 0, p.dt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dl_rs = __builtin_amdgcn_make_buffer_rsrc(p.dl, 0, p.dl_bytes, 0x00020000);
     for (int k0 = 0; k0 < dmax; k0 += PQ_SLOTS) {
         if (k0) pair_wave_sync();
         pair_softmax_chunk<LPB>(p, qb, kl, e0, d, k0, bc, a);
         pair_wave_sync();
         const int cnt = min(dmax - k0, PQ_SLOTS);
-        HT ha[FGC_M], hb[FGC_M];
-        pair_load_h<COUT, BF>(h_rs, qb, laneoff, ha);
-        int k = 0;
-        for (; k + 2 <= cnt; k += 2) {
-            pair_load_h<COUT, BF>(h_rs, qb + (k + 1) * PQ_LD, laneoff, hb);
-            consume(k0 + k, qb + k * PQ_LD, ha);
-            pair_load_h<COUT, BF>(h_rs, qb + min(k + 2, PQ_SLOTS - 1) * PQ_LD, laneoff, ha);
-            consume(k0 + k + 1, qb + (k + 1) * PQ_LD, hb);
+        HT h[FGC_M];
+        pair_load_h<COUT, BF>(h_rs, qb, laneoff, h);
+        FGC_PAIR_KLOOP_PRAGMA
+        for (int k = 0; k < cnt; ++k) {
+            const float* qk = qb + k * PQ_LD;
+            const int kk = k0 + k;
+            const unsigned noff = pair_row_off<COUT, BF>(qb + min(k + 1, PQ_SLOTS - 1) * PQ_LD, laneoff);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qk), q1 = *reinterpret_cast<const f32x4*>(qk + 4);
+            const f32x2c q8m = *reinterpret_cast<const f32x2c*>(qk + 8), mm = *reinterpret_cast<const f32x2c*>(qk + 10);
+            const float q[FGC_M] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q8m[0]};
+            const unsigned mu = __float_as_uint(mm[0]);
+            f32x4 dt = (float)(mu & 0xffu) * sv[0];
+            dt += (float)((mu >> 8) & 0xffu) * sv[1];
+            dt += (float)((mu >> 16) & 0xffu) * sv[2];
+            dt += (float)(mu >> 24) * sv[3];
+            const bool live = kk < d;
+            const unsigned erow = (unsigned)(e0 + kk);
+            if constexpr (BF) {
+                const u32x2 w = f4_to_bf4(dt);
+                __builtin_amdgcn_raw_buffer_store_b64(w, dt_rs,
+                                                      live ? erow * (unsigned)(COUT * 2) + (unsigned)kl * 8u : 0xFFFFFFF0u, 0, 0);
+                dt = bf4_to_f4(w);      // (the data kernel gathers the stored, rounded rows)
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dt), dt_rs,
+                                                       live ? erow * (unsigned)(COUT * 4) + (unsigned)kl * 16u : 0xFFFFFFF0u, 0, 0);
+            }
+            float dq[FGC_M], sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                const f32x4 hv = pair_h(h[m]);
+                h[m] = pair_load_piece<COUT, BF>(h_rs, noff, m);
+                float v = dt[0] * hv[0];
+                v = fmaf(dt[1], hv[1], v);
+                v = fmaf(dt[2], hv[2], v);
+                v = fmaf(dt[3], hv[3], v);
+                dq[m] = pair_block_sum<LPB>(v);
+                sum = fmaf(q[m], dq[m], sum);
+            }
+            float dlv[FGC_M];
+#pragma unroll
+            for (int m = 0; m < FGC_M; ++m) {
+                dlv[m] = q[m] * (dq[m] - sum);
+                da[m] += dlv[m];
+            }
+            // the block's lanes 0, 1, 2 store the three 16-byte pieces of the pair's d-logit row
+            const f32x4 piece = kl == 0 ? f32x4{dlv[0], dlv[1], dlv[2], dlv[3]}
+                                        : (kl == 1 ? f32x4{dlv[4], dlv[5], dlv[6], dlv[7]} : f32x4{dlv[8], 0.f, 0.f, 0.f});
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, piece), dl_rs,
+                                                   (live && kl < 3) ? erow * (unsigned)(FGC_DL_LD * 4) + (unsigned)kl * 16u : 0xFFFFFFF0u, 0, 0);
         }
-        if (k < cnt) consume(k0 + k, qb + k * PQ_LD, ha);
     }
     if (valid && kl == 0) {
         float* o = p.dag + (size_t)b * FGC_AG_LD;
@@ -647,6 +681,8 @@ int launch_pair_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, fl
     p.dag = io->dag;
     p.db_part = db_part;
     p.dc_part = dc_part;
+    p.dt_bytes = (unsigned)((size_t)d->n_pairs * d->cout * ((d->flags & FGC_CONV_BF16) ? 2 : 4));
+    p.dl_bytes = (unsigned)((size_t)d->n_pairs * FGC_DL_LD * 4);
     const int grid = pair_num_wgs(d);
     if (d->flags & FGC_CONV_BF16) {
         if (d->cout == 32) FGC_LAUNCH("pair_bwd_logits_kernel", st, (pair_bwd_logits_kernel<32, true>), dim3(grid), dim3(256), 0, p);
