@@ -696,13 +696,13 @@ __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd
                 // part + P, ...) and add up on the DPP crossbar in a fixed order.  (One thread per column walking the 32
                 // rows was a chain of 32 dependent LDS reads in front of a barrier, once per tile.)
                 constexpr int C = OKG * 16, P = NTHREADS / C;
-                static_assert(P == 8 || P == 4, "two or three DPP steps");
+                static_assert(P == 8 || P == 4 || P == 2, "one, two or three DPP steps");
                 const int col = tid / P, part = tid % P;
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < TILE / P; ++j) acc += dst[(part + P * j) * ostride + col];
                 acc += fgc_dpp_c<0xB1>(acc);
-                acc += fgc_dpp_c<0x4E>(acc);
+                if (P >= 4) acc += fgc_dpp_c<0x4E>(acc);
                 if (P == 8) acc += fgc_dpp_c<0x141>(acc);
                 if (part == 0) lp.db_part[(size_t)(tile0 / TILE) * C + col] = acc;
             }
@@ -824,7 +824,7 @@ __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd
                             }
                     }
                 };
-                if constexpr (OKG >= 4) {
+                if constexpr (OKG == 4) {      // (OKG = 8, the 128-wide layers: the plain loop was measured faster)
                     // two weight buffers with fixed roles: the fragments of group g + 1 are in flight under the MFMAs of g
                     f32x4 wA[K1_CTW], wB[K1_CTW];
                     loadw(0, wA);
@@ -2046,7 +2046,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const bool fuse_ds = (stages & 3) == 3 && deep_ok && w.nb_db == cdiv(d->n, k1_nodes(d)) &&
                          (bf16 ? (!narrow_path && (cout == 32 || cout == 64 || cout == 128) &&
                                   !(getenv("FGC_NO_FUSED_DS_BF16") && getenv("FGC_NO_FUSED_DS_BF16")[0] == '1'))
-                               : ((cout == 32 || cout == 64) &&
+                               : ((cout == 32 || cout == 64 || (cout == 128 && k1_nodes(d) == 16 &&
+                                                                   !(getenv("FGC_NO_FUSED_DS128") && getenv("FGC_NO_FUSED_DS128")[0] == '1'))) &&
                                   !(d->max_deg > 16 && cout > 32))) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
@@ -2188,6 +2189,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                     const bool al = ((uintptr_t)io->ds % 16) == 0;
                     if (cout == 32 && al) FGC_DEEP_HALF(2);
                     else if (cout == 64 && al) FGC_DEEP_HALF(4);
+                    else if (cout == 128 && al && fuse_ds) FGC_DEEP_HALF(8);   // (only for its prologue: s and db in this launch)
                     else FGC_DEEP_HALF(0);
 #undef FGC_DEEP_HALF
                 } else {
