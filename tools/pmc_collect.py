@@ -5,14 +5,14 @@ a pass with the tracing domains gpurun refuses).
     python tools/pmc_collect.py <fetch counter_collection.csv> <write counter_collection.csv> <steps> <out.json>
 
 FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half of the bytes of a wide coalesced read
-(MI355X_MICROARCH.md, HBM section): hbm = 2 * FETCH + WRITE.  Launches are matched to layers by their order inside a
-step (forward: conv2, conv3, dconv3, upconv2, dconv2, upconv1, dconv1; backward: the reverse, conv1 last)."""
+(MI355X_MICROARCH.md, HBM section): hbm = 2 * FETCH + WRITE.  Launches are matched to layers by the fixed schedule of a
+step (see `label`)."""
 import csv
 import json
 import sys
 
-FWD = ["conv2", "conv3", "dconv3", "upconv2", "dconv2", "upconv1", "dconv1"]
-BWD = ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2"]
+FWD = ["conv1", "conv2", "conv3", "dconv3", "upconv2", "dconv2", "upconv1", "dconv1"]
+BWD = ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]
 
 
 def load(path):
@@ -30,34 +30,49 @@ def short(k):
 
 
 def label(names):
-    """tag/kernel key (as bench.py prints them) for every dispatch of ONE step."""
-    out, cnt = [], {}
+    """tag/kernel key (as bench.py prints them) for every dispatch of ONE step.  The schedule is fixed: a forward layer
+    starts with its logit-table launch (proj_mfma_kernel, or pair_transform_kernel for a layer in the pair form), a backward
+    layer with its d-logits launch (conv_bwd_logits_*, pair_bwd_logits_kernel, conv_narrow_bwd_kernel); the backward pass
+    begins at the MLP's backward kernel."""
+    out = []
+    fi = bi = -1
+    bwd = False
     for k in names:
         s = short(k)
-        c = cnt.get(s.split("<")[0], 0)
-        key = None
-        if s.startswith("conv_w8_kernel<false"):
-            key = "fwd:%s/conv_w8_kernel<fwd>" % FWD[cnt.get("w8f", 0)]
-            cnt["w8f"] = cnt.get("w8f", 0) + 1
-        elif s.startswith("conv_w8_kernel<true"):
-            key = "bwd:%s/conv_w8_kernel<data>" % BWD[cnt.get("w8d", 0)]
-            cnt["w8d"] = cnt.get("w8d", 0) + 1
-        elif s.startswith("conv_bwd_logits"):
-            key = "bwd:%s/%s" % (BWD[cnt.get("k1", 0)], s.split("<")[0])
-            cnt["k1"] = cnt.get("k1", 0) + 1
-        elif s.startswith("gemm_tn"):
-            i = cnt.get("tn", 0)
-            key = "bwd:%s/gemm_tn_kernel:dW" % (BWD[i] if i < 7 else "conv1")
-            cnt["tn"] = i + 1
-        elif s.startswith("mlp_bwd_dx"):
-            key = "bwd:mlp/mlp_bwd_kernel<dx>"
-        elif s.startswith("mlp_bwd_w"):
-            key = "bwd:mlp/mlp_bwd_kernel<w>"
-        elif s.startswith("mlp_bwd") or s.startswith("mlp_fwd"):
-            key = "%s:mlp/%s" % ("bwd" if "bwd" in s else "fwd", "mlp_bwd_kernel" if "bwd" in s else "mlp_fwd_kernel")
+        base = s.split("<")[0]
+        key = "other/" + base
+        if base.startswith("mlp_bwd") or base.startswith("loss_step"):
+            bwd = True
+        if not bwd:
+            if base in ("proj_mfma_kernel", "pair_transform_kernel", "pair_transform_bf16_kernel"):
+                fi += 1
+            lay = FWD[min(max(fi, 0), 7)]
+            if s.startswith("conv_w8_kernel<false"):
+                key = "fwd:%s/conv_w8_kernel<fwd>" % lay
+            elif base.startswith("pair_transform"):
+                key = "fwd:%s/pair_transform_kernel" % lay
+            elif base == "pair_fwd_kernel":
+                key = "fwd:%s/pair_fwd_kernel" % lay
+            elif base.startswith("mlp_fwd"):
+                key = "fwd:mlp/mlp_fwd_kernel"
         else:
-            key = "other/" + s.split("<")[0]
-        cnt[s.split("<")[0]] = c + 1
+            if base.startswith("conv_bwd_logits") or base == "pair_bwd_logits_kernel" or base.startswith("conv_narrow_bwd"):
+                bi += 1
+            lay = BWD[min(max(bi, 0), 7)]
+            if s.startswith("conv_w8_kernel<true"):
+                key = "bwd:%s/conv_w8_kernel<data>" % lay
+            elif base.startswith("conv_bwd_logits"):
+                key = "bwd:%s/%s" % (lay, base)
+            elif base == "pair_bwd_logits_kernel":
+                key = "bwd:%s/pair_bwd_logits_kernel" % lay
+            elif base.startswith("gemm_tn"):
+                key = "bwd:%s/gemm_tn_kernel:dW" % lay
+            elif base.startswith("mlp_bwd_dx"):
+                key = "bwd:mlp/mlp_bwd_kernel<dx>"
+            elif base.startswith("mlp_bwd_w"):
+                key = "bwd:mlp/mlp_bwd_kernel<w>"
+            elif base.startswith("mlp_bwd"):
+                key = "bwd:mlp/mlp_bwd_kernel"
         out.append(key)
     return out
 
