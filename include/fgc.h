@@ -198,14 +198,17 @@ typedef struct fgc_conv_desc {
      * product per fine node), y_i = (1/deg_i) sum_P mult_iP sum_m q_pPm h_Pm - the same sums as the fine form in another
      * order; fgc_conv_uses_pairs tells whether a descriptor qualifies.  All NULL / 0: the fine form. */
     const int32_t* pair_rowptr;  /* [n/4 + 1] */
-    const int32_t* pair_col;     /* [n_pairs] */
-    const uint32_t* pair_mul;    /* [n_pairs] */
+    const int32_t* pair_col;     /* [n_pairs]: source row of the parent (< src_rows); at least one readable entry */
+    const uint32_t* pair_mul;    /* [n_pairs]: four 8-bit multiplicities (fgc_pair_graph); at least one readable entry */
     int32_t n_pairs;
     int32_t max_pair_deg;        /* largest number of pairs of a block */
     int32_t max_pair_in_deg;     /* largest number of in-pairs of a coarse row (transposed pair graph); 0 = not known:
                                     forward only.  fgc_conv_bwd needs 1 .. 24 */
-    float* hc;                   /* [src_rows (or n/4), M*cout]: the transformed coarse rows, written by fgc_conv_fwd and
-                                    read again by fgc_conv_bwd (bf16 with FGC_CONV_BF16) */
+    float* hc;                   /* [src_rows (or n/4), M*cout], 16-byte aligned: the transformed coarse rows, written by
+                                    fgc_conv_fwd and read again by fgc_conv_bwd (bf16 with FGC_CONV_BF16).  A partial forward
+                                    call transforms the source rows [proj_row0, proj_row0 + proj_rows) only; with a tile_list
+                                    of no tiles it stops there, without a tile_list it then computes every block (a
+                                    facet-sharded caller: owned rows while the halo parents travel, then the rest) */
 } fgc_conv_desc;
 
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
@@ -287,7 +290,9 @@ typedef struct fgc_conv_bwd_io {
     const int32_t* tpair_rowptr; /* [n/4 + 1] */
     const int32_t* tpair_col;    /* [n_pairs]: block p of the in-pair */
     const int32_t* tpair_edge;   /* [n_pairs]: its pair id */
-    float* dt;                   /* [n_pairs, cout] (bf16 with FGC_CONV_BF16) */
+    float* dt;                   /* [n_pairs (+ incoming cross-shard pairs), cout], 16-byte aligned (bf16 with
+                                    FGC_CONV_BF16): stage 1|2 writes the rows of the owned pairs, stage 4 gathers the rows the
+                                    transposed pair graph names (tpair_edge), like dl */
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
