@@ -18,7 +18,9 @@ Design (MI355X-first, nothing traced or compiled at run time):
     results are bitwise reproducible;
   * the whole forward+backward enqueue is capturable into a hipGraph (``capture=True``).
 """
+import contextlib
 import ctypes as C
+import gc
 import os
 import math
 
@@ -123,6 +125,28 @@ def _graph_node_count(g):
     if rc != 0:
         raise RuntimeError("hipGraphGetNodes failed (%d): cannot tell whether a schedule segment has launches" % rc)
     return int(n.value)
+
+
+@contextlib.contextmanager
+def _no_gc_while_capturing():
+    """A stream capture must not be interrupted by Python's cyclic garbage collector.  A dead reference cycle that still owns
+    device objects - the hipGraphs and pool tensors of an earlier network, say - is freed whenever the collector happens to
+    run, and it runs on allocation counts: in the middle of a capture its destructors call hipGraphDestroy / hipFree, which
+    a capturing stream refuses; torch raises from a destructor and the process ABORTS (the round-3 abort, caught in round 4
+    with its stack: `Garbage-collecting` under `_capture_segments`).  torch.cuda.graph stopped
+    collecting in its __enter__ (torch.compiler.config.force_cudagraph_gc, default off), so: collect once before the
+    capture, keep the collector off until it has ended.  FGC_NO_CAPTURE_GC_GUARD=1 (developer switch): no guard."""
+    if os.environ.get("FGC_NO_CAPTURE_GC_GUARD", "0") == "1":
+        yield
+        return
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class _ConvLayer:
@@ -866,8 +890,9 @@ class FacetDenoiser:
         self.segment_nodes = getattr(self, "segment_nodes", [])
         while True:
             g = torch.cuda.CUDAGraph(keep_graph=True)
-            # (thread_local: the collective back end's watchdog thread may query its events while this thread captures)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            # (thread_local: the collective back end's watchdog thread may query its events while this thread captures;
+            #  no garbage collection inside the capture: _no_gc_while_capturing)
+            with _no_gc_while_capturing(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 try:
                     req = next(gen)
                 except StopIteration:
@@ -1090,7 +1115,7 @@ class FacetDenoiser:
                     self._enqueue_loss_backward(rotate)
                 torch.cuda.current_stream().wait_stream(s)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _no_gc_while_capturing(), torch.cuda.graph(g):
                     self._enqueue_forward(rotate, training=True)
                     self._enqueue_loss_backward(rotate)
                 self._graph_fb = (g, rotate)

@@ -293,3 +293,24 @@ def test_no_schedule_segment_is_an_empty_graph_and_back_to_back_requests_run(gol
         i = kinds.index(("call", False)) if ("call", False) in kinds else kinds.index(("call", True))
         assert kinds[i + 1] == ("sum", True), kinds[i:i + 2]
         assert bwd[-1][1] is None and bwd[-1][0] is None, "nothing is launched behind the last all-reduce"
+
+
+def test_capture_is_not_interrupted_by_the_garbage_collector():
+    """The round-3 abort, as the stack of its round-4 recurrence shows it: Python's cyclic collector ran inside a segment
+    capture (`Garbage-collecting` under net._capture_segments) and freed a dead cycle that owned an earlier network's
+    hipGraphs; hipGraphDestroy / hipFree are not allowed on a capturing stream, torch raised from a destructor, abort.
+    `net._no_gc_while_capturing` collects before a capture and keeps the collector off until it ends.  The probe sets the
+    situation up on purpose - dead cycles holding captured networks, then a capture with the collector's thresholds at 1 -
+    in a process of its own, with the guard on (tools/capture_gc_probe.py; its `noguard` mode is the experiment, not a test)."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools", "capture_gc_probe.py"), "guard"], cwd=repo,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "probe ok (guard)" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    # in-process: the collector is off inside the guard and back on after it
+    import gc
+    from facet_graph_convolution_amd.net import _no_gc_while_capturing
+    assert gc.isenabled()
+    with _no_gc_while_capturing():
+        assert not gc.isenabled()
+    assert gc.isenabled()
