@@ -885,29 +885,31 @@ class FacetDenoiser:
         into one graph each; the exchanges themselves (row gather + grouped point-to-point, all-reduces) stay eager
         calls between the replays - a collective is not a graph node here.  The schedule is static (same buffers, same
         tile lists, same message sizes every step), so the requests recorded with the graphs are replayed as they are."""
-        gen = make_gen()
-        segs = []
-        self.segment_nodes = getattr(self, "segment_nodes", [])
-        while True:
-            g = torch.cuda.CUDAGraph(keep_graph=True)
-            # (thread_local: the collective back end's watchdog thread may query its events while this thread captures;
-            #  no garbage collection inside the capture: _no_gc_while_capturing)
-            with _no_gc_while_capturing(), torch.cuda.graph(g, capture_error_mode="thread_local"):
-                try:
-                    req = next(gen)
-                except StopIteration:
-                    req = None
-            # a stretch WITHOUT launches (two requests back to back, or nothing behind the last one) is no graph at all:
-            # an empty hipGraph is never instantiated or replayed (segment_nodes keeps the counts for the tests)
-            nodes = _graph_node_count(g)
-            if nodes == 0:
-                g = None
-            else:
-                g.instantiate()
-            self.segment_nodes.append(nodes)
-            segs.append((g, req))
-            if req is None:
-                return segs
+        # (one collection in front of the first capture, the collector off until the last one has ended: a full collection
+        #  per segment - thirty a step and shard - made the capture of an 8-shard step take seconds)
+        with _no_gc_while_capturing():
+            gen = make_gen()
+            segs = []
+            self.segment_nodes = getattr(self, "segment_nodes", [])
+            while True:
+                g = torch.cuda.CUDAGraph(keep_graph=True)
+                # (thread_local: the collective back end's watchdog thread may query its events while this thread captures)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    try:
+                        req = next(gen)
+                    except StopIteration:
+                        req = None
+                # a stretch WITHOUT launches (two requests back to back, or nothing behind the last one) is no graph at all:
+                # an empty hipGraph is never instantiated or replayed (segment_nodes keeps the counts for the tests)
+                nodes = _graph_node_count(g)
+                if nodes == 0:
+                    g = None
+                else:
+                    g.instantiate()
+                self.segment_nodes.append(nodes)
+                segs.append((g, req))
+                if req is None:
+                    return segs
 
     def _replay_segments(self, segs):
         pending = {}
