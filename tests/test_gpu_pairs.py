@@ -170,3 +170,35 @@ def test_facet_sharded_network_uses_the_pair_form_too(golden_dir):
                 assert n.L.fgc_conv_uses_pairs(C.byref(d)) == 1
                 g = n._mesh["graphs"][0 if name == "upconv1" else 1]
                 assert d.src_rows == d.n // 4 + g.pair.n_halo and g.pair.n_halo <= g.n_halo
+
+
+def test_network_in_the_pair_form_equals_the_network_in_the_fine_form(monkeypatch):
+    """The whole training step with the two up-convolutions in the pair form against the same step with FGC_NO_PAIRS=1 (the
+    round-3 kernels): same sums in another order - normals within 1e-6, loss 1e-6 relative, every gradient within 2e-5 of its
+    tensor's largest entry - on a natively preprocessed torus (Morton order, fake rows in most blocks)."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import torus, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = torus(96, 64)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F, 0.2, seed=1), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FGC_NO_PAIRS", mode)
+        net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+        assert bool(net.pair_dims()) == (mode == "0")
+        net.set_samples(samp)
+        net.set_rotation(Rm)
+        loss = net.forward_backward(rotate=True)
+        torch.cuda.synchronize()
+        out[mode] = (net.buffers["nconv"].clone(), loss[0].item(), [g.clone() for g in net.params.grads])
+        del net
+    (n0, l0, g0), (n1, l1, g1) = out["0"], out["1"]
+    assert (n0 - n1).abs().max().item() < 1e-6
+    assert abs(l0 - l1) < 1e-6 * abs(l1)
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        assert (a - b).abs().max().item() < 2e-5 * max(b.abs().max().item(), 1e-3), i
