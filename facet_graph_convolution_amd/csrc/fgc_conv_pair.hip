@@ -41,6 +41,8 @@ bool pairs_ok(const fgc_conv_desc* d) {
     if (d->tile_list && d->n_tiles != 0) return false;
     const size_t rows = d->src_rows > 0 ? (size_t)d->src_rows : (size_t)(d->n >> 2);
     if (rows * FGC_M * d->cout * 4 >= 0xFFFFFFFFull || (size_t)d->n_pairs * d->cout * 4 >= 0xFFFFFFFFull) return false;
+    // (row ids of hc and dt go through 24-bit multiplies; dt also holds a facet-sharded rank's incoming cross pairs: a margin)
+    if (rows >= (1u << 24) || d->n_pairs >= (1 << 24) - (1 << 20)) return false;
     if (((uintptr_t)d->x0 | (uintptr_t)d->hc) % 16) return false;
     return true;
 }
