@@ -32,6 +32,10 @@ def test_single_gpu_line_has_the_contract_fields_and_family_rooflines():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f32" and j["vs_baseline"] is None
     assert abs(j["value"] - 48 * 40 * 2 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
     assert j["hipgraph_replay"]["matches_eager"] is True
+    # a mesh this small is timed as ONE replayed hipGraph per step (its launches take the host longer than the GPU), and says so
+    assert j["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph replay" in j["config"]["workload"]
+    e = _bench(SMALL + ["--graph", "0"])
+    assert e["hipgraph_replay"]["timed_region"] == "eager" and "hipGraph replay" not in e["config"]["workload"]
     fams = [f["family"] for f in j["families"]]
     assert len(fams) == 3 and "conv_w8" in fams and j["roofline"]["family"] == fams[0]
     assert 0 < j["roofline"]["frac"] < 1 and len(j["repeats_ms_per_step"]) == 2
