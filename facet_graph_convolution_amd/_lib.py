@@ -56,7 +56,18 @@ class ConvBwdIO(C.Structure):
     ]
 
 
+class PackExtra(C.Structure):
+    """struct fgc_pack_extra (include/fgc.h): the rotation and the MLP operands that ride on fgc_conv_pack's launch."""
+    _fields_ = [
+        ("rot_x", C.c_void_p), ("rot_y", C.c_void_p), ("rot_R", C.c_void_p), ("rot_rows", C.c_int64), ("rot_vecs", C.c_int32),
+        ("mlp_bf16", C.c_int32), ("mlp_W1", C.c_void_p), ("mlp_W2", C.c_void_p),
+        ("mlp_n", C.c_int32), ("mlp_cin", C.c_int32), ("mlp_hidden", C.c_int32), ("mlp_cout", C.c_int32),
+        ("mlp_fwd_ws", C.c_void_p), ("mlp_bwd_ws", C.c_void_p),
+    ]
+
+
 CONV_PACKED = 1
+MLP_PACKED = 1
 CONV_DEFER_REDUCE = 2
 CONV_SAVE_Z = 4
 CONV_BF16 = 8
@@ -108,26 +119,26 @@ _SIGS = {
     "fgc_conv_uses_pairs": (C.c_int, [C.POINTER(ConvDesc)]),
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_conv_pack": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)), C.POINTER(C.c_void_p),
-                                C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+                                C.POINTER(C.c_void_p), C.c_int32, C.POINTER(PackExtra), C.c_void_p]),
     "fgc_conv_bwd_reduce": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)),
                                       C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "fgc_mlp_num_partials": (C.c_int32, [C.c_int32]),
     "fgc_mlp_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "fgc_mlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "fgc_mlp_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
     "fgc_mlp_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                              C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_mlp_bf16_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "fgc_mlp_bwd_bf16_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "fgc_mlp_fwd_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
     "fgc_mlp_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_pool4_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_void_p]),
     "fgc_lrelu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),

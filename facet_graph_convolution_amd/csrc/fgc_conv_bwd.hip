@@ -182,7 +182,14 @@ __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
     const PackJob& j = J.job[q];
     const int bid = blockIdx.x - j.block0;
     const int nb = (q + 1 < J.njobs ? J.job[q + 1].block0 : J.nblocks) - j.block0;
-    if (j.kind == 7) pack_plain_bf16_body(j.W0, (unsigned short*)j.dst, j.kdim, bid, nb);
+    if (j.kind >= 8) {
+        if (j.kind == 8) rotate_rows_body(j.W0, j.dst, j.kdim, j.aux, bid, nb);
+        else if (j.kind == 9) mlp_pack_body(j.W0, j.dst, j.cin, j.kdim, j.ncols, bid, nb);
+        else if (j.kind == 10) mlp_pack_split_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
+        else if (j.kind == 11) mlp_pack_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
+        else if (j.kind == 12) mlp_pack_w1dx_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
+        else mlp_pack_w2_bf16_body(j.W0, (u32x4*)j.dst, j.ncols, j.cout, bid);
+    } else if (j.kind == 7) pack_plain_bf16_body(j.W0, (unsigned short*)j.dst, j.kdim, bid, nb);
     else if (j.kind == 6) pack_logit_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);
     else if (j.kind >= 4) pack_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.kdim, j.ncols, j.npad, j.passes,
                                                 j.kind - 4, bid, nb);
@@ -2083,7 +2090,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             if (rc) return rc;
         }
         if (stages & 8) {
-            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, (io->flags & FGC_CONV_DEFER_REDUCE) ? 1 : 7, nullptr,
+            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, (io->flags & FGC_CONV_DEFER_REDUCE) ? 1 : 3, nullptr,
                                    st);
             if (rc) return rc;
         }
@@ -2293,8 +2300,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
 // whole-network helpers: one launch where every layer used to bring its own
 // ---------------------------------------------------------------------------------------------
 extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* fwd_ws,
-                             void* const* bwd_ws, int32_t count, void* stream) {
-    FGC_CHECK_ARG(descs && count >= 0, "fgc_conv_pack: bad arguments");
+                             void* const* bwd_ws, int32_t count, const fgc_pack_extra* extra, void* stream) {
+    FGC_CHECK_ARG((descs || count == 0) && count >= 0, "fgc_conv_pack: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     PackJobs J;
     J.njobs = 0;
@@ -2350,6 +2357,21 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
             }
         }
     }
+    if (extra && extra->rot_x) {
+        const int64_t nvec = (int64_t)extra->rot_rows * extra->rot_vecs;
+        FGC_CHECK_ARG(extra->rot_y && extra->rot_R && extra->rot_rows > 0 && extra->rot_vecs > 0 && nvec < (1ll << 31),
+                      "fgc_conv_pack: extra: bad rotation (rows=%lld vecs=%d)", (long long)extra->rot_rows, extra->rot_vecs);
+        PackJob j{extra->rot_x, extra->rot_y, 8, 0, 0, (int)nvec, 0, 0, 0, 0, 0, 0, 0, extra->rot_R};
+        add(j, (size_t)nvec * 2);     // two 3-vectors per thread-iteration share
+    }
+    if (extra && extra->mlp_W1) {
+        PackJob mj[4];
+        size_t tot[4];
+        const int nj = extra->mlp_bf16 ? mlp_pack_jobs_bf16(extra, mj, tot) : mlp_pack_jobs_f32(extra, mj, tot);
+        FGC_CHECK_ARG(nj >= 0, "fgc_conv_pack: extra: MLP shape cin=%d hidden=%d cout=%d n=%d not served%s", extra->mlp_cin,
+                      extra->mlp_hidden, extra->mlp_cout, extra->mlp_n, extra->mlp_bf16 ? " (bf16)" : "");
+        for (int i = 0; i < nj; ++i) add(mj[i], tot[i]);
+    }
     flush();
     FGC_CHECK_LAUNCH("fgc_conv_pack");
     return FGC_OK;
@@ -2378,20 +2400,12 @@ extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_
         if (io->dx0 == nullptr && w.narrow) {
             rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, 0, jobs + nj, st);
             if (rc) return rc;
-            nj += 3;
+            nj += NARROW_RED_JOBS;
         } else {
             conv_param_jobs(d, io, w, jobs + nj);
             nj += 5;
         }
     }
     if ((rc = flush())) return rc;
-    // the narrow first layer turns its reduced sums into dW0 / du / dv / dc
-    for (int i = 0; i < count; ++i) {
-        const BwdWorkspace w = plan_bwd(descs[i], (char*)bwd_ws[i]);
-        if (ios[i]->dx0 == nullptr && w.narrow) {
-            rc = narrow_bwd_params(descs[i], ios[i], w.narrow, w.db_part, w.nb_db, 4, nullptr, st);
-            if (rc) return rc;
-        }
-    }
     return FGC_OK;
 }

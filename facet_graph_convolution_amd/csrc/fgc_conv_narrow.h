@@ -17,9 +17,10 @@ int narrow_zld(int cin);
 int narrow_splits(const fgc_conv_desc* d);
 size_t narrow_bwd_floats(const fgc_conv_desc* d);
 int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, hipStream_t st);
-// parts: 1 = weight-gradient GEMM, 2 = the fixed-order sums, 4 = dW0 / du / dv / dc out of the sums; jobs_out (may be
-// NULL) receives the three reduction jobs so that a caller can run them together with other layers'
+// parts: 1 = weight-gradient GEMM, 2 = the fixed-order sums (they write dW0 / du / dv / dc / db); jobs_out (may be NULL)
+// receives the NARROW_RED_JOBS reduction jobs so that a caller can run them together with other layers'
 struct RedJob;
+constexpr int NARROW_RED_JOBS = 5;
 int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
                       int nb_db, int parts, RedJob* jobs_out, hipStream_t st);
 

@@ -497,23 +497,6 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
     }
 }
 
-// du/dv from their [9][CIN] slots to [9][cin]; dW0[m][o][c] = T[(m * CIN + c) * cout + o]
-__global__ void narrow_finish_kernel(const float* __restrict__ uvc /* [NARROW_PART] */, const float* __restrict__ T,
-                                     int CIN, int cin, int cout, float* __restrict__ du, float* __restrict__ dv,
-                                     float* __restrict__ dc, float* __restrict__ dW0) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < FGC_M * cin) {
-        const int m = k / cin, c = k % cin;
-        du[k] = uvc[m * CIN + c];
-        dv[k] = uvc[FGC_M * CIN + m * CIN + c];
-    }
-    if (k < FGC_M) dc[k] = uvc[2 * FGC_M * CIN + k];
-    if (k < FGC_M * cout * cin) {
-        const int c = k % cin, o = (k / cin) % cout, m = k / (cin * cout);
-        dW0[k] = T[(size_t)(m * CIN + c) * cout + o];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -640,9 +623,7 @@ int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     float* zbuf = scratch;
     float* part = zbuf + (size_t)d->n * zld + 64;
     float* slab = part + (size_t)nblk * NARROW_PART + 64;
-    float* T = slab + (size_t)splits * zld * cout + 64;
-    float* uvc = T + (size_t)zld * cout;
-    float* rtmp = uvc + NARROW_PART + 64;
+    float* rtmp = slab + (size_t)splits * zld * cout + 64;
     const int rps = cdiv(cdiv(d->n, splits), 4) * 4;
     const int ns = cdiv(d->n, rps);
     int rc = 0;
@@ -651,22 +632,21 @@ int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
                                    ns, slab, st);
         if (rc) return rc;
     }
-    const RedJob jobs[3] = {
-        {slab, (size_t)zld * cout, ns, zld * cout, cout, cout, T, rtmp},
-        {part, (size_t)NARROW_PART, nblk, NARROW_PART, NARROW_PART, NARROW_PART, uvc},
+    // dW0[m][o][c] is the z^T s product [m * cin + c][o] summed over its slabs and written transposed per m; du / dv / dc are
+    // three ranges of the logit kernel's per-workgroup partial rows
+    RedJob jobs[NARROW_RED_JOBS] = {
+        {slab, (size_t)zld * cout, ns, zld * cout, cout, FGC_M * CIN, io->dW0, rtmp},
+        {part, (size_t)NARROW_PART, nblk, FGC_M * CIN, FGC_M * CIN, FGC_M * CIN, io->du},
+        {part + FGC_M * CIN, (size_t)NARROW_PART, nblk, FGC_M * CIN, FGC_M * CIN, FGC_M * CIN, io->dv},
+        {part + 2 * FGC_M * CIN, (size_t)NARROW_PART, nblk, FGC_M, FGC_M, FGC_M, io->dc},
         {db_part, (size_t)cout, nb_db, cout, cout, cout, io->db},
     };
+    jobs[0].tr = CIN;
     if (jobs_out)
-        for (int q = 0; q < 3; ++q) jobs_out[q] = jobs[q];
+        for (int q = 0; q < NARROW_RED_JOBS; ++q) jobs_out[q] = jobs[q];
     if (parts & 2) {
-        rc = reduce_jobs("reduce:params", jobs, 3, nullptr, st);
+        rc = reduce_jobs("reduce:params", jobs, NARROW_RED_JOBS, nullptr, st);
         if (rc) return rc;
-    }
-    if (parts & 4) {
-        const int total = FGC_M * cout * cin;
-        FGC_LAUNCH("narrow_finish_kernel", st, narrow_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, uvc, T, CIN, cin,
-                   cout, io->du, io->dv, io->dc, io->dW0);
-        FGC_CHECK_LAUNCH("narrow_finish_kernel");
     }
     return FGC_OK;
 }

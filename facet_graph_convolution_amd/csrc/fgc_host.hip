@@ -97,7 +97,7 @@ extern "C" int fgc_profile_collect(char* buf, int32_t buf_bytes) {
 extern "C" const char* fgc_last_error(void) { return fgc::g_err; }
 extern "C" int fgc_version(void) { return 101; }
 extern "C" size_t fgc_struct_size(int32_t which) {
-    return which == 0 ? sizeof(fgc_conv_desc) : (which == 1 ? sizeof(fgc_conv_bwd_io) : 0);
+    return which == 0 ? sizeof(fgc_conv_desc) : (which == 1 ? sizeof(fgc_conv_bwd_io) : (which == 2 ? sizeof(fgc_pack_extra) : 0));
 }
 
 // K-list -> CSR, slot order and duplicates preserved (model.py:380-405 gathers every non-zero slot;

@@ -4,6 +4,7 @@
 #include <math.h>
 
 #include "fgc_common.h"
+#include "fgc_pack.h"
 
 namespace fgc {
 
@@ -444,15 +445,7 @@ __global__ __launch_bounds__(256) void loss_step_rows_kernel(const float* __rest
 // ---- rotation augmentation (train.py:439-451) ---------------------------------------------------
 __global__ void rotate_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t nvec,
                                    const float* __restrict__ Rd) {
-    float r[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r[i] = Rd[i];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
-        y[3 * i] = r[0] * a + r[1] * b + r[2] * c;
-        y[3 * i + 1] = r[3] * a + r[4] * b + r[5] * c;
-        y[3 * i + 2] = r[6] * a + r[7] * b + r[8] * c;
-    }
+    rotate_rows_body(x, y, nvec, Rd, blockIdx.x, gridDim.x);
 }
 
 // ---- TF1 Adam ------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 
 #include "fgc_reduce.h"
 #include "fgc_mlp_split.h"
+#include "fgc_pack.h"
 
 namespace fgc {
 
@@ -25,15 +26,7 @@ constexpr int MLP_DHS = 20;    // transposed dh rows
 
 // W1 [cin, hidden] -> Wp1[k/4][hidden][k%4], k padded to a multiple of 16 with zeros
 __global__ void mlp_pack_kernel(const float* __restrict__ W1, float* __restrict__ Wp, int cin, int kpad, int hidden) {
-    const size_t total = (size_t)kpad * hidden;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 3;
-        const size_t v4 = idx >> 2;
-        const int col = v4 % hidden;
-        const int k = (int)(v4 / hidden) * 4 + e;
-        Wp[idx] = k < cin ? W1[(size_t)k * hidden + col] : 0.f;
-    }
+    mlp_pack_body(W1, Wp, cin, kpad, hidden, blockIdx.x, gridDim.x);
 }
 
 template <int T = MLP_T>
@@ -505,6 +498,34 @@ static int mlp_bwd_gx(int n) {
     return ntiles < 128 ? ntiles : 128;
 }
 
+namespace fgc {
+// fgc_conv_pack's view of the two workspaces: the forward operand at the start of mlp_fwd_ws (split planes where the shape
+// takes the split path, else the k-interleaved fp32 operand), the backward operand at the start of mlp_bwd_ws
+int mlp_pack_jobs_f32(const fgc_pack_extra* e, PackJob* jobs, size_t* totals) {
+    const int cin = e->mlp_cin, hidden = e->mlp_hidden, cout = e->mlp_cout;
+    if (cin <= 0 || cin > 128 || hidden <= 0 || hidden % 64 != 0 || cout <= 0 || cout > MLP_COUT_MAX) return -1;
+    int nj = 0;
+    if (e->mlp_fwd_ws) {
+        if ((uintptr_t)e->mlp_fwd_ws % 16 != 0) return -1;
+        if (mlp_fwd_split_ok(nullptr, cin, hidden, cout)) {
+            jobs[nj] = PackJob{e->mlp_W1, (float*)e->mlp_fwd_ws, 10, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+            totals[nj++] = (size_t)cin * hidden;
+        } else {
+            const int kpad = mlp_kpad(cin);
+            jobs[nj] = PackJob{e->mlp_W1, (float*)e->mlp_fwd_ws, 9, cin, cout, kpad, hidden, 0, 0, 0, 0, 0, 0};
+            totals[nj++] = (size_t)kpad * hidden;
+        }
+    }
+    if (e->mlp_bwd_ws) {
+        if (hidden % 256 != 0) return -1;
+        const int kpad = mlp_bwd_kpad(cin);
+        jobs[nj] = PackJob{e->mlp_W1, (float*)e->mlp_bwd_ws, 9, cin, cout, kpad, hidden, 0, 0, 0, 0, 0, 0};
+        totals[nj++] = (size_t)kpad * hidden;
+    }
+    return nj;
+}
+}  // namespace fgc
+
 extern "C" int32_t fgc_mlp_num_partials(int32_t n) { return cdiv(n, MLP_T); }
 
 extern "C" size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout) {
@@ -530,8 +551,9 @@ extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hi
 
 extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
                            const float* b1, const float* W2, const float* b2, float alpha, float* y,
-                           float* abs_partial, void* workspace, size_t workspace_bytes, void* stream) {
+                           float* abs_partial, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
     FGC_CHECK_ARG(x && W1 && b1 && W2 && b2 && y, "fgc_mlp_fwd: null pointer");
+    const bool packed = (flags & FGC_MLP_PACKED) != 0;
     FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 128, "fgc_mlp_fwd: n=%d cin=%d (cin must be in [1,128])", n, cin);
     FGC_CHECK_ARG(hidden > 0 && hidden % 64 == 0, "fgc_mlp_fwd: hidden=%d must be a multiple of 64", hidden);
     FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_fwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
@@ -542,11 +564,16 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
     // the two 1024-wide products on the bf16 matrix pipe with three-term operand splits (fgc_mlp_bf16.hip) where the shape
     // allows: fp32-equivalent results, the matrix time a sixth of the fp32 MFMA's
     if (mlp_fwd_split_ok(x, cin, hidden, cout) && (uintptr_t)workspace % 16 == 0)
-        return launch_mlp_fwd_split(x, n, cin, hidden, cout, W1, b1, W2, b2, alpha, y, abs_partial, workspace, st);
+        return launch_mlp_fwd_split(x, n, cin, hidden, cout, W1, b1, W2, b2, alpha, y, abs_partial, workspace, packed, st);
+    // (the operands fgc_conv_pack leaves are the split planes whenever the SHAPE takes the split path)
+    FGC_CHECK_ARG(!packed || !mlp_fwd_split_ok(nullptr, cin, hidden, cout),
+                  "fgc_mlp_fwd: FGC_MLP_PACKED needs 16-byte aligned x and workspace for this shape");
     const int kpad = mlp_kpad(cin);
     float* Wp = (float*)workspace;
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
-    FGC_CHECK_LAUNCH("fgc_mlp_fwd/pack");
+    if (!packed) {
+        FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
+        FGC_CHECK_LAUNCH("fgc_mlp_fwd/pack");
+    }
     const size_t smem = (size_t)(MLP_T * (kpad + MLP_XPAD) + 4 * MLP_T * 4 + 4) * 4;
 #define FGC_MLP_FWD_LAUNCH(KG)                                                                                     \
     do {                                                                                                           \
@@ -567,7 +594,7 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
 
 extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
                            const float* W1, const float* b1, const float* W2, float alpha, float* dx, float* dW1,
-                           float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes,
+                           float* db1, float* dW2, float* db2, int32_t flags, void* workspace, size_t workspace_bytes,
                            void* stream) {
     FGC_CHECK_ARG(x && dy && W1 && b1 && W2 && dx && dW1 && db1 && dW2 && db2, "fgc_mlp_bwd: null pointer");
     FGC_CHECK_ARG(n > 0 && cin > 0 && cin <= 128, "fgc_mlp_bwd: n=%d cin=%d (cin must be in [1,128])", n, cin);
@@ -596,8 +623,10 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     w += align_up((size_t)1024 * 4 * 4, 256);
     float* rtmp = (float*)w;
 
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
-    FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
+    if (!(flags & FGC_MLP_PACKED)) {
+        FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_kernel, dim3(cdiv(kpad * hidden, 1024)), dim3(256), 0, W1, Wp, cin, kpad, hidden);
+        FGC_CHECK_LAUNCH("fgc_mlp_bwd/pack");
+    }
     const int hcw = 64 * ctw;   // + the workgroup's weight slice [kpad/4][hcw+1][4], b1 [hcw], W2 [hcw][4]
     const size_t smem = (size_t)(BWD_T * (kpad + MLP_XPAD) + BWD_T * 4 + 4 * BWD_T * MLP_DHS + (ctw == 4 ? 4 : 1) * BWD_T * (kpad + MLP_XPAD) +
                                  4 + (kpad / 4) * (hcw + 1) * 4 + hcw * 5) * 4;

@@ -15,6 +15,7 @@
 
 #include "fgc_reduce.h"
 #include "fgc_mlp_split.h"
+#include "fgc_pack.h"
 
 namespace fgc {
 
@@ -24,61 +25,14 @@ constexpr int MB_FWD_RT = MB_FWD_T / 16;
 constexpr int MB_T = 32;           // rows per backward tile
 constexpr int MB_RT = MB_T / 16;
 
-// W1 [cin, hidden] fp32 -> B fragments [k-step][column tile][lane][8] bf16 (k = input channel, 32 per step)
-__device__ __forceinline__ void mlp_pack_bf16_body(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden,
-                                                   int bid, int nb) {
-    const int nct = hidden >> 4;
-    const size_t total = (size_t)(cin >> 5) * nct * 512;
-    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
-        const int j = idx & 7, lane = (idx >> 3) & 63;
-        const size_t rest = idx >> 9;
-        const int ct = rest % nct, ks = (int)(rest / nct);
-        const int c = ks * 32 + 8 * (lane >> 4) + j;
-        Wp[idx] = f_to_bf(W1[(size_t)c * hidden + ct * 16 + (lane & 15)]);
-    }
-}
 __global__ void mlp_pack_bf16_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
     mlp_pack_bf16_body(W1, Wp, cin, hidden, blockIdx.x, gridDim.x);
 }
 
-// The 1024 -> 3 layer of the backward pass on the matrix pipe.  g[row][col] = sum_o dy[row][o] W2[col][o] has K = 3: on the
-// vector ALU it cost three FMAs per hidden element, a third of the kernel's vector work.  One bf16 MFMA has 32 k slots:
-// slots 0-2 carry dy_hi x W2_hi, 3-5 dy_lo x W2_hi, 8-10 dy_hi x W2_lo (v_hi = bf16(v), v_lo = bf16(v - v_hi): 16
-// significand bits per operand; g is rounded to bf16 right afterwards for the products that consume it).
-//   A (per 16 rows):  lane (lr = row, lq):  lq 0: {hi0 hi1 hi2 lo0 lo1 lo2 0 0}   lq 1: {hi0 hi1 hi2 0 ...}   else 0
-//   B (per 16 hidden columns, packed once per launch): lq 0: {Whi0-2 Whi0-2 0 0}   lq 1: {Wlo0-2 0 ...}   else 0
-__device__ __forceinline__ void mlp_pack_w2_bf16_body(const float* __restrict__ W2, u32x4* __restrict__ W2p, int hidden, int cout,
-                                                      int bid) {
-    const int idx = bid * blockDim.x + threadIdx.x;
-    if (idx >= (hidden >> 4) * 32) return;       // lanes 0..31 of a fragment (lq 0 and 1); lanes 32..63 are zero, not stored
-    const int lane = idx & 31, ct = idx >> 5, lr = lane & 15, lq = lane >> 4;
-    unsigned short hi[3], lo[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const float w = o < cout ? W2[(size_t)(ct * 16 + lr) * cout + o] : 0.f;
-        hi[o] = f_to_bf(w);
-        lo[o] = f_to_bf(w - bf_to_f(hi[o]));
-    }
-    W2p[idx] = lq == 0 ? u32x4{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[0] << 16), hi[1] | ((unsigned)hi[2] << 16), 0u}
-                       : u32x4{lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2], 0u, 0u};
-}
+// (operand packs of the backward pass: fgc_pack.h)
 __device__ __forceinline__ u32x4 mb_w2_frag(const u32x4* __restrict__ W2p, int ct, int lane) {
     const u32x4 v = W2p[ct * 32 + (lane & 31)];
     return lane < 32 ? v : u32x4{0u, 0u, 0u, 0u};
-}
-// W1 [cin, hidden] fp32 -> B fragments of dx += dh W1^T in the k order of the dx kernel's transposed dh (pair pp of column
-// tiles, input-channel tile m, lane (lr = channel, lq)): element j = c2*4 + t is W1[m*16 + lr][pp*32 + c2*16 + 4*lq + t]
-__device__ __forceinline__ void mlp_pack_w1dx_bf16_body(const float* __restrict__ W1, unsigned short* __restrict__ Wd, int cin,
-                                                        int hidden, int bid, int nb) {
-    const size_t total = (size_t)cin * hidden;
-    const int mt = cin >> 4;
-    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
-        const int j = idx & 7, lane = (idx >> 3) & 63;
-        const size_t rest = idx >> 9;
-        const int m = rest % mt, pp = (int)(rest / mt);
-        const int ch = m * 16 + (lane & 15), col = pp * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
-        Wd[idx] = f_to_bf(W1[(size_t)ch * hidden + col]);
-    }
 }
 // the three operand packs of the backward pass in one launch: blocks [0, nb) W1 fragments, [nb, 2 nb) W1 in dx order, the rest W2
 __global__ void mlp_pack_bwd_bf16_kernel(const float* __restrict__ W1, const float* __restrict__ W2, unsigned short* __restrict__ Wp,
@@ -234,22 +188,7 @@ __device__ __forceinline__ void split3(const f32x4& v, u32x2& p0, u32x2& p1, u32
 
 // W1 [cin, hidden] fp32 -> three planes of B fragments [plane][k-step][column tile][lane][8] bf16
 __global__ void mlp_pack_split_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
-    const int nct = hidden >> 4;
-    const size_t total = (size_t)(cin >> 5) * nct * 512;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int j = idx & 7, lane = (idx >> 3) & 63;
-        const size_t rest = idx >> 9;
-        const int ct = rest % nct, ks = (int)(rest / nct);
-        const int c = ks * 32 + 8 * (lane >> 4) + j;
-        const float w = W1[(size_t)c * hidden + ct * 16 + (lane & 15)];
-        const unsigned short w0 = f_to_bf(w);
-        const float r1 = w - bf_to_f(w0);
-        const unsigned short w1 = f_to_bf(r1);
-        const unsigned short w2 = f_to_bf(r1 - bf_to_f(w1));
-        Wp[idx] = w0;
-        Wp[total + idx] = w1;
-        Wp[2 * total + idx] = w2;
-    }
+    mlp_pack_split_body(W1, Wp, cin, hidden, blockIdx.x, gridDim.x);
 }
 
 // six MFMAs of one split product, smallest terms first
@@ -743,9 +682,10 @@ bool mlp_fwd_split_ok(const float* x, int cin, int hidden, int cout) {
     return mlp_split_enabled() && (cin == 32 || cin == 64) && hidden % 256 == 0 && cout <= 4 && (uintptr_t)x % 16 == 0;
 }
 int launch_mlp_fwd_split(const float* x, int n, int cin, int hidden, int cout, const float* W1, const float* b1, const float* W2,
-                         const float* b2, float alpha, float* y, float* abs_partial, void* workspace, hipStream_t st) {
+                         const float* b2, float alpha, float* y, float* abs_partial, void* workspace, bool packed, hipStream_t st) {
     unsigned short* Wp = (unsigned short*)workspace;
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_split_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
+    if (!packed)
+        FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_split_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
     const u32x4* Wp16 = (const u32x4*)Wp;
     const dim3 grid(cdiv(n, MB_FWD_T));
 #define FGC_MS_FWD(KS)                                                                                                       \
@@ -784,6 +724,36 @@ extern "C" size_t fgc_mlp_bwd_bf16_workspace_bytes(int32_t n, int32_t cin, int32
     return b;
 }
 
+namespace fgc {
+// byte offset of the W2 fragments in the backward workspace (behind the two W1 operands and the gradient slabs)
+static size_t mb_w2p_offset(int n, int cin, int hidden) {
+    const size_t gx = mb_gx(n);
+    return 2 * align_up((size_t)cin * hidden * 2, 256) + align_up(gx * (size_t)cin * hidden * 4, 256) +
+           align_up(gx * (size_t)hidden * 4, 256) + align_up(gx * (size_t)hidden * 4 * 4, 256) + align_up((size_t)1024 * 4 * 4, 256);
+}
+int mlp_pack_jobs_bf16(const fgc_pack_extra* e, PackJob* jobs, size_t* totals) {
+    const int cin = e->mlp_cin, hidden = e->mlp_hidden, cout = e->mlp_cout;
+    if (!(cin == 32 || cin == 64 || cin == 128) || hidden <= 0 || hidden % 256 != 0 || cout <= 0 || cout > 4) return -1;
+    int nj = 0;
+    if (e->mlp_fwd_ws) {
+        if ((uintptr_t)e->mlp_fwd_ws % 16 != 0) return -1;
+        jobs[nj] = PackJob{e->mlp_W1, (float*)e->mlp_fwd_ws, 11, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+        totals[nj++] = (size_t)cin * hidden;
+    }
+    if (e->mlp_bwd_ws) {
+        if ((uintptr_t)e->mlp_bwd_ws % 16 != 0 || cin == 128 || cout > 3 || e->mlp_n <= 0 || !e->mlp_W2) return -1;
+        char* w = (char*)e->mlp_bwd_ws;
+        jobs[nj] = PackJob{e->mlp_W1, (float*)w, 11, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+        totals[nj++] = (size_t)cin * hidden;
+        jobs[nj] = PackJob{e->mlp_W1, (float*)(w + align_up((size_t)cin * hidden * 2, 256)), 12, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+        totals[nj++] = (size_t)cin * hidden;
+        jobs[nj] = PackJob{e->mlp_W2, (float*)(w + mb_w2p_offset(e->mlp_n, cin, hidden)), 13, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+        totals[nj++] = (size_t)cdiv((hidden >> 4) * 32, 256) * 1024;
+    }
+    return nj;
+}
+}  // namespace fgc
+
 static int mlp_bf16_check(const char* who, const void* x, int n, int cin, int hidden, int cout) {
     FGC_CHECK_ARG(x && n > 0, "%s: null x / n=%d", who, n);
     FGC_CHECK_ARG(cin == 32 || cin == 64 || cin == 128, "%s: cin=%d (the bf16 MLP takes 32, 64 or 128 input channels)", who, cin);
@@ -799,7 +769,7 @@ static int mlp_bf16_alpha(const char* who, float alpha) {
 
 extern "C" int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
                                 const float* b1, const float* W2, const float* b2, float alpha, float* y,
-                                float* abs_partial, void* workspace, size_t workspace_bytes, void* stream) {
+                                float* abs_partial, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = mlp_bf16_check("fgc_mlp_fwd_bf16", x, n, cin, hidden, cout);
     if (rc) return rc;
     if ((rc = mlp_bf16_alpha("fgc_mlp_fwd_bf16", alpha))) return rc;
@@ -808,7 +778,8 @@ extern "C" int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t h
                   "fgc_mlp_fwd_bf16: workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;
     unsigned short* Wp = (unsigned short*)workspace;
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
+    if (!(flags & FGC_MLP_PACKED))
+        FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bf16_kernel, dim3(cdiv(cin * hidden, 1024)), dim3(256), 0, W1, Wp, cin, hidden);
     const unsigned short* x16 = (const unsigned short*)x;
     const u32x4* Wp16 = (const u32x4*)Wp;
     const dim3 grid(cdiv(n, MB_FWD_T));
@@ -831,7 +802,7 @@ extern "C" int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t h
 
 extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
                                 const float* W1, const float* b1, const float* W2, float alpha, void* dx, float* dW1,
-                                float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes,
+                                float* db1, float* dW2, float* db2, int32_t flags, void* workspace, size_t workspace_bytes,
                                 void* stream) {
     int rc = mlp_bf16_check("fgc_mlp_bwd_bf16", x, n, cin, hidden, cout);
     if (rc) return rc;
@@ -861,8 +832,9 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
     float* rtmp = (float*)w;
 
     const int nbp = cdiv(cin * hidden, 1024);
-    FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bwd_bf16_kernel, dim3(2 * nbp + cdiv((hidden >> 4) * 32, 256)), dim3(256), 0, W1, W2, Wp,
-               W1h, W2p, cin, hidden, cout, nbp);
+    if (!(flags & FGC_MLP_PACKED))
+        FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bwd_bf16_kernel, dim3(2 * nbp + cdiv((hidden >> 4) * 32, 256)), dim3(256), 0, W1, W2, Wp,
+                   W1h, W2p, cin, hidden, cout, nbp);
     const unsigned short* x16 = (const unsigned short*)x;
     const u32x4* Wp16 = (const u32x4*)Wp;
     const int tiles = cdiv(n, MB_T);

@@ -93,20 +93,131 @@ __device__ __forceinline__ void pack_plain_bf16_body(const float* __restrict__ W
     for (int i = bid * blockDim.x + threadIdx.x; i < count; i += nb * blockDim.x) Wb[i] = f_to_bf(W0[i]);
 }
 
+// ---- operands of the per-facet MLP (fgc_mlp.hip, fgc_mlp_bf16.hip) and the rotation of the input rows: device bodies here so
+// ---- that the step's one housekeeping launch (fgc_conv_pack with an fgc_pack_extra) can run them beside the conv packs
+
+// W1 [cin, hidden] -> Wp1[k/4][hidden][k%4], k padded to kpad with zeros
+__device__ __forceinline__ void mlp_pack_body(const float* __restrict__ W1, float* __restrict__ Wp, int cin, int kpad, int hidden,
+                                              int bid, int nb) {
+    const size_t total = (size_t)kpad * hidden;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
+        const int e = idx & 3;
+        const size_t v4 = idx >> 2;
+        const int col = v4 % hidden;
+        const int k = (int)(v4 / hidden) * 4 + e;
+        Wp[idx] = k < cin ? W1[(size_t)k * hidden + col] : 0.f;
+    }
+}
+
+// W1 [cin, hidden] fp32 -> B fragments [k-step][column tile][lane][8] bf16 (k = input channel, 32 per step)
+__device__ __forceinline__ void mlp_pack_bf16_body(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden,
+                                                   int bid, int nb) {
+    const int nct = hidden >> 4;
+    const size_t total = (size_t)(cin >> 5) * nct * 512;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int ct = rest % nct, ks = (int)(rest / nct);
+        const int c = ks * 32 + 8 * (lane >> 4) + j;
+        Wp[idx] = f_to_bf(W1[(size_t)c * hidden + ct * 16 + (lane & 15)]);
+    }
+}
+
+// the same fragments as three planes hi / mid / lo of a three-term split (v = bf16(v) + bf16(v - v0) + bf16(v - v0 - v1))
+__device__ __forceinline__ void mlp_pack_split_body(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden,
+                                                    int bid, int nb) {
+    const int nct = hidden >> 4;
+    const size_t total = (size_t)(cin >> 5) * nct * 512;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int ct = rest % nct, ks = (int)(rest / nct);
+        const int c = ks * 32 + 8 * (lane >> 4) + j;
+        const float w = W1[(size_t)c * hidden + ct * 16 + (lane & 15)];
+        const unsigned short w0 = f_to_bf(w);
+        const float r1 = w - bf_to_f(w0);
+        const unsigned short w1 = f_to_bf(r1);
+        const unsigned short w2 = f_to_bf(r1 - bf_to_f(w1));
+        Wp[idx] = w0;
+        Wp[total + idx] = w1;
+        Wp[2 * total + idx] = w2;
+    }
+}
+
+// The 1024 -> 3 layer of the bf16 backward pass on the matrix pipe.  g[row][col] = sum_o dy[row][o] W2[col][o] has K = 3: on the
+// vector ALU it cost three FMAs per hidden element, a third of the kernel's vector work.  One bf16 MFMA has 32 k slots:
+// slots 0-2 carry dy_hi x W2_hi, 3-5 dy_lo x W2_hi, 8-10 dy_hi x W2_lo (v_hi = bf16(v), v_lo = bf16(v - v_hi): 16
+// significand bits per operand; g is rounded to bf16 right afterwards for the products that consume it).
+//   A (per 16 rows):  lane (lr = row, lq):  lq 0: {hi0 hi1 hi2 lo0 lo1 lo2 0 0}   lq 1: {hi0 hi1 hi2 0 ...}   else 0
+//   B (per 16 hidden columns, packed once per launch): lq 0: {Whi0-2 Whi0-2 0 0}   lq 1: {Wlo0-2 0 ...}   else 0
+__device__ __forceinline__ void mlp_pack_w2_bf16_body(const float* __restrict__ W2, u32x4* __restrict__ W2p, int hidden, int cout,
+                                                      int bid) {
+    const int idx = bid * blockDim.x + threadIdx.x;
+    if (idx >= (hidden >> 4) * 32) return;       // lanes 0..31 of a fragment (lq 0 and 1); lanes 32..63 are zero, not stored
+    const int lane = idx & 31, ct = idx >> 5, lr = lane & 15, lq = lane >> 4;
+    unsigned short hi[3], lo[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float w = o < cout ? W2[(size_t)(ct * 16 + lr) * cout + o] : 0.f;
+        hi[o] = f_to_bf(w);
+        lo[o] = f_to_bf(w - bf_to_f(hi[o]));
+    }
+    W2p[idx] = lq == 0 ? u32x4{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[0] << 16), hi[1] | ((unsigned)hi[2] << 16), 0u}
+                       : u32x4{lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2], 0u, 0u};
+}
+// W1 [cin, hidden] fp32 -> B fragments of dx += dh W1^T in the k order of the dx kernel's transposed dh (pair pp of column
+// tiles, input-channel tile m, lane (lr = channel, lq)): element j = c2*4 + t is W1[m*16 + lr][pp*32 + c2*16 + 4*lq + t]
+__device__ __forceinline__ void mlp_pack_w1dx_bf16_body(const float* __restrict__ W1, unsigned short* __restrict__ Wd, int cin,
+                                                        int hidden, int bid, int nb) {
+    const size_t total = (size_t)cin * hidden;
+    const int mt = cin >> 4;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int m = rest % mt, pp = (int)(rest / mt);
+        const int ch = m * 16 + (lane & 15), col = pp * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
+        Wd[idx] = f_to_bf(W1[(size_t)ch * hidden + col]);
+    }
+}
+
+// rotation augmentation (train.py:439-451): every 3-vector of x times R^T
+__device__ __forceinline__ void rotate_rows_body(const float* __restrict__ x, float* __restrict__ y, int64_t nvec,
+                                                 const float* __restrict__ Rd, int bid, int nb) {
+    float r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = Rd[i];
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)nb * blockDim.x) {
+        const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+        y[3 * i] = r[0] * a + r[1] * b + r[2] * c;
+        y[3 * i + 1] = r[3] * a + r[4] * b + r[5] * c;
+        y[3 * i + 2] = r[6] * a + r[7] * b + r[8] * c;
+    }
+}
+
 // every packed operand of several layers in one launch (fgc_conv_pack)
 struct PackJob {
     const float* W0;
     float* dst;
     int kind;   // 0: forward operand, 1: data-gradient operand (transposed), 2: d-logits operand; +4: the bf16 forms;
-                // 7: plain bf16 copy of W0 (pair form; kdim = element count)
+                // 7: plain bf16 copy of W0 (pair form; kdim = element count);
+                // 8: rotate_rows_body (W0 = x, dst = y, aux = R, kdim = 3-vectors);
+                // MLP operands, W0 = W1 [cin, ncols]: 9 mlp_pack_body (kdim = kpad), 10 mlp_pack_split_body,
+                // 11 mlp_pack_bf16_body, 12 mlp_pack_w1dx_bf16_body; 13 mlp_pack_w2_bf16_body (W0 = W2 [ncols, cout])
     int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
     int block0;
+    const float* aux;
 };
-constexpr int PACK_MAX_JOBS = 24;
+constexpr int PACK_MAX_JOBS = 28;
 struct PackJobs {
     PackJob job[PACK_MAX_JOBS];
     int njobs, nblocks;
 };
 __global__ void pack_many_kernel(PackJobs J);
+
+// host side: the jobs that leave an MLP's operands in the workspaces of fgc_mlp_fwd / fgc_mlp_bwd (fgc_mlp.hip) or of their
+// bf16 forms (fgc_mlp_bf16.hip) exactly as those entry points lay them out themselves; `totals[i]` = elements of job i (a
+// workgroup takes 1024).  Return the number of jobs written (<= 4), or -1 for a shape the entry points refuse.
+int mlp_pack_jobs_f32(const fgc_pack_extra* e, PackJob* jobs, size_t* totals);
+int mlp_pack_jobs_bf16(const fgc_pack_extra* e, PackJob* jobs, size_t* totals);
 
 }  // namespace fgc

@@ -16,7 +16,7 @@ static inline size_t reduce_tmp_floats(int nslabs, size_t count) {
     return tot;
 }
 // Several independent reductions in (at most) two launches:
-//   out[(j / in_ld) * out_ld + j % in_ld] = sum_s slab[s * stride + j]   for j % in_ld < out_ld
+//   out[(j / in_ld) * out_ld + j % in_ld] = sum_s slab[s * stride + j]   for j % in_ld < out_ld   (RedJob::tr: see there)
 // Stage 1 sums groups of RED_GROUP slabs of every job, stage 2 sums the group results (jobs with a single group finish in
 // stage 1; lists of up to 2 * RED_GROUP slabs are summed by ONE workgroup per column block in a single stage, longer than
 // RED_GROUP^2 in proportionally larger groups).  One entry point, one fixed order per (nslabs, count): the per-layer and the
@@ -30,6 +30,9 @@ struct RedJob {
     float* out;
     float* tmp = nullptr;   // when set: this job's (and the following jobs') stage-1 results go here instead of
                             // continuing in the scratch of the job before
+    int tr = 0;             // > 0: the slab is [rows][in_ld] with row = m * tr + c; the result goes out TRANSPOSED per m as
+                            // out[(m * in_ld + col) * tr + c] for rows < out_ld (the first layer's dW0[m][o][c] out of
+                            // its z^T s product [m * cin + c][o]); out_ld then counts rows, not columns
 };
 // scratch: sum over jobs of reduce_tmp_floats(nslabs, count) (an upper bound: at most RED_GROUP * count per job);
 // tmp may be NULL when the first job names its own

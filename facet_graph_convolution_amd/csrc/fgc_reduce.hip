@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobsT<MAXJ> J) {
     if (sl == 0 && j < job.count) {
         const float v = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
         float* out = J.stage_out[q];
-        if (J.fin[q]) {
+        if (J.fin[q] && job.tr > 0) {
+            const int row = j / job.in_ld, col = j % job.in_ld;
+            if (row < job.out_ld) out[((size_t)(row / job.tr) * job.in_ld + col) * job.tr + row % job.tr] = v;
+        } else if (J.fin[q]) {
             const int c = j % job.in_ld;
             if (c < job.out_ld) out[(size_t)(j / job.in_ld) * job.out_ld + c] = v;
         } else {
@@ -134,7 +137,7 @@ static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, flo
             return FGC_EINVAL;
         }
         A.job[q] = j;
-        const bool wide = j.nslabs <= 4 && j.count >= (1 << 16) && j.count % 4 == 0 && j.in_ld == j.out_ld &&
+        const bool wide = j.tr == 0 && j.nslabs <= 4 && j.count >= (1 << 16) && j.count % 4 == 0 && j.in_ld == j.out_ld &&
                           j.stride % 4 == 0 && ((uintptr_t)j.slab % 16) == 0 && ((uintptr_t)j.out % 16) == 0;
         if (wide) {
             A.xblocks[q] = (j.count / 4 + 255) / 256;
@@ -147,7 +150,7 @@ static int reduce_jobs_impl(const char* what, const RedJob* jobs, int njobs, flo
             continue;
         }
         // four columns per thread where the layout allows it: a quarter of the workgroups, 16-byte accesses
-        const bool vec = j.count >= 4096 && j.count % 4 == 0 && j.in_ld == j.out_ld && j.stride % 4 == 0 &&
+        const bool vec = j.tr == 0 && j.count >= 4096 && j.count % 4 == 0 && j.in_ld == j.out_ld && j.stride % 4 == 0 &&
                          ((uintptr_t)j.slab % 16) == 0 && ((uintptr_t)j.out % 16) == 0 &&
                          (groups == 1 || ((uintptr_t)t % 16) == 0);
         A.vec[q] = vec ? 1 : 0;

@@ -183,6 +183,7 @@ class FacetDenoiser:
         # one launch packs the weight operands of all layers, one pair sums all parameter gradients (each small launch
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
+        self.step_prologue = os.environ.get("FGC_NO_STEP_PROLOGUE", "0") != "1"
         self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
         # the gradient of the 4:1 max pooling behind conv1 / conv2 is a term of those layers' backward stage 1
         self.fused_pool = os.environ.get("FGC_NO_FUSED_POOL", "0") != "1"
@@ -427,6 +428,10 @@ class FacetDenoiser:
         if bf16:
             ws_b = max(ws_b, self.L.fgc_mlp_bwd_bf16_workspace_bytes(n0, 32, HIDDEN, 3))
         B["ws"] = torch.empty(max(ws_f, ws_b) + 256, dtype=torch.uint8, device=dev)     # the MLP heads
+        # the last head's forward operands have a workspace of their own: the step's first launch (fgc_conv_pack with an
+        # fgc_pack_extra) packs them and the backward operands (at the start of B["ws"]) beside the conv operands
+        B["ws_mlp_f"] = torch.empty(max(self.L.fgc_mlp_workspace_bytes(32, HIDDEN, 3),
+                                        self.L.fgc_mlp_bf16_workspace_bytes(32, HIDDEN, 3)) + 256, dtype=torch.uint8, device=dev)
         for k, t in wsf.items():
             B["wsf_" + k] = t
         for k, t in wsb.items():
@@ -519,13 +524,18 @@ class FacetDenoiser:
         B, ws = M["B"], M["B"]["ws"]
         n0 = M["ns"][0]
         rows0 = B["x"].shape[0]
+        vals = self.params.values
+        # one housekeeping launch per step: conv operands, the rotation of the input rows, the MLP's operands
+        # (FGC_NO_STEP_PROLOGUE=1: the rotation and the MLP packs as launches of their own)
+        prologue = self.batched and self.step_prologue
+        mlp_packed = _lib.MLP_PACKED if (prologue and not self.multi_scale) else 0
+        M["mlp_packed"] = mlp_packed
         self._tag("fwd:input")
-        if rotate:
+        if rotate and not prologue:
             _lib.check(L.fgc_rotate_rows(_p(B["x"]), _p(B["xr"]), rows0, self.in_channels // 3, _p(B["R"]), st),
                        "rotate")
-        else:
+        elif not rotate:
             B["xr"].copy_(B["x"])
-        vals = self.params.values
         # what a layer's output feeds on OTHER ranks: sent in one grouped exchange right behind the layer; the consumer
         # waits for it between its interior and its boundary tiles
         send_after = {"conv1": [("rows", 0, "h1", False), ("rows", 1, "p1", False)],
@@ -540,7 +550,21 @@ class FacetDenoiser:
         if self.batched:
             A = M["arrays"]
             self._tag("fwd:pack")
-            _lib.check(L.fgc_conv_pack(A["descs"], A["ios"], A["wsf"], A["wsb"], A["count"], st), "pack")
+            ex = None
+            if prologue:
+                ex = _lib.PackExtra()
+                if rotate:
+                    ex.rot_x, ex.rot_y, ex.rot_R = _p(B["x"]), _p(B["xr"]), _p(B["R"])
+                    ex.rot_rows, ex.rot_vecs = rows0, self.in_channels // 3
+                if mlp_packed:
+                    s0 = self.slot["head0"]
+                    ex.mlp_bf16 = 1 if self.dtype == "bf16" else 0
+                    ex.mlp_W1, ex.mlp_W2 = _p(vals[s0]), _p(vals[s0 + 2])
+                    ex.mlp_n, ex.mlp_cin, ex.mlp_hidden, ex.mlp_cout = n0, 32, HIDDEN, 3
+                    ex.mlp_fwd_ws = _p(B["ws_mlp_f"])
+                    ex.mlp_bwd_ws = _p(ws) if M["has_gt"] else None
+            _lib.check(L.fgc_conv_pack(A["descs"], A["ios"], A["wsf"], A["wsb"], A["count"],
+                                       C.byref(ex) if ex is not None else None, st), "pack")
             packed = _lib.CONV_PACKED
         for lay in self.layers:
             d = M["descs"][lay.name]
@@ -597,12 +621,13 @@ class FacetDenoiser:
                 xin = B[lay.y]
                 nrows = M["ns"][lay.level]
                 _lib.check(self._mlp_fwd(_p(xin), nrows, xin.shape[1], HIDDEN, 3, _p(W1), _p(b1), _p(W2),
-                                         _p(b2), LRELU_ALPHA, _p(B[out]), _p(B["abs_part" + out[1]]), _p(ws),
+                                         _p(b2), LRELU_ALPHA, _p(B[out]), _p(B["abs_part" + out[1]]), 0, _p(ws),
                                          ws.numel(), st), head)
         self._tag("fwd:mlp")
         W1, b1, W2, b2 = vals[self.slot["head0"]:self.slot["head0"] + 4]
+        wsm = B["ws_mlp_f"]
         _lib.check(self._mlp_fwd(_p(B["d1"]), n0, 32, HIDDEN, 3, _p(W1), _p(b1), _p(W2), _p(b2), LRELU_ALPHA,
-                                 _p(B["y0"]), _p(B["abs_part"]), _p(ws), ws.numel(), st), "head0")
+                                 _p(B["y0"]), _p(B["abs_part"]), mlp_packed, _p(wsm), wsm.numel(), st), "head0")
         self._tag("fwd:normalize")
         if defer_normalize and self.sharded:
             # training: the global mean |y| (utils.py:1705 takes it over the whole tensor) is all that is needed here -
@@ -731,13 +756,14 @@ class FacetDenoiser:
                 hs = self.slot[head]
                 _lib.check(L.fgc_mlp_bwd(_p(xin), _p(B["g_y" + k]), nk, xin.shape[1], HIDDEN, 3, _p(vals[hs]),
                                          _p(vals[hs + 1]), _p(vals[hs + 2]), LRELU_ALPHA, _p(B["g_" + lay.y]),
-                                         _p(grads[hs]), _p(grads[hs + 1]), _p(grads[hs + 2]), _p(grads[hs + 3]), _p(ws),
+                                         _p(grads[hs]), _p(grads[hs + 1]), _p(grads[hs + 2]), _p(grads[hs + 3]), 0, _p(ws),
                                          ws.numel(), st), head + " bwd")
         s = self.slot["head0"]
         self._tag("bwd:mlp")
         _lib.check(self._mlp_bwd(_p(B["d1"]), _p(B["g_y0"]), n0, 32, HIDDEN, 3, _p(vals[s]), _p(vals[s + 1]),
                                  _p(vals[s + 2]), LRELU_ALPHA, _p(B["g_d1"]), _p(grads[s]), _p(grads[s + 1]),
-                                 _p(grads[s + 2]), _p(grads[s + 3]), _p(ws), ws.numel(), st), "head0 bwd")
+                                 _p(grads[s + 2]), _p(grads[s + 3]), M.get("mlp_packed", 0), _p(ws), ws.numel(), st),
+                   "head0 bwd")
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
             self._tag("bwd:" + name)
             # (g_h2 += d pool2 and g_h1 += d pool1 are folded into stage 1 of conv2 / conv1: fgc_conv_bwd_io.pool_y / pool_dy;

@@ -162,7 +162,7 @@ def mlp_fwd(x, W1, b1, W2, b2, alpha=0.1, want_abs_partial=False):
     y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
     part = torch.empty(L.fgc_mlp_num_partials(n), dtype=torch.float32, device=x.device) if want_abs_partial else None
     check(L.fgc_mlp_fwd(ptr(x), n, cin, hidden, cout, ptr(W1), ptr(b1), ptr(W2), ptr(b2), alpha, ptr(y), ptr(part),
-                        ptr(ws), ws.numel(), stream_ptr()), "fgc_mlp_fwd")
+                        0, ptr(ws), ws.numel(), stream_ptr()), "fgc_mlp_fwd")
     return (y, part) if want_abs_partial else y
 
 
@@ -177,7 +177,7 @@ def mlp_bwd(x, dy, W1, b1, W2, alpha=0.1):
     dW1, db1, dW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
     db2 = torch.empty(cout, dtype=torch.float32, device=x.device)
     check(L.fgc_mlp_bwd(ptr(x), ptr(dy), n, cin, hidden, cout, ptr(W1), ptr(b1), ptr(W2), alpha, ptr(dx), ptr(dW1),
-                        ptr(db1), ptr(dW2), ptr(db2), ptr(ws), ws.numel(), stream_ptr()), "fgc_mlp_bwd")
+                        ptr(db1), ptr(dW2), ptr(db2), 0, ptr(ws), ws.numel(), stream_ptr()), "fgc_mlp_bwd")
     return dx, dW1, db1, dW2, db2
 
 

@@ -42,7 +42,8 @@ extern "C" {
 
 const char* fgc_last_error(void);
 int fgc_version(void);
-/* sizeof the descriptor structs as this library was compiled (which = 0: fgc_conv_desc, 1: fgc_conv_bwd_io; else 0):
+/* sizeof the descriptor structs as this library was compiled (which = 0: fgc_conv_desc, 1: fgc_conv_bwd_io,
+ * 2: fgc_pack_extra; else 0):
  * lets a foreign-language binding check its mirror of the layouts before the first call */
 size_t fgc_struct_size(int32_t which);
 
@@ -307,6 +308,26 @@ int fgc_conv_uses_pairs(const fgc_conv_desc* d);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);
 
+/* Extra jobs of fgc_conv_pack's launch (each part optional: rot_x == NULL / mlp_W1 == NULL skips it). */
+typedef struct fgc_pack_extra {
+    /* rot_y[r, 3v:3v+3] = R rot_x[r, 3v:3v+3] for rot_rows rows of rot_vecs 3-vectors (fgc_rotate_rows) */
+    const float* rot_x;
+    float* rot_y;
+    const float* rot_R;         /* [9] on the device */
+    int64_t rot_rows;
+    int32_t rot_vecs;
+    /* the MLP whose operands are packed: W1 [cin, hidden], W2 [hidden, cout] (bf16 backward only), n rows.  mlp_fwd_ws /
+     * mlp_bwd_ws are the workspaces later handed to fgc_mlp_fwd / fgc_mlp_bwd (mlp_bf16 != 0: to the _bf16 forms) with
+     * FGC_MLP_PACKED; they must stay untouched in between, so the two calls need workspaces of their own.  Either may
+     * be NULL. */
+    int32_t mlp_bf16;
+    const float* mlp_W1;
+    const float* mlp_W2;
+    int32_t mlp_n, mlp_cin, mlp_hidden, mlp_cout;
+    void* mlp_fwd_ws;
+    void* mlp_bwd_ws;
+} fgc_pack_extra;
+
 /* Whole-network helpers for a caller that runs the same `count` layers every step (train.py:558-575 runs the graph of
  * model.py:853-941 once per iteration) and gives every layer a workspace of its own that stays untouched from the
  * first call of a step to the last: the per-layer housekeeping launches (each costs about 5 us on an idle MI355X
@@ -316,12 +337,15 @@ int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* worksp
  * backward operands into bwd_ws[i] (either array, or single entries, may be NULL to skip; ios may be NULL, it only
  * tells which layer takes the narrow first-layer path and has nothing to pack).  Call it after the weights change;
  * then pass FGC_CONV_PACKED in fgc_conv_desc.flags / fgc_conv_bwd_io.flags.
+ * `extra` (may be NULL): the step's other housekeeping in the same launch - the rotation of the input rows
+ * (train.py:563-565, what fgc_rotate_rows does) and the operands of the network's per-facet MLP, which the fgc_mlp_*
+ * entry points then take with FGC_MLP_PACKED.  count may be 0 with descs NULL.
  *
  * fgc_conv_bwd_reduce: with FGC_CONV_DEFER_REDUCE in fgc_conv_bwd_io.flags stage 8 leaves the partial sums of the
  * parameter gradients in the layer's workspace; this call sums them for all layers in two launches, in the same
  * fixed order as the per-layer path (bit-identical gradients). */
 int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* fwd_ws,
-                  void* const* bwd_ws, int32_t count, void* stream);
+                  void* const* bwd_ws, int32_t count, const fgc_pack_extra* extra, void* stream);
 int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* bwd_ws,
                         int32_t count, void* stream);
 
@@ -335,17 +359,20 @@ int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io
  * three-term operand splits (v = bf16(v) + bf16(v - v0) + bf16(v - v0 - v1); six exact partial products per product,
  * fp32 accumulation): as close to a float64 reference as the fp32 MFMA kernel it replaces (1.7e-7 vs 2.0e-7 on outputs
  * of size 1).  FGC_NO_MLP_SPLIT=1 in the environment keeps the fp32 MFMA.  alpha must be in [0, 1].
+ * flags: FGC_MLP_PACKED = the workspace already holds this call's weight operands (fgc_conv_pack with an
+ * fgc_pack_extra naming it, same W1 / W2 / shape, nothing written to it since): the call skips its own pack launch.
  * ---------------------------------------------------------------------------------- */
+#define FGC_MLP_PACKED 1
 int32_t fgc_mlp_num_partials(int32_t n);
 size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout);
 size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout);
 int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
                 const float* b1, const float* W2, const float* b2, float alpha, float* y, float* abs_partial,
-                void* workspace, size_t workspace_bytes, void* stream);
+                int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 /* dW1,db1,dW2,db2 overwritten; dx [n, cin] overwritten. */
 int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
                 const float* W1, const float* b1, const float* W2, float alpha, float* dx, float* dW1,
-                float* db1, float* dW2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+                float* db1, float* dW2, float* db2, int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same MLP with bf16-STORED activations (companion of FGC_CONV_BF16; a build extension, the reference is fp32 only:
  * train.py:409-427).  x [n, cin] and dx [n, cin] are bf16 (uint16_t) tensors, cin in {32, 64, 128} (backward: 32, 64),
@@ -355,10 +382,10 @@ size_t fgc_mlp_bf16_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout);
 size_t fgc_mlp_bwd_bf16_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout);
 int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t hidden, int32_t cout, const float* W1,
                      const float* b1, const float* W2, const float* b2, float alpha, float* y, float* abs_partial,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32_t cin, int32_t hidden, int32_t cout,
                      const float* W1, const float* b1, const float* W2, float alpha, void* dx, float* dW1, float* db1,
-                     float* dW2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+                     float* dW2, float* db2, int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Element-wise / reduction ops

@@ -29,6 +29,7 @@ def test_header_symbols_are_exported_and_bound():
     # the ctypes mirrors of the descriptor structs have the layout the library was compiled with
     assert _lib.lib().fgc_struct_size(0) == C.sizeof(_lib.ConvDesc)
     assert _lib.lib().fgc_struct_size(1) == C.sizeof(_lib.ConvBwdIO)
+    assert _lib.lib().fgc_struct_size(2) == C.sizeof(_lib.PackExtra)
 
 
 def test_error_reporting_across_the_boundary():
@@ -38,7 +39,7 @@ def test_error_reporting_across_the_boundary():
     with pytest.raises(RuntimeError, match="fgc_csr_from_klist"):
         _lib.check(rc, "fgc_csr_from_klist")
     assert L.fgc_conv_fwd(None, None, None, None, None, 0, None) == -22       # null descriptor, no launch
-    assert L.fgc_mlp_fwd(None, 0, 0, 0, 0, None, None, None, None, 0.1, None, None, None, 0, None) == -22
+    assert L.fgc_mlp_fwd(None, 0, 0, 0, 0, None, None, None, None, 0.1, None, None, 0, None, 0, None) == -22
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

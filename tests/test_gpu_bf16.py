@@ -125,13 +125,28 @@ def test_bf16_mlp_kernels_against_torch(golden_dir):
         ws = torch.empty(L.fgc_mlp_bwd_bf16_workspace_bytes(n, cin, 1024, 3) + 256, dtype=torch.uint8, device=dev)
         st = _lib.stream_ptr()
         p = _lib.ptr
-        _lib.check(L.fgc_mlp_fwd_bf16(p(xd), n, cin, 1024, 3, p(W1d), p(b1d), p(W2d), p(b2d), 0.1, p(y), None, p(ws),
+        _lib.check(L.fgc_mlp_fwd_bf16(p(xd), n, cin, 1024, 3, p(W1d), p(b1d), p(W2d), p(b2d), 0.1, p(y), None, 0, p(ws),
                                       ws.numel(), st))
         dx = torch.empty(n, cin, dtype=torch.bfloat16, device=dev)
         dW1, db1, dW2, db2 = (torch.empty_like(t) for t in (W1d, b1d, W2d, b2d))
         _lib.check(L.fgc_mlp_bwd_bf16(p(xd), p(dyd), n, cin, 1024, 3, p(W1d), p(b1d), p(W2d), 0.1, p(dx), p(dW1), p(db1),
-                                      p(dW2), p(db2), p(ws), ws.numel(), st))
+                                      p(dW2), p(db2), 0, p(ws), ws.numel(), st))
+        # the same two calls on operands packed ahead of time by fgc_conv_pack's launch (FGC_MLP_PACKED): bit-identical
+        wsf = torch.empty(L.fgc_mlp_bf16_workspace_bytes(cin, 1024, 3) + 256, dtype=torch.uint8, device=dev)
+        wsb = torch.empty_like(ws)
+        ex = _lib.PackExtra(mlp_bf16=1, mlp_W1=p(W1d), mlp_W2=p(W2d), mlp_n=n, mlp_cin=cin, mlp_hidden=1024, mlp_cout=3,
+                            mlp_fwd_ws=p(wsf), mlp_bwd_ws=p(wsb))
+        _lib.check(L.fgc_conv_pack(None, None, None, None, 0, C.byref(ex), st))
+        y2, dx2 = torch.empty_like(y), torch.empty_like(dx)
+        g2 = [torch.empty_like(t) for t in (W1d, b1d, W2d, b2d)]
+        _lib.check(L.fgc_mlp_fwd_bf16(p(xd), n, cin, 1024, 3, p(W1d), p(b1d), p(W2d), p(b2d), 0.1, p(y2), None,
+                                      _lib.MLP_PACKED, p(wsf), wsf.numel(), st))
+        _lib.check(L.fgc_mlp_bwd_bf16(p(xd), p(dyd), n, cin, 1024, 3, p(W1d), p(b1d), p(W2d), 0.1, p(dx2), p(g2[0]), p(g2[1]),
+                                      p(g2[2]), p(g2[3]), _lib.MLP_PACKED, p(wsb), wsb.numel(), st))
         torch.cuda.synchronize()
+        assert torch.equal(y, y2) and torch.equal(dx, dx2)
+        for a, b in zip((dW1, db1, dW2, db2), g2):
+            assert torch.equal(a, b)
         X = x.double().requires_grad_(True)
         P = [t.double().requires_grad_(True) for t in (W1, b1, W2, b2)]
         h = X @ P[0] + P[1]

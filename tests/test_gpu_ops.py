@@ -56,6 +56,46 @@ def test_mlp_forward_split_operands_are_as_accurate_as_the_fp32_mfma():
     assert errs["split"] < 2.0 * errs["fp32"] + 2e-7, errs
 
 
+@pytest.mark.parametrize("n,cin", [(1000, 32), (300, 64), (130, 128), (70, 48)])
+def test_mlp_operands_packed_by_the_step_prologue(n, cin):
+    """fgc_conv_pack with an fgc_pack_extra leaves the MLP's operands (split planes or the fp32 operand, whichever the shape
+    takes) and the rotated input rows in ONE launch; fgc_mlp_fwd / fgc_mlp_bwd with FGC_MLP_PACKED then give bit for bit what
+    they give when they pack themselves, and the rotation what fgc_rotate_rows gives."""
+    import ctypes as C
+    from facet_graph_convolution_amd import _lib, ops
+    L, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+    rs = np.random.RandomState(n)
+    x = _t(rs.normal(size=(n, cin))).to(DEV)
+    W1, b1 = _t(rs.normal(0, 0.05, (cin, 1024))).to(DEV), _t(rs.normal(0, 0.01, 1024)).to(DEV)
+    W2, b2 = _t(rs.normal(0, 0.05, (1024, 3))).to(DEV), _t(rs.normal(0, 0.01, 3)).to(DEV)
+    dy = _t(rs.normal(size=(n, 3))).to(DEV)
+    rows = _t(rs.normal(size=(n, 6))).to(DEV)
+    Rm = _t(np.linalg.qr(rs.normal(size=(3, 3)))[0].reshape(9)).to(DEV)
+    y_ref = ops.mlp_fwd(x, W1, b1, W2, b2, 0.1)
+    y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
+    g_ref = ops.mlp_bwd(x, dy, W1, b1, W2, 0.1)
+    rot_ref = torch.empty_like(rows)
+    _lib.check(L.fgc_rotate_rows(p(rows), p(rot_ref), n, 2, p(Rm), st))
+    wsf = torch.empty(L.fgc_mlp_workspace_bytes(cin, 1024, 3) + 256, dtype=torch.uint8, device=DEV)
+    wsb = torch.empty(L.fgc_mlp_bwd_workspace_bytes(n, cin, 1024, 3) + 256, dtype=torch.uint8, device=DEV)
+    rot = torch.empty_like(rows)
+    ex = _lib.PackExtra(rot_x=p(rows), rot_y=p(rot), rot_R=p(Rm), rot_rows=n, rot_vecs=2, mlp_bf16=0, mlp_W1=p(W1),
+                        mlp_W2=p(W2), mlp_n=n, mlp_cin=cin, mlp_hidden=1024, mlp_cout=3, mlp_fwd_ws=p(wsf), mlp_bwd_ws=p(wsb))
+    _lib.check(L.fgc_conv_pack(None, None, None, None, 0, C.byref(ex), st))
+    y = torch.empty(n, 3, device=DEV)
+    _lib.check(L.fgc_mlp_fwd(p(x), n, cin, 1024, 3, p(W1), p(b1), p(W2), p(b2), 0.1, p(y), None, _lib.MLP_PACKED, p(wsf),
+                             wsf.numel(), st))
+    dx = torch.empty_like(x)
+    g = [torch.empty_like(t) for t in (W1, b1, W2, b2)]
+    _lib.check(L.fgc_mlp_bwd(p(x), p(dy), n, cin, 1024, 3, p(W1), p(b1), p(W2), 0.1, p(dx), p(g[0]), p(g[1]), p(g[2]), p(g[3]),
+                             _lib.MLP_PACKED, p(wsb), wsb.numel(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(rot, rot_ref)
+    assert torch.equal(y, y_ref)
+    for a, b in zip([dx] + g, g_ref):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n,cin", [(1000, 32), (77, 32), (5000, 32), (6, 32), (900, 64), (333, 128), (70, 48)])
 def test_mlp_backward(n, cin):
     """cin = 32 is the network head; 64 / 128 are the multi-scale heads (model.py:894-899, 915-920)."""
