@@ -2061,7 +2061,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                          (!io->pool_dy || (((uintptr_t)io->y | (uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % 16) == 0) &&
                          !(getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1');
     // s = dy*lrelu'(y)/deg, db partials
-    if ((stages & 1) && !fuse_ds) {
+    if ((stages & 1) && !fuse_ds && !(narrow_path && narrow_fuses_ds(d, io))) {
         int cp2 = 1;
         while (cp2 < cout) cp2 <<= 1;
         const int vw = bf16 ? 8 : 4;
@@ -2086,12 +2086,12 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     // first layer over a narrow input (no input gradient wanted): vector-ALU path, no transposed graph, no r buffer
     if (io->dx0 == nullptr && w.narrow) {
         if (stages & 2) {
-            rc = narrow_bwd_logits(d, io, w.narrow, st);
+            rc = narrow_bwd_logits(d, io, w.narrow, w.db_part, st);
             if (rc) return rc;
         }
         if (stages & 8) {
-            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, (io->flags & FGC_CONV_DEFER_REDUCE) ? 1 : 3, nullptr,
-                                   st);
+            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, narrow_db_partials(d, io, w.nb_db),
+                                   (io->flags & FGC_CONV_DEFER_REDUCE) ? 1 : 3, nullptr, st);
             if (rc) return rc;
         }
         return FGC_OK;
@@ -2398,7 +2398,7 @@ extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_
         const BwdWorkspace w = plan_bwd(d, (char*)bwd_ws[i]);
         if (nj + 5 > RED_MAX_JOBS && (rc = flush())) return rc;
         if (io->dx0 == nullptr && w.narrow) {
-            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, w.nb_db, 0, jobs + nj, st);
+            rc = narrow_bwd_params(d, io, w.narrow, w.db_part, narrow_db_partials(d, io, w.nb_db), 0, jobs + nj, st);
             if (rc) return rc;
             nj += NARROW_RED_JOBS;
         } else {

@@ -16,7 +16,11 @@ int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* 
 int narrow_zld(int cin);
 int narrow_splits(const fgc_conv_desc* d);
 size_t narrow_bwd_floats(const fgc_conv_desc* d);
-int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, hipStream_t st);
+int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, float* db_part, hipStream_t st);
+// does the stage-2 kernel compute s = dy * lrelu'(y) / deg (+ the pooled gradient) and the db partials itself (stage 1 is then
+// empty), and how many db partials does the layer leave (nb_db = the count of stage 1's own launch)
+bool narrow_fuses_ds(const fgc_conv_desc* d, const fgc_conv_bwd_io* io);
+int narrow_db_partials(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, int nb_db);
 // parts: 1 = weight-gradient GEMM, 2 = the fixed-order sums (they write dW0 / du / dv / dc / db); jobs_out (may be NULL)
 // receives the NARROW_RED_JOBS reduction jobs so that a caller can run them together with other layers'
 struct RedJob;

@@ -17,6 +17,8 @@
 #include <stdlib.h>
 
 #include "fgc_conv_narrow.h"
+#include <type_traits>
+
 #include "fgc_reduce.h"
 
 namespace fgc {
@@ -352,14 +354,32 @@ struct NarrowBwd {
     const float* ds;       // [n, cout]  s = dy * lrelu'(y) / deg
     int cin, cout;
     float* part;           // [grid][NARROW_PART]: du [9*CIN] | dv [9*CIN] | dc [9], zero padded
+    // FUSE (stage 1 folded in, cout == 32): s is computed here from dy / y (and the pooled gradient), written to ds_out for
+    // the weight-gradient GEMM; one db partial per workgroup
+    const float* dy;
+    const float* y;
+    const float* pool_y;
+    const float* pool_dy;
+    float* ds_out;
+    float* db_part;        // [grid][32]
+    int act, bias_mask, in_bf16;
+    float alpha;
 };
+__device__ __forceinline__ float narrow_slope(float y, float alpha) { return y > 0.f ? 1.f : (y < 0.f ? alpha : 0.f); }
+// lane (lane & ~3) + Q of every quad of lanes
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, false));
+}
 constexpr int NARROW_PART = 160;   // >= 2 * 9 * 8 + 9
 
 // MMA (cout == 32): dz = W^T s of the workgroup's 256 nodes as [64 x 32] x [32 x K] per wave on the matrix cores, handed
 // to the node-per-lane part through LDS (the vector form spends 1 728 FMAs per lane and 32 strided 4-byte loads of s)
-template <int CIN, bool MMA>
+template <int CIN, bool MMA, bool FUSE = false>
 __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
+    static_assert(MMA || !FUSE, "the fused prologue belongs to the matrix-core form");
     __shared__ float red[NB / 64][NARROW_PART];
+    __shared__ float reddb[FUSE ? NB / 64 : 1][32];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int i = blockIdx.x * NB + threadIdx.x;
     const bool active = i < p.n;
@@ -397,12 +417,83 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
         __syncthreads();
         const int w0 = wave * 64;
         const int node0 = blockIdx.x * NB + w0;
-#pragma unroll 1
-        for (int nt = 0; nt < 4; ++nt) {
-            const int row = min(node0 + nt * 16 + lr, p.n - 1);      // rows past n: never used (no edges there)
-            f32x4 av[2];
+        f32x4 dbacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // FUSE: every operand of s for the wave's four row tiles is requested up front (32 loads in flight per lane; the
+        // kernel runs two waves per SIMD on its LDS footprint, registers are free)
+        f32x4 Gd[FUSE ? 4 : 1][2], Yd[FUSE ? 4 : 1][2], Md[FUSE ? 4 : 1][2], Pd[FUSE ? 4 : 1][2];
+        int Dg[FUSE ? 4 : 1];
+        if constexpr (FUSE) {
+            auto load_all = [&](auto bf_tag) {
+                constexpr bool BF = decltype(bf_tag)::value;
+                auto ld4 = [&](const float* base, size_t chunk) {     // four columns of a 32-wide row
+                    if constexpr (BF) return bf4_to_f4(reinterpret_cast<const u32x2*>(base)[chunk]);
+                    else return reinterpret_cast<const f32x4*>(base)[chunk];
+                };
 #pragma unroll
-            for (int g = 0; g < 2; ++g) av[g] = *reinterpret_cast<const f32x4*>(p.ds + (size_t)row * 32 + g * 16 + lq * 4);
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int row = min(node0 + nt * 16 + lr, p.n - 1);
+                    Dg[nt] = p.rowptr[row + 1] - p.rowptr[row];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        Gd[nt][g] = ld4(p.dy, (size_t)row * 8 + g * 4 + lq);
+                        Yd[nt][g] = ld4(p.y, (size_t)row * 8 + g * 4 + lq);
+                    }
+                }
+                if (p.pool_dy) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int row = min(node0 + nt * 16 + lr, p.n - 1);
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            Md[nt][g] = ld4(p.pool_y, (size_t)(row >> 2) * 8 + g * 4 + lq);
+                            Pd[nt][g] = ld4(p.pool_dy, (size_t)(row >> 2) * 8 + g * 4 + lq);
+                        }
+                    }
+                }
+            };
+            if (p.in_bf16) load_all(std::true_type{});
+            else load_all(std::false_type{});
+        }
+        auto row_tile = [&](int nt, const int ntc) {      // ntc: nt as an index of the register arrays (FUSE: unrolled)
+            const int rown = node0 + nt * 16 + lr;
+            const int row = min(rown, p.n - 1);      // rows past n: never used (no edges there)
+            f32x4 av[2];
+            if constexpr (FUSE) {
+                // s = (dy + pooled gradient) * lrelu'(y) / deg of this lane's row, columns g * 16 + lq * 4 .. + 3: the same
+                // operations in the same order as ds_db_vec_kernel (the same s bit for bit; reciprocal multiplies in place of
+                // the divisions did not change the launch time: it is the 55 MB this prologue moves).  The rows of a 4:1
+                // pooling group sit in the four lanes of a quad.
+                const int dg = Dg[ntc];
+                const bool counts = rown < p.n && (!p.bias_mask || dg > 0);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 gv = Gd[ntc][g];
+                    const f32x4 yv = Yd[ntc][g];
+                    if (p.pool_dy) {
+                        const f32x4 m = Md[ntc][g], gp = Pd[ntc][g];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float ne = 0.f;
+                            ne += quad_bcast<0>(yv[k]) == m[k] ? 1.f : 0.f;
+                            ne += quad_bcast<1>(yv[k]) == m[k] ? 1.f : 0.f;
+                            ne += quad_bcast<2>(yv[k]) == m[k] ? 1.f : 0.f;
+                            ne += quad_bcast<3>(yv[k]) == m[k] ? 1.f : 0.f;
+                            gv[k] += yv[k] == m[k] ? gp[k] / ne : 0.f;
+                        }
+                    }
+                    if (p.act) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) gv[k] *= narrow_slope(yv[k], p.alpha);
+                    }
+                    if (counts) dbacc[g] += gv;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) av[g][k] = dg > 0 ? gv[k] / (float)dg : 0.f;
+                    if (rown < p.n) *reinterpret_cast<f32x4*>(p.ds_out + (size_t)row * 32 + g * 16 + lq * 4) = av[g];
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) av[g] = *reinterpret_cast<const f32x4*>(p.ds + (size_t)row * 32 + g * 16 + lq * 4);
+            }
 #pragma unroll
             for (int kt = 0; kt < KZ / 16; ++kt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -415,6 +506,29 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dzt[(w0 + nt * 16 + lq * 4 + t) * ZS + kt * 16 + lr] = acc[t];
             }
+        };
+        if constexpr (FUSE) {
+            row_tile(0, 0);
+            row_tile(1, 1);
+            row_tile(2, 2);
+            row_tile(3, 3);
+        } else {
+#pragma unroll 1
+            for (int nt = 0; nt < 4; ++nt) row_tile(nt, 0);
+        }
+        if constexpr (FUSE) {
+            // column sums over the wave's 64 rows: the 16 lanes of a row group hold the same columns
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = dbacc[g][k];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    if (lr == 0) reddb[wave][g * 16 + lq * 4 + k] = v;
+                }
         }
         // the wave wrote the rows of its own 64 nodes: each lane takes its node's row back
         float dzf[KZ];
@@ -494,6 +608,11 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
     for (int k = threadIdx.x; k < NARROW_PART; k += NB) {
         const float v = k < 2 * FGC_M * CIN + FGC_M ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
         p.part[(size_t)blockIdx.x * NARROW_PART + k] = v;
+    }
+    if constexpr (FUSE) {
+        if (threadIdx.x < 32)
+            p.db_part[(size_t)blockIdx.x * 32 + threadIdx.x] =
+                (reddb[0][threadIdx.x] + reddb[1][threadIdx.x]) + (reddb[2][threadIdx.x] + reddb[3][threadIdx.x]);
     }
 }
 
@@ -576,8 +695,29 @@ int narrow_splits(const fgc_conv_desc* d) {
     return tn_balanced_splits(768 / cdiv(d->cout, 64), cdiv(d->n, 256), d->n);
 }
 
-// stage 2 of the first layer's backward: everything except db (stage 1 left its partials) and the final sums
-int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, hipStream_t st) {
+static bool narrow_bwd_mma(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
+    return !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
+           ((uintptr_t)io->ds % 16) == 0 && (d->c0 == 6 || d->c0 == 3);
+}
+// stage 1 (s and the db partials) folded into the stage-2 kernel: a function of descriptor, io and environment alone, so that
+// every stage call and the reduction agree on where the db partials are and how many there are
+bool narrow_fuses_ds(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
+    if (getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1') return false;
+    if (getenv("FGC_NO_NARROW_FUSED_DS") && getenv("FGC_NO_NARROW_FUSED_DS")[0] == '1') return false;
+    if (!narrow_bwd_mma(d, io) || !io->dy) return false;
+    const uintptr_t al = (d->flags & FGC_CONV_BF16) ? 8 : 16;
+    const float* yy = io->y ? io->y : io->dy;
+    if (((uintptr_t)io->dy | (uintptr_t)yy) % al) return false;
+    if (io->pool_dy && (!io->pool_y || !io->y || d->n % 4 != 0 || ((uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % al)) return false;
+    return true;
+}
+int narrow_db_partials(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, int nb_db) {
+    return narrow_fuses_ds(d, io) ? cdiv(d->n, NB) : nb_db;
+}
+
+// stage 2 of the first layer's backward: everything except the final sums (db partials: stage 1 left them, or - when
+// narrow_fuses_ds - this launch leaves one per workgroup in db_part)
+int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, float* db_part, hipStream_t st) {
     const int cin = d->c0, zld = narrow_zld(cin);
     float* zbuf = scratch;
     float* part = zbuf + (size_t)d->n * zld + 64;
@@ -586,15 +726,35 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     int rc = io->z_saved ? FGC_OK : launch_narrow_fwd_z<true>(pz, st);   // forward left them (FGC_CONV_SAVE_Z)
     if (rc) return rc;
     NarrowBwd pb{d->n, d->rowptr, d->col, d->x0, io->ag, d->W0, io->ds, cin, d->cout, part};
+    const bool fuse = narrow_fuses_ds(d, io);
+    if (fuse) {
+        pb.dy = io->dy;
+        pb.y = io->y ? io->y : io->dy;
+        pb.pool_y = io->pool_dy ? io->pool_y : nullptr;
+        pb.pool_dy = io->pool_dy;
+        pb.ds_out = io->ds;
+        pb.db_part = db_part;
+        pb.act = d->act;
+        pb.bias_mask = d->bias_mask;
+        pb.in_bf16 = (d->flags & FGC_CONV_BF16) ? 1 : 0;
+        pb.alpha = d->alpha;
+    }
     const dim3 grid(cdiv(d->n, NB));
 #define FGC_NARROW_BWD(C_) \
     case C_: FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<C_, false>), grid, dim3(NB), 0, pb); break;
-    const bool mma = !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
-                     ((uintptr_t)io->ds % 16) == 0 && (cin == 6 || cin == 3);
+    const bool mma = narrow_bwd_mma(d, io);
     if (mma) {
         const int KZ = (FGC_M * cin + 15) / 16 * 16;
         const size_t smem = (size_t)(NB + 32) * (KZ + 4) * 4;
-        if (cin == 6) {
+        if (fuse && cin == 6) {
+            hipFuncSetAttribute((const void*)conv_narrow_bwd_kernel<6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+            FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<6, true, true>), grid, dim3(NB), smem, pb);
+        } else if (fuse) {
+            hipFuncSetAttribute((const void*)conv_narrow_bwd_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+            FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<3, true, true>), grid, dim3(NB), smem, pb);
+        } else if (cin == 6) {
             hipFuncSetAttribute((const void*)conv_narrow_bwd_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem);
             FGC_LAUNCH("conv_narrow_kernel<bwd>", st, (conv_narrow_bwd_kernel<6, true>), grid, dim3(NB), smem, pb);

@@ -453,13 +453,28 @@ class FacetDenoiser:
         """The per-step inputs - sample indices (train.py:561) and the rotation (train.py:563-565) - live in ONE device
         buffer [ns ints | 9 floats | pad]: a step refreshes them with a single device-to-device copy
         (set_step_inputs_packed)."""
-        B["step_in"] = torch.zeros(ns + 12, dtype=torch.int32, device=self.device)
+        B["step_in"] = B["step_in_own"] = torch.zeros(ns + 12, dtype=torch.int32, device=self.device)
         B["loss_scratch"] = torch.zeros(self.L.fgc_loss_step_scratch_floats(ns), dtype=torch.float32, device=self.device)
         # facet-sharded steps: [0] the all-reduced sum of |y|, [4:] the all-reduced per-256-samples partial table
         B["loss_sums"] = torch.zeros(self.L.fgc_loss_shard_floats(ns), dtype=torch.float32, device=self.device)
-        B["sample_ind"] = B["step_in"][:ns]
-        B["R"] = B["step_in"][ns:ns + 9].view(torch.float32)
+        self._bind_step_inputs(B, B["step_in"])
         B["R"].copy_(torch.eye(3, dtype=torch.float32).reshape(9))
+
+    @staticmethod
+    def _bind_step_inputs(B, row):
+        ns = row.numel() - 12
+        B["step_in"] = row
+        B["sample_ind"] = row[:ns]
+        B["R"] = row[ns:ns + 9].view(torch.float32)
+
+    def _own_step_inputs(self):
+        """The step inputs back in the network's own buffer (set_step_inputs_packed may have let the steps read a caller's
+        row in place): before anything writes them, and before a hipGraph records their address."""
+        B = self._mesh["B"]
+        own = B["step_in_own"]
+        if B["step_in"] is not own:
+            own.copy_(B["step_in"])
+            self._bind_step_inputs(B, own)
 
     def bind_cached(self, key, x, adjs, gt=None, max_bytes=64 << 30):
         """bind_mesh with the bound state (graphs, activations, descriptors: ~7 KB per facet) kept in HBM under `key`,
@@ -968,11 +983,13 @@ class FacetDenoiser:
 
     def set_rotation(self, R):
         """R [3,3] (train.py:563-565); identity = no augmentation."""
+        self._own_step_inputs()
         self._upload(self._mesh["B"]["R"], np.asarray(R, dtype=np.float32).reshape(9))
 
     def set_samples(self, sample_ind):
         """Indices of the rows the loss is evaluated on (train.py:561), any of the N0 padded rows."""
         t = np.asarray(sample_ind).astype(np.int32)
+        self._own_step_inputs()
         B = self._mesh["B"]
         if t.size != B["sample_ind"].numel():
             R = B["R"].clone()
@@ -993,6 +1010,7 @@ class FacetDenoiser:
         copies are kernels on the compute queue, ordered with hipGraph replays; host -> device DMAs between replays of a
         captured graph were observed to race on this stack when many steps are queued.  sample_local_dev: a facet-sharded
         rank's own part of the samples (local_samples_device), used in place as this step's list."""
+        self._own_step_inputs()
         B = self._mesh["B"]
         B["sample_ind"].copy_(sample_ind_dev)
         B["R"].copy_(R_dev.reshape(9))
@@ -1013,9 +1031,18 @@ class FacetDenoiser:
         return torch.from_numpy(out).to(device)
 
     def set_step_inputs_packed(self, packed_row, sample_local_dev=None):
-        """One device-to-device copy refreshes samples and rotation (a row of pack_step_inputs)."""
+        """Samples and rotation of the next step(s) = a row of pack_step_inputs.  With eager launches the step reads the row
+        where it is (the caller keeps it alive and unchanged while steps that use it are queued); once a hipGraph holds the
+        address of the network's own buffer, one device-to-device copy refreshes that."""
         B = self._mesh["B"]
-        B["step_in"].copy_(packed_row)
+        if (self._graph_fb is None and packed_row.dtype == torch.int32 and packed_row.is_contiguous()
+                and packed_row.numel() == B["step_in_own"].numel() and packed_row.device == B["step_in_own"].device
+                and packed_row.data_ptr() % 4 == 0 and os.environ.get("FGC_COPY_STEP_INPUTS", "0") != "1"):
+            self._bind_step_inputs(B, packed_row)
+        else:
+            if B["step_in"] is not B["step_in_own"]:
+                self._bind_step_inputs(B, B["step_in_own"])
+            B["step_in_own"].copy_(packed_row)
         if self.sharded:
             if sample_local_dev is None:
                 raise ValueError("a sharded network needs the rank's local sample list (local_samples_device)")
@@ -1123,6 +1150,7 @@ class FacetDenoiser:
                 # instead of ~110 launches); the first call runs one step eagerly (lazy one-time set-up inside the
                 # library must not happen under capture), every later one replays
                 if self._graph_fb is None:
+                    self._own_step_inputs()
                     self._enqueue_forward(rotate, training=True)
                     self._enqueue_loss_backward(rotate)
                     torch.cuda.synchronize()
@@ -1136,6 +1164,7 @@ class FacetDenoiser:
                 return self._mesh["B"]["loss"]
             if self._graph_fb is None:
                 # warm up on a side stream, then capture the whole enqueue sequence into one hipGraph
+                self._own_step_inputs()
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):

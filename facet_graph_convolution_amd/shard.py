@@ -509,6 +509,7 @@ def sim_forward_backward_captured(nets, rotate=True):
     Run one eager step first: one-time set-up inside the library must not happen under capture."""
     for n in nets:
         if n._graph_fb is None:
+            n._own_step_inputs()
             n._graph_fb = ((n._capture_segments(lambda: n._forward_gen(rotate, n._fused_loss_now())),
                             n._capture_segments(lambda: n._loss_backward_gen(rotate))), rotate)
 

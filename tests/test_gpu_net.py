@@ -334,6 +334,78 @@ def test_whole_network_pack_and_reduce_match_the_per_layer_path():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_first_layer_backward_computes_s_itself(dtype, monkeypatch):
+    """The first layer's backward kernel computes s = (dy + pooled gradient) * lrelu'(y) / deg in its prologue and leaves one
+    bias-gradient partial per workgroup (no ds_db launch); FGC_NO_NARROW_FUSED_DS=1 keeps the separate launch.  Same
+    operations per element: every gradient is bit-identical except the first layer's bias gradient, whose partial sums group
+    the rows differently."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = icosphere(3)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    out = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("FGC_NO_NARROW_FUSED_DS", off)
+        net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
+        loss = net.train_step(sample_ind=samp, R=Rm)[0].item()
+        out.append((loss, [g.clone() for g in net.params.grads]))
+    assert out[0][0] == out[1][0]
+    sb = 1          # conv1's variables in creation order: W0, b, u, c, v (model.py:427-460)
+    for i, (a, b) in enumerate(zip(out[0][1], out[1][1])):
+        if i == sb:
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-6), "db of the first layer"
+            assert not torch.equal(a, torch.zeros_like(a))
+        else:
+            assert torch.equal(a, b), "gradient %d" % i
+
+
+def test_packed_step_inputs_are_read_in_place_until_a_graph_is_captured():
+    """set_step_inputs_packed lets eager steps read the caller's row where it is (no copy launch); FGC_COPY_STEP_INPUTS=1 and a
+    captured hipGraph use the network's own buffer.  Same steps either way, and set_rotation afterwards must not write into
+    the caller's window."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = icosphere(3)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    rs = np.random.RandomState(4)
+    samples = [rs.randint(x.shape[1], size=4000) for _ in range(4)]
+    rots = [rand_rotation_matrix(randnums=rs.uniform(size=3)) for _ in range(4)]
+    window = FacetDenoiser.pack_step_inputs(samples, rots, "cuda:0")
+    keep = window.clone()
+    out = []
+    for mode in ("alias", "copy", "graph"):
+        os.environ["FGC_COPY_STEP_INPUTS"] = "1" if mode == "copy" else "0"
+        try:
+            net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+            losses = []
+            for k in range(4):
+                net.set_step_inputs_packed(window[k])
+                own = net.buffers["step_in"].data_ptr() == net.buffers["step_in_own"].data_ptr()
+                assert own == (mode == "copy" or net._graph_fb is not None)
+                net.forward_backward(rotate=True, capture=(mode == "graph"))
+                net.adam_step()
+                losses.append(net.buffers["loss"][0].item())
+            out.append((losses, net.params.theta.clone()))
+            net.set_rotation(np.eye(3))
+            torch.cuda.synchronize()
+            assert torch.equal(window, keep)
+        finally:
+            os.environ.pop("FGC_COPY_STEP_INPUTS", None)
+    for o in out[1:]:
+        assert o[0] == out[0][0] and torch.equal(o[1], out[0][1])
+
+
 def test_pool_gradient_folded_into_the_conv_backward_equals_the_separate_pass():
     """fgc_conv_bwd_io.pool_y / pool_dy: the gradient of the 4:1 max pooling behind conv1 and conv2 is added to dy inside
     stage 1 of those layers (the d-logits kernel's prologue for conv2, ds_db_kernel for the narrow first layer) instead of
