@@ -70,22 +70,26 @@ def _up(x):
     return x.repeat_interleave(4, dim=0)                            # model.py:817-825, steps = 2
 
 
-def get_model(x, graphs, params):
-    """ref: model.py:837-946 (multiScale = False).  x [n0, 6]; graphs = three pad_klist tuples."""
+def get_model(x, graphs, params, multi_scale=False):
+    """ref: model.py:837-946.  x [n0, 6]; graphs = three pad_klist tuples; multi_scale: also the two coarse heads
+    (model.py:894-899, 915-920), returned as (y0, y1, y2) like oracle/model_ref.get_model_reg_multi_scale."""
     p = list(params)
     take = lambda k: [p.pop(0) for _ in range(k)]
     a = R.LRELU_ALPHA
+    head = lambda t, W1, b1, W2, b2: R.lrelu(t @ W1 + b1, a) @ W2 + b2          # model.py:763-769
     h1 = R.lrelu(custom_conv2d(x, graphs[0], take(5)), a)
     h2 = R.lrelu(custom_conv2d(_pool(h1), graphs[1], take(5)), a)
     h3 = R.lrelu(custom_conv2d(_pool(h2), graphs[2], take(5)), a)
     d3 = R.lrelu(custom_conv2d(h3, graphs[2], take(5)), a)
+    y2 = head(d3, *take(4)) if multi_scale else None
     u2 = custom_conv2d(_up(d3), graphs[1], take(5))                 # no activation, model.py:905
     d2 = R.lrelu(custom_conv2d(torch.cat([u2, h2], 1), graphs[1], take(5)), a)
+    y1 = head(d2, *take(4)) if multi_scale else None
     u1 = custom_conv2d(_up(d2), graphs[0], take(5))                 # model.py:926
     d1 = R.lrelu(custom_conv2d(torch.cat([u1, h1], 1), graphs[0], take(5)), a)
-    W1, b1, W2, b2 = take(4)
+    y0 = head(d1, *take(4))                                         # model.py:937-941
     assert not p
-    return R.lrelu(d1 @ W1 + b1, a) @ W2 + b2                       # model.py:937-941
+    return (y0, y1, y2) if multi_scale else y0
 
 
 def train_loss(x, adjs, gt, params, sample_ind, Rm):
@@ -101,6 +105,29 @@ def train_loss(x, adjs, gt, params, sample_ind, Rm):
     return R.faceNormalsLoss(n_conv[:, idx], gt_r[:, idx]), n_conv
 
 
-def init_params(seed=0):
+def train_loss_ms(x, adjs, gt, params, sample_ind, Rm):
+    """oracle/model_ref.train_loss_ms (the build's multi-scale training objective: one sampled angular loss per head against
+    the pooled ground truth) in float64 on the closed form.  Returns (loss0 + loss1 + loss2, [loss_k], [n_conv_k])."""
+    xt = torch.as_tensor(np.asarray(x), dtype=DT).reshape(1, -1, 6)
+    gtt = torch.as_tensor(np.asarray(gt), dtype=DT).reshape(1, -1, 3)
+    Rt = torch.as_tensor(np.asarray(Rm), dtype=DT)
+    x_r, gt_r = R.rotate_inputs(xt, gtt, Rt)
+    ys = get_model(x_r[0], [pad_klist(a) for a in adjs], params, multi_scale=True)
+    gts = [gt_r, None, None]
+    g = gtt
+    for k in (1, 2):
+        g = R.pooled_gt(g)
+        gts[k] = torch.matmul(g, Rt.t())
+    idx = torch.as_tensor(np.asarray(sample_ind), dtype=torch.long)
+    losses, nconvs = [], []
+    for y, gk in zip(ys, gts):
+        n_conv = R.normalizeTensor(y[None])
+        ik = idx % y.shape[0]
+        losses.append(R.faceNormalsLoss(n_conv[:, ik], gk[:, ik]))
+        nconvs.append(n_conv)
+    return losses[0] + losses[1] + losses[2], losses, nconvs
+
+
+def init_params(seed=0, multi_scale=False):
     """The fixture generator's seeded parameters (model_ref.init_params) as float64 leaves."""
-    return [p.to(DT).requires_grad_(True) for p in R.init_params(seed)]
+    return [p.to(DT).requires_grad_(True) for p in R.init_params(seed, multi_scale=multi_scale)]

@@ -202,3 +202,43 @@ def test_100k_facet_bf16_train_step_gradients_within_the_stated_tolerance_of_the
 def test_200k_facet_train_step_gradients_match_the_float64_oracle():
     """torus 400 x 250 = 200 000 facets (N0 about 245k: the size of two weak-scaling shards)."""
     _train_step_vs_csr_oracle(400, 250, "f32", (2e-5, 1e-4, 2e-3))
+
+
+def test_100k_facet_multi_scale_train_step_matches_the_float64_oracle():
+    """The three-head network (BASELINE config 5's architecture; model.py:894-899, 915-920) at the headline size: the heads
+    over 25k x 64 and 6k x 128 rows run the wide forms of the MLP kernels, the coarse heads' input gradients are added to
+    the up-convolutions'.  Outputs of the three heads, the three losses and all 52 gradients against the float64 closed
+    form (oracle/model_csr_ref.train_loss_ms), tolerances of the single-head test."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    from oracle import model_csr_ref as C
+    torch.set_num_threads(min(len(__import__("os").sched_getaffinity(0)), 32))
+    x, adjs, gt = _mesh(250, 200, seed=0)
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3)).astype(np.float32)
+    _CSR_ORACLE.clear()
+    params = C.init_params(0, multi_scale=True)
+    tot, losses, nconvs = C.train_loss_ms(x.astype(np.float32), adjs, gt.astype(np.float32), params, samp, Rm)
+    tot.backward()
+    ref_g = [p.grad.float() for p in params]
+    ref_l = [l.item() for l in losses]
+    ref_n = [n[0].detach().float() for n in nconvs]
+    del tot, losses, nconvs
+    net = FacetDenoiser("cuda:0", seed=0, multi_scale=True).bind_mesh(x, adjs, gt=gt)
+    net.set_samples(samp)
+    net.set_rotation(Rm)
+    net.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    B = net.buffers
+    got_l = [B["loss"][0].item(), B["loss1"][0].item(), B["loss2"][0].item()]
+    for a, b in zip(got_l, ref_l):
+        assert abs(a - b) < 1e-4 * abs(b), (got_l, ref_l)
+    assert (B["nconv"].cpu() - ref_n[0]).abs().max().item() < 2e-5
+    worst = 0.0
+    assert len(net.params.grads) == 52
+    for i, (g, r) in enumerate(zip(net.params.grads, ref_g)):
+        scale = max(r.abs().max().item(), 1e-3)
+        err = (g.cpu() - r).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
+    print("multi-scale, 100k facets: losses %s vs %s, worst rel grad err %.2e" % (got_l, ref_l, worst))

@@ -156,3 +156,26 @@ def test_csr_oracle_matches_the_reference_shaped_oracle_at_39k_facets():
     for i, (a, b) in enumerate(zip(p32, p64)):
         scale = max(b.grad.abs().max().item(), 1e-3)
         assert (a.grad.double() - b.grad).abs().max().item() < 2e-3 * scale, i
+
+
+def test_csr_oracle_multi_scale_matches_the_reference_shaped_oracle(golden_dir):
+    """The three-head network and the build's multi-scale training objective: float64 closed form against the reference-
+    shaped oracle run in float64 on the icosphere fixture mesh (same arithmetic, different association: 1e-9)."""
+    from oracle import model_csr_ref as C
+    prep = _load(golden_dir, "prep_ico3.npz")
+    x, adjs, gt = prep["x"], [prep["adj%d" % l] for l in range(3)], prep["gt"]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = np.linalg.qr(np.random.RandomState(3).normal(size=(3, 3)))[0]
+    pr = [p.double().requires_grad_(True) for p in R.init_params(0, multi_scale=True)]
+    tot_r, losses_r = R.train_loss_ms(torch.tensor(x).double(), [torch.tensor(a.astype(np.int32)) for a in adjs],
+                                      torch.tensor(gt).double(), pr, samp, torch.tensor(Rm).double())
+    tot_r.backward()
+    pc = C.init_params(0, multi_scale=True)
+    tot_c, losses_c, _ = C.train_loss_ms(x, adjs, gt, pc, samp, Rm)
+    tot_c.backward()
+    assert len(pc) == 52
+    for a, b in zip(losses_r, losses_c):
+        assert abs(a.item() - b.item()) < 1e-9 * abs(a.item())
+    for i, (a, b) in enumerate(zip(pr, pc)):
+        scale = max(a.grad.abs().max().item(), 1e-3)
+        assert (a.grad - b.grad).abs().max().item() < 1e-9 * scale, i
