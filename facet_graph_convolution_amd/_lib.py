@@ -60,6 +60,7 @@ class PackExtra(C.Structure):
     """struct fgc_pack_extra (include/fgc.h): the rotation and the MLP operands that ride on fgc_conv_pack's launch."""
     _fields_ = [
         ("rot_x", C.c_void_p), ("rot_y", C.c_void_p), ("rot_R", C.c_void_p), ("rot_rows", C.c_int64), ("rot_vecs", C.c_int32),
+        ("rot_ag", C.c_void_p), ("rot_u", C.c_void_p), ("rot_c", C.c_void_p), ("rot_v", C.c_void_p),
         ("mlp_bf16", C.c_int32), ("mlp_W1", C.c_void_p), ("mlp_W2", C.c_void_p),
         ("mlp_n", C.c_int32), ("mlp_cin", C.c_int32), ("mlp_hidden", C.c_int32), ("mlp_cout", C.c_int32),
         ("mlp_fwd_ws", C.c_void_p), ("mlp_bwd_ws", C.c_void_p),

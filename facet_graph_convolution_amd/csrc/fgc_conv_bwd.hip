@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
     const int bid = blockIdx.x - j.block0;
     const int nb = (q + 1 < J.njobs ? J.job[q + 1].block0 : J.nblocks) - j.block0;
     if (j.kind >= 8) {
-        if (j.kind == 8) rotate_rows_body(j.W0, j.dst, j.kdim, j.aux, bid, nb);
+        if (j.kind == 14) rotate_logits_body(j.W0, j.dst, j.kdim, j.cin, j.aux, j.lg_u, j.lg_c, j.lg_v, j.lg_ag, bid, nb);
+        else if (j.kind == 8) rotate_rows_body(j.W0, j.dst, j.kdim, j.aux, bid, nb);
         else if (j.kind == 9) mlp_pack_body(j.W0, j.dst, j.cin, j.kdim, j.ncols, bid, nb);
         else if (j.kind == 10) mlp_pack_split_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
         else if (j.kind == 11) mlp_pack_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
@@ -2361,8 +2362,16 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
         const int64_t nvec = (int64_t)extra->rot_rows * extra->rot_vecs;
         FGC_CHECK_ARG(extra->rot_y && extra->rot_R && extra->rot_rows > 0 && extra->rot_vecs > 0 && nvec < (1ll << 31),
                       "fgc_conv_pack: extra: bad rotation (rows=%lld vecs=%d)", (long long)extra->rot_rows, extra->rot_vecs);
-        PackJob j{extra->rot_x, extra->rot_y, 8, 0, 0, (int)nvec, 0, 0, 0, 0, 0, 0, 0, extra->rot_R};
-        add(j, (size_t)nvec * 2);     // two 3-vectors per thread-iteration share
+        if (extra->rot_ag) {
+            FGC_CHECK_ARG(extra->rot_u && extra->rot_c && extra->rot_v && extra->rot_vecs <= 2 && (uintptr_t)extra->rot_ag % 16 == 0,
+                          "fgc_conv_pack: extra: the first layer's logit table needs u, c, v and at most 6 input channels");
+            PackJob j{extra->rot_x, extra->rot_y, 14, extra->rot_vecs, 0, (int)extra->rot_rows, 0, 0, 0, 0, 0, 0, 0, extra->rot_R,
+                      extra->rot_u, extra->rot_c, extra->rot_v, extra->rot_ag};
+            add(j, (size_t)extra->rot_rows * 4);     // one row per thread
+        } else {
+            PackJob j{extra->rot_x, extra->rot_y, 8, 0, 0, (int)nvec, 0, 0, 0, 0, 0, 0, 0, extra->rot_R};
+            add(j, (size_t)nvec * 2);     // two 3-vectors per thread-iteration share
+        }
     }
     if (extra && extra->mlp_W1) {
         PackJob mj[4];

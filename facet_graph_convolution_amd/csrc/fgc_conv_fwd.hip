@@ -90,6 +90,13 @@ __global__ __launch_bounds__(256) void proj_mfma_kernel(const float* __restrict_
     }
 }
 
+// the table of a narrow first layer (cin <= 8): a row per thread on the vector ALU, the arithmetic of narrow_logits_row
+__global__ __launch_bounds__(256) void proj_narrow_kernel(const float* __restrict__ x, int rows, int cin, const float* __restrict__ u,
+                                                          const float* __restrict__ c, const float* __restrict__ v,
+                                                          float* __restrict__ ag) {
+    narrow_logits_body(x, rows, cin, u, c, v, ag, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------
@@ -309,7 +316,10 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
         const float* px1 = d->x1 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(d->x1) + (size_t)prow0 * d->c1 * esz)
                                  : nullptr;
         float* pag = ag + (size_t)prow0 * FGC_AG_LD;
-        if (xbf)
+        if (narrow)
+            FGC_LAUNCH("proj_mfma_kernel", st, proj_narrow_kernel, dim3(cdiv(prows, 256)), dim3(256), 0, px0, prows, d->c0, d->u, d->c,
+                       d->v, pag);
+        else if (xbf)
             FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true, true>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
                        prows, d->u, d->c, d->v, pag);
         else if (conv_vec4_ok(d))

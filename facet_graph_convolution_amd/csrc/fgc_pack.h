@@ -180,6 +180,66 @@ __device__ __forceinline__ void mlp_pack_w1dx_bf16_body(const float* __restrict_
     }
 }
 
+// one 3-vector times R^T, with the association spelled out (wherever a row is rotated it gets the same bits)
+__device__ __forceinline__ void rot3(const float (&r)[9], float a, float b, float c, float& o0, float& o1, float& o2) {
+    o0 = fmaf(r[2], c, fmaf(r[1], b, r[0] * a));
+    o1 = fmaf(r[5], c, fmaf(r[4], b, r[3] * a));
+    o2 = fmaf(r[8], c, fmaf(r[7], b, r[6] * a));
+}
+
+// assignment logits of ONE row of a narrow input (cin <= 8, the first layer): ag[0..8] = u x + c, ag[12..20] = v x, pads 0.
+// One fixed order of fused multiply-adds wherever this table is computed (a launch of its own, or a job of the step's
+// housekeeping launch): the same bits.
+__device__ __forceinline__ void narrow_logits_row(const float* xr, int cin, const float* __restrict__ u, const float* __restrict__ c,
+                                                  const float* __restrict__ v, float* __restrict__ agr) {
+#pragma unroll 1
+    for (int m = 0; m < FGC_M; ++m) {
+        float a = c[m], g = 0.f;
+        for (int k = 0; k < cin; ++k) {
+            a = fmaf(u[m * cin + k], xr[k], a);
+            g = fmaf(v[m * cin + k], xr[k], g);
+        }
+        agr[m] = a;
+        agr[12 + m] = g;
+    }
+#pragma unroll
+    for (int m = FGC_M; m < 12; ++m) {
+        agr[m] = 0.f;
+        agr[12 + m] = 0.f;
+    }
+}
+__device__ __forceinline__ void narrow_logits_body(const float* __restrict__ x, int rows, int cin, const float* __restrict__ u,
+                                                   const float* __restrict__ c, const float* __restrict__ v, float* __restrict__ ag,
+                                                   int bid, int nb) {
+    for (int r = bid * blockDim.x + threadIdx.x; r < rows; r += nb * blockDim.x) {
+        float xr[8];
+        for (int k = 0; k < cin; ++k) xr[k] = x[(size_t)r * cin + k];
+        narrow_logits_row(xr, cin, u, c, v, ag + (size_t)r * FGC_AG_LD);
+    }
+}
+// rotation of the rows of a 3- or 6-channel input AND the first layer's logit table of the rotated rows, one row per thread
+__device__ __forceinline__ void rotate_logits_body(const float* __restrict__ x, float* __restrict__ y, int rows, int vecs,
+                                                   const float* __restrict__ Rd, const float* __restrict__ u,
+                                                   const float* __restrict__ c, const float* __restrict__ v, float* __restrict__ ag,
+                                                   int bid, int nb) {
+    float r9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r9[i] = Rd[i];
+    const int cin = 3 * vecs;
+    for (int r = bid * blockDim.x + threadIdx.x; r < rows; r += nb * blockDim.x) {
+        float xr[8];
+        for (int q = 0; q < vecs; ++q) {
+            const size_t i = (size_t)r * vecs + q;
+            const float a = x[3 * i], b = x[3 * i + 1], cc = x[3 * i + 2];
+            rot3(r9, a, b, cc, xr[3 * q], xr[3 * q + 1], xr[3 * q + 2]);
+            y[3 * i] = xr[3 * q];
+            y[3 * i + 1] = xr[3 * q + 1];
+            y[3 * i + 2] = xr[3 * q + 2];
+        }
+        narrow_logits_row(xr, cin, u, c, v, ag + (size_t)r * FGC_AG_LD);
+    }
+}
+
 // rotation augmentation (train.py:439-451): every 3-vector of x times R^T
 __device__ __forceinline__ void rotate_rows_body(const float* __restrict__ x, float* __restrict__ y, int64_t nvec,
                                                  const float* __restrict__ Rd, int bid, int nb) {
@@ -188,9 +248,7 @@ __device__ __forceinline__ void rotate_rows_body(const float* __restrict__ x, fl
     for (int i = 0; i < 9; ++i) r[i] = Rd[i];
     for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)nb * blockDim.x) {
         const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
-        y[3 * i] = r[0] * a + r[1] * b + r[2] * c;
-        y[3 * i + 1] = r[3] * a + r[4] * b + r[5] * c;
-        y[3 * i + 2] = r[6] * a + r[7] * b + r[8] * c;
+        rot3(r, a, b, c, y[3 * i], y[3 * i + 1], y[3 * i + 2]);
     }
 }
 
@@ -201,11 +259,14 @@ struct PackJob {
     int kind;   // 0: forward operand, 1: data-gradient operand (transposed), 2: d-logits operand; +4: the bf16 forms;
                 // 7: plain bf16 copy of W0 (pair form; kdim = element count);
                 // 8: rotate_rows_body (W0 = x, dst = y, aux = R, kdim = 3-vectors);
+                // 14: rotate_logits_body (W0 = x, dst = y, aux = R, kdim = rows, cin = 3-vectors per row, lg_* = the table);
                 // MLP operands, W0 = W1 [cin, ncols]: 9 mlp_pack_body (kdim = kpad), 10 mlp_pack_split_body,
                 // 11 mlp_pack_bf16_body, 12 mlp_pack_w1dx_bf16_body; 13 mlp_pack_w2_bf16_body (W0 = W2 [ncols, cout])
     int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
     int block0;
     const float* aux;
+    const float *lg_u, *lg_c, *lg_v;     // kind 14: the first layer's assignment parameters and its logit table
+    float* lg_ag;
 };
 constexpr int PACK_MAX_JOBS = 28;
 struct PackJobs {

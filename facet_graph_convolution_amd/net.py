@@ -562,6 +562,7 @@ class FacetDenoiser:
                        "upconv1": "dconv2", "dconv1": "upconv1"}
         split = self.sharded and self.overlap
         packed = 0
+        table_done = False      # the first layer's logit table came with the housekeeping launch
         if self.batched:
             A = M["arrays"]
             self._tag("fwd:pack")
@@ -571,6 +572,13 @@ class FacetDenoiser:
                 if rotate:
                     ex.rot_x, ex.rot_y, ex.rot_R = _p(B["x"]), _p(B["xr"]), _p(B["R"])
                     ex.rot_rows, ex.rot_vecs = rows0, self.in_channels // 3
+                    d1 = M["descs"]["conv1"]
+                    if self.in_channels <= 6 and (d1.src_rows or d1.n) == rows0:
+                        # ... and the first layer's logit table of the rotated rows in the same pass
+                        s1 = self.slot["conv1"]
+                        ex.rot_ag = _p(B["ag_conv1"])
+                        ex.rot_u, ex.rot_c, ex.rot_v = _p(vals[s1 + 2]), _p(vals[s1 + 3]), _p(vals[s1 + 4])
+                        table_done = True
                 if mlp_packed:
                     s0 = self.slot["head0"]
                     ex.mlp_bf16 = 1 if self.dtype == "bf16" else 0
@@ -626,7 +634,11 @@ class FacetDenoiser:
                 if need:
                     yield ("wait", need)
                 self._tag("fwd:" + lay.name)
+                if lay.name == "conv1" and table_done:
+                    d.proj_rows = -1
                 _lib.check(L.fgc_conv_fwd(*args), lay.name)
+                if lay.name == "conv1" and table_done:
+                    d.proj_rows = 0
             if self.sharded and lay.name in send_after:
                 items = [(k, lv, B[t], par) for k, lv, t, par in send_after[lay.name]]
                 yield ("xchg", items, lay.name)

@@ -316,6 +316,13 @@ typedef struct fgc_pack_extra {
     const float* rot_R;         /* [9] on the device */
     int64_t rot_rows;
     int32_t rot_vecs;
+    /* optional (rot_vecs <= 2): the assignment-logit table of the layer that reads rot_y (the network's first layer:
+     * rot_ag [rot_rows, 24] = what its fgc_conv_fwd would compute from u [9, 3 rot_vecs], c [9], v [9, 3 rot_vecs]) in the
+     * same pass; that layer's forward call then sets proj_rows = -1.  Same arithmetic as the layer's own table launch. */
+    float* rot_ag;
+    const float* rot_u;
+    const float* rot_c;
+    const float* rot_v;
     /* the MLP whose operands are packed: W1 [cin, hidden], W2 [hidden, cout] (bf16 backward only), n rows.  mlp_fwd_ws /
      * mlp_bwd_ws are the workspaces later handed to fgc_mlp_fwd / fgc_mlp_bwd (mlp_bf16 != 0: to the _bf16 forms) with
      * FGC_MLP_PACKED; they must stay untouched in between, so the two calls need workspaces of their own.  Either may

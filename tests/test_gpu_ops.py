@@ -79,7 +79,12 @@ def test_mlp_operands_packed_by_the_step_prologue(n, cin):
     wsf = torch.empty(L.fgc_mlp_workspace_bytes(cin, 1024, 3) + 256, dtype=torch.uint8, device=DEV)
     wsb = torch.empty(L.fgc_mlp_bwd_workspace_bytes(n, cin, 1024, 3) + 256, dtype=torch.uint8, device=DEV)
     rot = torch.empty_like(rows)
-    ex = _lib.PackExtra(rot_x=p(rows), rot_y=p(rot), rot_R=p(Rm), rot_rows=n, rot_vecs=2, mlp_bf16=0, mlp_W1=p(W1),
+    # ... and the first layer's logit table of the rotated rows (fgc_pack_extra.rot_ag): ag[:, 0:9] = u x + c, [12:21] = v x
+    u, v = _t(rs.normal(0, 0.3, (9, 6))).to(DEV), _t(rs.normal(0, 0.3, (9, 6))).to(DEV)
+    cc = _t(rs.normal(0, 0.3, 9)).to(DEV)
+    ag = torch.full((n, 24), 7.0, device=DEV)
+    ex = _lib.PackExtra(rot_x=p(rows), rot_y=p(rot), rot_R=p(Rm), rot_rows=n, rot_vecs=2, rot_ag=p(ag), rot_u=p(u), rot_c=p(cc),
+                        rot_v=p(v), mlp_bf16=0, mlp_W1=p(W1),
                         mlp_W2=p(W2), mlp_n=n, mlp_cin=cin, mlp_hidden=1024, mlp_cout=3, mlp_fwd_ws=p(wsf), mlp_bwd_ws=p(wsb))
     _lib.check(L.fgc_conv_pack(None, None, None, None, 0, C.byref(ex), st))
     y = torch.empty(n, 3, device=DEV)
@@ -91,6 +96,10 @@ def test_mlp_operands_packed_by_the_step_prologue(n, cin):
                              _lib.MLP_PACKED, p(wsb), wsb.numel(), st))
     torch.cuda.synchronize()
     assert torch.equal(rot, rot_ref)
+    ag_ref = torch.zeros(n, 24, dtype=torch.float64)
+    ag_ref[:, 0:9] = rot_ref.cpu().double() @ u.cpu().double().t() + cc.cpu().double()
+    ag_ref[:, 12:21] = rot_ref.cpu().double() @ v.cpu().double().t()
+    assert (ag.cpu().double() - ag_ref).abs().max().item() < 2e-6
     assert torch.equal(y, y_ref)
     for a, b in zip([dx] + g, g_ref):
         assert torch.equal(a, b)

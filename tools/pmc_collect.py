@@ -37,6 +37,7 @@ def label(names):
     out = []
     fi = bi = -1
     bwd = False
+    started = False      # a table launch opened the current forward layer
     for k in names:
         s = short(k)
         base = s.split("<")[0]
@@ -44,8 +45,13 @@ def label(names):
         if base.startswith("mlp_bwd") or base.startswith("loss_step"):
             bwd = True
         if not bwd:
-            if base in ("proj_mfma_kernel", "pair_transform_kernel", "pair_transform_bf16_kernel"):
+            if base in ("proj_mfma_kernel", "proj_narrow_kernel", "pair_transform_kernel", "pair_transform_bf16_kernel"):
                 fi += 1
+                started = True
+            elif s.startswith("conv_w8_kernel<false") or base in ("pair_fwd_kernel", "conv_narrow_fwd_mma_kernel", "conv_narrow_fwd_kernel"):
+                if not started:      # (the first layer's table can come with the step's housekeeping launch)
+                    fi += 1
+                started = False
             lay = FWD[min(max(fi, 0), 7)]
             if s.startswith("conv_w8_kernel<false"):
                 key = "fwd:%s/conv_w8_kernel<fwd>" % lay
