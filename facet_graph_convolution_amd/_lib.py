@@ -70,6 +70,7 @@ class PackExtra(C.Structure):
 CONV_PACKED = 1
 MLP_PACKED = 1
 CONV_DEFER_REDUCE = 2
+CONV_DEFER_DW = 16
 CONV_SAVE_Z = 4
 CONV_BF16 = 8
 

@@ -1430,13 +1430,40 @@ __device__ __forceinline__ void tn_load(const float* __restrict__ A, int lda, in
 // tiles of a split run on one XCD, next to each other in dispatch order: the rows are fetched once and the other tiles
 // hit in L2.  The grid is padded to 8 * ceil(splits / 8) splits; workgroups of a padding split return at once.
 // Same work per (tile, split), same slabs, same sums: results are unchanged bit for bit.
-__device__ __forceinline__ bool tn_block(int ntiles, int nsplits, int& tile, int& split) {
-    const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+__device__ __forceinline__ bool tn_block(int ntiles, int nsplits, int& tile, int& split, int vblock = -1) {
+    // (vblock: the workgroup's index within ITS job of a grouped launch; jobs start at multiples of 8, so vblock & 7 is
+    //  still the XCD the hardware dealt this workgroup to)
+    const int L = vblock >= 0 ? vblock : (int)blockIdx.x, xcd = L & 7, idx = L >> 3;
     tile = idx % ntiles;
     split = (idx / ntiles) * 8 + xcd;
     return split < nsplits;
 }
 static inline dim3 tn_grid(int ntiles, int nsplits) { return dim3((unsigned)(ntiles * 8 * cdiv(nsplits, 8))); }
+
+// The weight-gradient GEMMs of several layers in ONE launch (fgc_conv_bwd_reduce with FGC_CONV_DEFER_DW): every job is what
+// one launch of the kernel would be - same tiles, same slabs, same sums, bit-identical gradients -, its workgroups are the
+// range [block0, block0 + tn_grid) of the grid.  On the bf16 network a layer's GEMM is 5-15 us of ramp and tail around a few
+// microseconds of streaming: eight of them back to back cost four times what their work takes.
+struct TnArgs {
+    const void* A;
+    const void* x0;
+    const void* x1;
+    float* slab;
+    int lda, P, c0, c1, shift, rows, rps;
+    int block0;
+};
+constexpr int TN_MAX_JOBS = 8;
+struct TnJobs {
+    TnArgs job[TN_MAX_JOBS];
+    int njobs;
+};
+__device__ __forceinline__ int tn_job_of(const TnJobs& J) {
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < TN_MAX_JOBS; ++t)
+        if (t < J.njobs && (int)blockIdx.x >= J.job[t].block0) q = t;
+    return q;
+}
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, int P,
@@ -1509,16 +1536,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 // 2*lr, 2*lr+1: half the MFMAs instead of multiplying clamped duplicates)
 // BF: both operands are bf16 tensors (FGC_CONV_BF16); they are widened on load and multiplied on the fp32 MFMA: the
 // products are exact and the sum over the nodes stays an fp32 chain, as in the fp32 network
-template <int NJ, bool BF = false>
-__global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __restrict__ A, int lda, int P,
-                                                                const float* __restrict__ x0,
-                                                                const float* __restrict__ x1, int c0, int c1, int shift,
-                                                                int rows, int rows_per_split, float* __restrict__ slab) {
+template <int NJ, bool BF>
+__device__ __forceinline__ void tn_stream_body(const float* __restrict__ A, int lda, int P, const float* __restrict__ x0,
+                                               const float* __restrict__ x1, int c0, int c1, int shift, int rows,
+                                               int rows_per_split, float* __restrict__ slab, int vblock) {
     __shared__ float red[2][64][65];
     const int Q = c0 + c1;
     const int npt = (P + 63) >> 6;
     int tile_id, split_id;
-    if (!tn_block(npt * ((Q + 16 * NJ - 1) / (16 * NJ)), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id)) return;
+    if (!tn_block(npt * ((Q + 16 * NJ - 1) / (16 * NJ)), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id, vblock))
+        return;
     const int pt = tile_id % npt, qt = tile_id / npt;
     const int p0 = pt * 64, q0 = qt * (16 * NJ);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -1624,6 +1651,19 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __r
         if (p0 + pp < P && q0 + qq < Q) out[(size_t)(p0 + pp) * Q + q0 + qq] = red[0][pp][qq] + red[1][pp][qq];
     }
 }
+template <int NJ, bool BF = false>
+__global__ __launch_bounds__(256, 4) void gemm_tn_stream_kernel(const float* __restrict__ A, int lda, int P,
+                                                                const float* __restrict__ x0,
+                                                                const float* __restrict__ x1, int c0, int c1, int shift,
+                                                                int rows, int rows_per_split, float* __restrict__ slab) {
+    tn_stream_body<NJ, BF>(A, lda, P, x0, x1, c0, c1, shift, rows, rows_per_split, slab, -1);
+}
+template <int NJ, bool BF = false>
+__global__ __launch_bounds__(256, 4) void gemm_tn_stream_group_kernel(TnJobs J) {
+    const TnArgs& a = J.job[tn_job_of(J)];
+    tn_stream_body<NJ, BF>((const float*)a.A, a.lda, a.P, (const float*)a.x0, (const float*)a.x1, a.c0, a.c1, a.shift, a.rows,
+                           a.rps, a.slab, (int)blockIdx.x - a.block0);
+}
 
 // ---------------------------------------------------------------------------------------------
 // K3 for bf16-stored operands ON the bf16 matrix cores (FGC_CONV_BF16).  C[P,Q] = sum_rows A[row,P] * X[row >> shift, Q]
@@ -1653,11 +1693,10 @@ __device__ __forceinline__ u32x4 tnb_frag(const char* tile, int stride, int col0
 }
 
 template <int QT>
-__global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsigned short* __restrict__ A, int lda, int P,
-                                                                      const unsigned short* __restrict__ x0,
-                                                                      const unsigned short* __restrict__ x1, int c0, int c1,
-                                                                      int shift, int rows, int rows_per_split,
-                                                                      float* __restrict__ slab) {
+__device__ __forceinline__ void tn_bf16_body(const unsigned short* __restrict__ A, int lda, int P,
+                                             const unsigned short* __restrict__ x0, const unsigned short* __restrict__ x1, int c0,
+                                             int c1, int shift, int rows, int rows_per_split, float* __restrict__ slab,
+                                             int vblock) {
     constexpr int QC = QT * 16;
     constexpr int XS = QC * 2 + 32;
     constexpr int APC = TNB_PC / 8;                                  // 16-byte pieces per row of the A chunk
@@ -1668,7 +1707,7 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsi
     const int Q = c0 + c1;
     const int npc = (P + TNB_PC - 1) / TNB_PC;
     int tile_id, split_id;
-    if (!tn_block(npc * (Q / QC), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id)) return;
+    if (!tn_block(npc * (Q / QC), (rows + rows_per_split - 1) / rows_per_split, tile_id, split_id, vblock)) return;
     const int pc = tile_id % npc, qc = tile_id / npc;
     const int p0 = pc * TNB_PC, q0 = qc * QC;
     const int pw = min(P - p0, TNB_PC);                              // valid columns of A here (a multiple of 8)
@@ -1750,6 +1789,20 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsi
                 if (pp < p0 + pw && qq < Q) out[(size_t)pp * Q + qq] = acc[i][j][t];
             }
 }
+template <int QT>
+__global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_kernel(const unsigned short* __restrict__ A, int lda, int P,
+                                                                      const unsigned short* __restrict__ x0,
+                                                                      const unsigned short* __restrict__ x1, int c0, int c1,
+                                                                      int shift, int rows, int rows_per_split,
+                                                                      float* __restrict__ slab) {
+    tn_bf16_body<QT>(A, lda, P, x0, x1, c0, c1, shift, rows, rows_per_split, slab, -1);
+}
+template <int QT>
+__global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_group_kernel(TnJobs J) {
+    const TnArgs& a = J.job[tn_job_of(J)];
+    tn_bf16_body<QT>((const unsigned short*)a.A, a.lda, a.P, (const unsigned short*)a.x0, (const unsigned short*)a.x1, a.c0, a.c1,
+                     a.shift, a.rows, a.rps, a.slab, (int)blockIdx.x - a.block0);
+}
 
 static bool tn_bf16_ok(int P, int c0, int c1) {
     if (getenv("FGC_NO_TNBF16") && getenv("FGC_NO_TNBF16")[0] == '1') return false;
@@ -1821,6 +1874,77 @@ static int k1_nodes(const fgc_conv_desc* d) {
     return deep ? 16 : TILE;
 }
 
+// ---- which kernel computes a layer's weight gradient, and with what arguments: shared by the per-layer launch (stage 8) and
+// ---- the grouped launch of fgc_conv_bwd_reduce (FGC_CONV_DEFER_DW)
+enum TnVariant { TN_STREAM2 = 0, TN_STREAM4, TN_STREAM2_BF, TN_STREAM4_BF, TN_BF16_4, TN_BF16_2, TN_PLAIN_V4, TN_PLAIN, TN_NVARIANTS };
+struct TnPlan {
+    int variant;
+    TnArgs a;
+    int ntiles, nsplits;
+};
+static bool tn_groupable(int v) { return v <= TN_BF16_2; }
+// rows x [PL columns of A] against [c0 + c1 columns of x0 | x1]
+static TnPlan tn_plan_of(bool bf16, bool vec4, bool stream_ok, const void* A, int PL, const void* x0, const void* x1, int c0, int c1,
+                         int shift, int rows, int rps, float* slab) {
+    TnPlan pl;
+    const int cin = c0 + c1, ns = cdiv(rows, rps);
+    pl.a = TnArgs{A, x0, x1, slab, PL, PL, c0, c1, shift, rows, rps, 0};
+    pl.nsplits = ns;
+    if (bf16 && tn_bf16_ok(PL, c0, c1)) {
+        pl.variant = cin % 64 == 0 ? TN_BF16_4 : TN_BF16_2;
+        pl.ntiles = cdiv(PL, TNB_PC) * (cin % 64 == 0 ? cin / 64 : cin / 32);
+    } else if (bf16 && cin <= 32 && c1 == 0) {
+        pl.variant = TN_STREAM2_BF;
+        pl.ntiles = cdiv(PL, 64);
+    } else if (bf16) {
+        pl.variant = TN_STREAM4_BF;
+        pl.ntiles = cdiv(PL, 64) * cdiv(cin, 64);
+    } else if (stream_ok && cin <= 32 && c1 == 0 && cin % 2 == 0) {
+        pl.variant = TN_STREAM2;
+        pl.ntiles = cdiv(PL, 64);
+    } else if (stream_ok) {
+        pl.variant = TN_STREAM4;
+        pl.ntiles = cdiv(PL, 64) * cdiv(cin, 64);
+    } else {
+        pl.variant = vec4 ? TN_PLAIN_V4 : TN_PLAIN;
+        pl.ntiles = cdiv(PL, 64) * cdiv(cin, 64);
+    }
+    return pl;
+}
+static int tn_launch_one(const TnPlan& pl, const char* tag, hipStream_t st) {
+    const TnArgs& a = pl.a;
+    const dim3 grid = tn_grid(pl.ntiles, pl.nsplits);
+    const float *A = (const float*)a.A, *x0 = (const float*)a.x0, *x1 = (const float*)a.x1;
+    const unsigned short *A16 = (const unsigned short*)a.A, *h0 = (const unsigned short*)a.x0, *h1 = (const unsigned short*)a.x1;
+    switch (pl.variant) {
+        case TN_BF16_4: FGC_LAUNCH(tag, st, (gemm_tn_bf16_kernel<4>), grid, dim3(TNB_THREADS), 0, A16, a.lda, a.P, h0, h1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        case TN_BF16_2: FGC_LAUNCH(tag, st, (gemm_tn_bf16_kernel<2>), grid, dim3(TNB_THREADS), 0, A16, a.lda, a.P, h0, h1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        case TN_STREAM2_BF: FGC_LAUNCH(tag, st, (gemm_tn_stream_kernel<2, true>), grid, dim3(256), 0, A, a.lda, a.P, x0, x1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        case TN_STREAM4_BF: FGC_LAUNCH(tag, st, (gemm_tn_stream_kernel<4, true>), grid, dim3(256), 0, A, a.lda, a.P, x0, x1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        case TN_STREAM2: FGC_LAUNCH(tag, st, gemm_tn_stream_kernel<2>, grid, dim3(256), 0, A, a.lda, a.P, x0, x1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        case TN_STREAM4: FGC_LAUNCH(tag, st, gemm_tn_stream_kernel<4>, grid, dim3(256), 0, A, a.lda, a.P, x0, x1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        case TN_PLAIN_V4: FGC_LAUNCH(tag, st, (gemm_tn_kernel<true>), grid, dim3(256), 0, A, a.lda, a.P, x0, x1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+        default: FGC_LAUNCH(tag, st, (gemm_tn_kernel<false>), grid, dim3(256), 0, A, a.lda, a.P, x0, x1, a.c0, a.c1, a.shift, a.rows, a.rps, a.slab); break;
+    }
+    FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
+    return FGC_OK;
+}
+// jobs of one variant in one launch (block ranges in job order; every tn_grid is a multiple of 8 workgroups)
+static int tn_launch_group(int variant, TnJobs& J, int nblocks, const char* tag, hipStream_t st) {
+    if (J.njobs == 0) return FGC_OK;
+    switch (variant) {
+        case TN_BF16_4: FGC_LAUNCH(tag, st, (gemm_tn_bf16_group_kernel<4>), dim3(nblocks), dim3(TNB_THREADS), 0, J); break;
+        case TN_BF16_2: FGC_LAUNCH(tag, st, (gemm_tn_bf16_group_kernel<2>), dim3(nblocks), dim3(TNB_THREADS), 0, J); break;
+        case TN_STREAM2_BF: FGC_LAUNCH(tag, st, (gemm_tn_stream_group_kernel<2, true>), dim3(nblocks), dim3(256), 0, J); break;
+        case TN_STREAM4_BF: FGC_LAUNCH(tag, st, (gemm_tn_stream_group_kernel<4, true>), dim3(nblocks), dim3(256), 0, J); break;
+        case TN_STREAM2: FGC_LAUNCH(tag, st, (gemm_tn_stream_group_kernel<2>), dim3(nblocks), dim3(256), 0, J); break;
+        default: FGC_LAUNCH(tag, st, (gemm_tn_stream_group_kernel<4>), dim3(nblocks), dim3(256), 0, J); break;
+    }
+    FGC_CHECK_LAUNCH("fgc_conv_bwd_reduce/dW");
+    J.njobs = 0;
+    return FGC_OK;
+}
+
 struct BwdWorkspace {
     float* Wq;        // logits operand
     float* Wpt;       // data-gradient operand
@@ -1875,6 +1999,22 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.narrow = narrow_supported(d) ? take(narrow_bwd_floats(d) + reduce_tmp_floats(w.nb_db, d->cout) + 64) : nullptr;
     w.bytes = off;
     return w;
+}
+
+// the weight-gradient GEMM of a layer in the fine or in the pair form (not the narrow first layer: narrow_tn_operands)
+static TnPlan layer_tn_plan(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, const BwdWorkspace& w) {
+    const int cin = d->c0 + d->c1, cout = d->cout;
+    const int PL = FGC_M * cout + 24;
+    const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
+    if (pairs_ok(d)) {      // K = the n / 4 coarse rows, one source
+        const int nc = d->n >> 2;
+        return tn_plan_of(bf16, true, true, io->r, PL, d->x0, nullptr, d->c0, 0, 0, nc, tn_rows_per_slab(nc, w.splitW), w.slab);
+    }
+    const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0);
+    const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
+    (void)cin;
+    return tn_plan_of(bf16, v4, stream_ok, io->r, PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, tn_rows_per_slab(d->n, w.splitW),
+                      w.slab);
 }
 
 // the five fixed-order sums behind a layer's parameter gradients (slabs of the weight-gradient GEMM, db and dc partials)
@@ -2003,29 +2143,10 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             if (rc) return rc;
         }
         if (stages & 8) {
-            const int P = FGC_M * cout, PL = P + 24;
-            const int rps = tn_rows_per_slab(nc, w.splitW);
-            const int ns = cdiv(nc, rps);
-            if (bf16 && tn_bf16_ok(PL, d->c0, 0)) {
-                const unsigned short* r16 = (const unsigned short*)io->r;
-                const unsigned short* h0 = (const unsigned short*)d->x0;
-                const int npc = cdiv(PL, TNB_PC);
-                if (cin % 64 == 0)
-                    FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<4>), tn_grid(npc * (cin / 64), ns), dim3(TNB_THREADS), 0, r16, PL,
-                               PL, h0, (const unsigned short*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
-                else
-                    FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<2>), tn_grid(npc * (cin / 32), ns), dim3(TNB_THREADS), 0, r16, PL,
-                               PL, h0, (const unsigned short*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
-            } else if (bf16) {
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<4, true>), tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns), dim3(256), 0,
-                           io->r, PL, PL, d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
-            } else if (cin <= 32)
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
-                           d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
-            else
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<4>, tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns), dim3(256), 0,
-                           io->r, PL, PL, d->x0, (const float*)nullptr, d->c0, 0, 0, nc, rps, w.slab);
-            FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
+            if (!(io->flags & FGC_CONV_DEFER_DW)) {
+                rc = tn_launch_one(layer_tn_plan(d, io, w), "gemm_tn_kernel:dW", st);
+                if (rc) return rc;
+            }
             if (!(io->flags & FGC_CONV_DEFER_REDUCE)) {
                 RedJob jobs[5];
                 conv_param_jobs(d, io, w, jobs);
@@ -2249,40 +2370,12 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     }
     // K3: dW0 = r^T x ; [du; dv] = dag^T x
     if (stages & 8) {
-        const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0);
         // one GEMM over the rows of r = [9*cout aggregate columns | da | dg]: rows 0..P-1 of the product are dW0^T
-        // blocks, rows P..P+8 du, rows P+12..P+20 dv
-        const int P = FGC_M * cout, PL = P + 24;
-        const int rps = tn_rows_per_slab(d->n, w.splitW);
-        const int ns = cdiv(d->n, rps);
-        const dim3 g1 = tn_grid(cdiv(PL, 64) * cdiv(cin, 64), ns);
-        const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
-        if (bf16 && tn_bf16_ok(PL, d->c0, d->c1)) {
-            const unsigned short* r16 = (const unsigned short*)io->r;
-            const unsigned short *h0 = (const unsigned short*)d->x0, *h1 = (const unsigned short*)d->x1;
-            const int npc = cdiv(PL, TNB_PC);
-            if (cin % 64 == 0)
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<4>), tn_grid(npc * (cin / 64), ns), dim3(TNB_THREADS), 0, r16, PL,
-                           PL, h0, h1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
-            else
-                FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_bf16_kernel<2>), tn_grid(npc * (cin / 32), ns), dim3(TNB_THREADS), 0, r16, PL,
-                           PL, h0, h1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        } else if (bf16 && cin <= 32 && d->c1 == 0)
-            FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<2, true>), tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL,
-                       PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else if (bf16)
-            FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_stream_kernel<4, true>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
-                       d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else if (stream_ok && cin <= 32 && d->c1 == 0)
-            FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<2>, tn_grid(cdiv(PL, 64), ns), dim3(256), 0, io->r, PL, PL,
-                       d->x0, d->x1, d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else if (stream_ok) FGC_LAUNCH("gemm_tn_kernel:dW", st, gemm_tn_stream_kernel<4>, g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
-                                  d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else if (v4) FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<true>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
-                           d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        else FGC_LAUNCH("gemm_tn_kernel:dW", st, (gemm_tn_kernel<false>), g1, dim3(256), 0, io->r, PL, PL, d->x0, d->x1,
-                        d->c0, d->c1, d->shift, d->n, rps, w.slab);
-        FGC_CHECK_LAUNCH("fgc_conv_bwd/dW");
+        // blocks, rows P..P+8 du, rows P+12..P+20 dv (layer_tn_plan); FGC_CONV_DEFER_DW: launched by fgc_conv_bwd_reduce
+        if (!(io->flags & FGC_CONV_DEFER_DW)) {
+            rc = tn_launch_one(layer_tn_plan(d, io, w), "gemm_tn_kernel:dW", st);
+            if (rc) return rc;
+        }
         // every parameter gradient of the layer in two launches (fixed summation order).  The db / dc partials were
         // left in the workspace by stages 1 and 2: a staged caller keeps the workspace untouched between its calls;
         // with FGC_CONV_DEFER_REDUCE also until fgc_conv_bwd_reduce sums the layers of the whole network at once.
@@ -2397,6 +2490,50 @@ extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_
         nj = 0;
         return r;
     };
+    // the weight-gradient GEMMs of the layers that deferred them (FGC_CONV_DEFER_DW): one launch per kernel form
+    {
+        TnJobs G[TN_NVARIANTS];
+        int nb[TN_NVARIANTS];
+        for (int v = 0; v < TN_NVARIANTS; ++v) G[v].njobs = 0, nb[v] = 0;
+        for (int i = 0; i < count; ++i) {
+            const fgc_conv_desc* d = descs[i];
+            const fgc_conv_bwd_io* io = ios[i];
+            if (!io || !(io->flags & FGC_CONV_DEFER_DW)) continue;
+            rc = validate_conv_desc(d, "fgc_conv_bwd_reduce");
+            if (rc) return rc;
+            FGC_CHECK_ARG(bwd_ws[i], "fgc_conv_bwd_reduce: layer %d: null workspace", i);
+            const BwdWorkspace w = plan_bwd(d, (char*)bwd_ws[i]);
+            TnPlan pl;
+            if (io->dx0 == nullptr && w.narrow) {
+                const float* A;
+                float* slab;
+                int zld, rps;
+                narrow_tn_operands(d, io, w.narrow, &A, &zld, &slab, &rps);
+                pl = tn_plan_of(false, true, true, A, zld, io->ds, nullptr, d->cout, 0, 0, d->n, rps, slab);
+            } else {
+                FGC_CHECK_ARG(io->r, "fgc_conv_bwd_reduce: layer %d: FGC_CONV_DEFER_DW without r", i);
+                pl = layer_tn_plan(d, io, w);
+            }
+            if (!tn_groupable(pl.variant)) {
+                rc = tn_launch_one(pl, "gemm_tn_kernel:dW", st);
+                if (rc) return rc;
+                continue;
+            }
+            TnJobs& J = G[pl.variant];
+            if (J.njobs == TN_MAX_JOBS) {
+                rc = tn_launch_group(pl.variant, J, nb[pl.variant], "gemm_tn_kernel:dW", st);
+                if (rc) return rc;
+                nb[pl.variant] = 0;
+            }
+            pl.a.block0 = nb[pl.variant];
+            J.job[J.njobs++] = pl.a;
+            nb[pl.variant] += (int)tn_grid(pl.ntiles, pl.nsplits).x;
+        }
+        for (int v = 0; v < TN_NVARIANTS; ++v) {
+            rc = tn_launch_group(v, G[v], nb[v], "gemm_tn_kernel:dW", st);
+            if (rc) return rc;
+        }
+    }
     for (int i = 0; i < count; ++i) {
         const fgc_conv_desc* d = descs[i];
         const fgc_conv_bwd_io* io = ios[i];

@@ -28,6 +28,9 @@ constexpr int NARROW_RED_JOBS = 5;
 int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
                       int nb_db, int parts, RedJob* jobs_out, hipStream_t st);
 
+void narrow_tn_operands(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float** A, int* zld_out,
+                        float** slab_out, int* rps_out);
+
 // streaming TN GEMM (fgc_conv_bwd.hip): slab[split][P][c0] = A[rows of the split, P]^T x0[rows of the split, c0]
 int tn_balanced_splits(int desired, int maxs, int rows);   // slab count of a weight-gradient GEMM, XCD-balanced
 int launch_gemm_tn_stream(const char* tag, const float* A, int lda, int P, const float* x0, int c0, int rows,

@@ -774,6 +774,20 @@ int narrow_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     return FGC_OK;
 }
 
+// operands of the first layer's weight-gradient GEMM dW0^T = z^T s (for a caller that launches it with other layers')
+void narrow_tn_operands(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float** A, int* zld_out,
+                        float** slab_out, int* rps_out) {
+    const int zld = narrow_zld(d->c0);
+    const int nblk = cdiv(d->n, NB);
+    const int splits = narrow_splits(d);
+    float* zbuf = scratch;
+    float* part = zbuf + (size_t)d->n * zld + 64;
+    *A = io->z_saved ? io->z_saved : zbuf;
+    *zld_out = zld;
+    *slab_out = part + (size_t)nblk * NARROW_PART + 64;
+    *rps_out = cdiv(cdiv(d->n, splits), 4) * 4;
+}
+
 // stage 8: dW0 = sum_i s_i (x) z_i through the streaming GEMM, then every partial in two reduction launches
 int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* scratch, const float* db_part,
                       int nb_db, int parts, RedJob* jobs_out, hipStream_t st) {
@@ -787,7 +801,7 @@ int narrow_bwd_params(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, float* 
     const int rps = cdiv(cdiv(d->n, splits), 4) * 4;
     const int ns = cdiv(d->n, rps);
     int rc = 0;
-    if (parts & 1) {
+    if ((parts & 1) && !(io->flags & FGC_CONV_DEFER_DW)) {
         rc = launch_gemm_tn_stream("gemm_tn_kernel:dW", io->z_saved ? io->z_saved : zbuf, zld, zld, io->ds, cout, d->n, rps,
                                    ns, slab, st);
         if (rc) return rc;

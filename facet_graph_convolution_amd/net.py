@@ -184,6 +184,11 @@ class FacetDenoiser:
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
         self.step_prologue = os.environ.get("FGC_NO_STEP_PROLOGUE", "0") != "1"
+        # bf16 storage: the weight-gradient GEMMs of all layers in one launch per kernel form at the end of the backward pass
+        # (every layer keeps an `r` of its own until then): there a layer's GEMM is mostly ramp and tail (100k facets: 1.095 ->
+        # 1.070 ms per step, 50k: 0.726 -> 0.705).  The fp32 GEMMs are matrix-bound and lose the shared `r` that stays in the
+        # Infinity Cache (1.761 -> 1.773 ms): a launch per layer.  FGC_GROUPED_DW=0 / 1 forces either.
+        self.grouped_dw = self.batched and os.environ.get("FGC_GROUPED_DW", "1" if dtype == "bf16" else "0") == "1"
         self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
         # the gradient of the 4:1 max pooling behind conv1 / conv2 is a term of those layers' backward stage 1
         self.fused_pool = os.environ.get("FGC_NO_FUSED_POOL", "0") != "1"
@@ -308,6 +313,10 @@ class FacetDenoiser:
         B["dl"] = torch.zeros(max(max_dl, 1) * DL_LD, **f)
         B["dag"] = torch.empty(max(ns) * AG_LD, **f)
         B["r"] = torch.empty(max_r, **f)
+        if self.grouped_dw and gt is not None:
+            for lay in self.layers[1:]:        # (the first layer has no r: its GEMM reads the saved aggregates and ds)
+                cnt = ns[lay.level] * (FGC_M * self._cout(lay) + 24)
+                B["r_" + lay.name] = torch.empty((cnt + 1) // 2 if bf16 else cnt, **f)
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
         B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
         B["loss"] = torch.zeros(2, **f)
@@ -384,6 +393,8 @@ class FacetDenoiser:
             io.stages = 0
             io.ag, io.y, io.dy = B["ag_" + lay.name].data_ptr(), B[lay.y].data_ptr(), B["g_" + lay.y].data_ptr()
             io.ds, io.dl, io.dag, io.r = (B[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
+            if ("r_" + lay.name) in B:
+                io.r = B["r_" + lay.name].data_ptr()
             gW0, gb, gu, gc, gv = grads[lay.pidx:lay.pidx + 5]
             io.dW0, io.db, io.du, io.dc, io.dv = (t.data_ptr() for t in (gW0, gb, gu, gc, gv))
             if pg is not None:
@@ -804,6 +815,8 @@ class FacetDenoiser:
             d, io = M["descs"][name], M["ios"][name]
             lws = B["wsb_" + name]
             base = (_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0
+            if self.batched and self.grouped_dw:
+                base |= _lib.CONV_DEFER_DW
             if not self.sharded:
                 io.stages, io.flags = 0, base
                 _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st), name + " bwd")
@@ -862,6 +875,9 @@ class FacetDenoiser:
                 io.flags = 0
         if self.batched:
             A = M["arrays"]
+            if self.grouped_dw:      # (the staged calls of a sharded step leave other flags behind)
+                for io in M["ios"].values():
+                    io.flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW
             self._tag("bwd:reduce")
             _lib.check(L.fgc_conv_bwd_reduce(A["descs"], A["ios"], A["wsb"], A["count"], st), "reduce")
         if self.sharded:

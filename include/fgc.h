@@ -215,6 +215,11 @@ typedef struct fgc_conv_desc {
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
 #define FGC_CONV_PACKED 1
 #define FGC_CONV_DEFER_REDUCE 2   /* fgc_conv_bwd_io.flags: stage 8 leaves its partial sums for fgc_conv_bwd_reduce */
+#define FGC_CONV_DEFER_DW 16      /* fgc_conv_bwd_io.flags, with FGC_CONV_DEFER_REDUCE: stage 8 does not launch the layer's
+                                   * weight-gradient GEMM either; fgc_conv_bwd_reduce runs the GEMMs of all such layers in one
+                                   * launch per kernel form (same slabs, bit-identical gradients).  The layer's r (a first layer
+                                   * over a narrow input: ds and its saved aggregates), its inputs x0 / x1 and its workspace must
+                                   * then stay untouched until that call: a caller that shares r between layers cannot use it */
 #define FGC_CONV_SAVE_Z 4         /* fgc_conv_desc.flags, first layer over a narrow input (cin <= 8): the forward pass
                                   * leaves the aggregates z [n, roundup4(9*cin)] in its workspace (sized for it by
                                   * fgc_conv_workspace_bytes when the flag is set) so that the backward pass, given
@@ -348,7 +353,8 @@ typedef struct fgc_pack_extra {
  * (train.py:563-565, what fgc_rotate_rows does) and the operands of the network's per-facet MLP, which the fgc_mlp_*
  * entry points then take with FGC_MLP_PACKED.  count may be 0 with descs NULL.
  *
- * fgc_conv_bwd_reduce: with FGC_CONV_DEFER_REDUCE in fgc_conv_bwd_io.flags stage 8 leaves the partial sums of the
+ * fgc_conv_bwd_reduce: (layers with FGC_CONV_DEFER_DW: first their weight-gradient GEMMs, grouped.)  With
+ * FGC_CONV_DEFER_REDUCE in fgc_conv_bwd_io.flags stage 8 leaves the partial sums of the
  * parameter gradients in the layer's workspace; this call sums them for all layers in two launches, in the same
  * fixed order as the per-layer path (bit-identical gradients). */
 int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io* const* ios, void* const* fwd_ws,

@@ -406,6 +406,32 @@ def test_packed_step_inputs_are_read_in_place_until_a_graph_is_captured():
         assert o[0] == out[0][0] and torch.equal(o[1], out[0][1])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_grouped_weight_gradient_launches_equal_the_per_layer_launches(dtype, monkeypatch):
+    """FGC_CONV_DEFER_DW: fgc_conv_bwd_reduce runs the weight-gradient GEMMs of all layers in one launch per kernel form (the
+    bf16 network's default; every layer keeps its own `r` until then).  Same tiles, same slabs, same sums: every gradient is
+    bit-identical to the per-layer launches, over several steps."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = icosphere(3)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    out = []
+    for grouped in ("1", "0"):
+        monkeypatch.setenv("FGC_GROUPED_DW", grouped)
+        net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
+        assert net.grouped_dw == (grouped == "1")
+        losses = [net.train_step(sample_ind=samp, R=Rm)[0].item() for _ in range(3)]
+        out.append((losses, net.params.grad.clone(), net.params.theta.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
 def test_pool_gradient_folded_into_the_conv_backward_equals_the_separate_pass():
     """fgc_conv_bwd_io.pool_y / pool_dy: the gradient of the 4:1 max pooling behind conv1 and conv2 is added to dy inside
     stage 1 of those layers (the d-logits kernel's prologue for conv2, ds_db_kernel for the narrow first layer) instead of

@@ -71,6 +71,8 @@ def label(names):
                 key = "bwd:%s/%s" % (lay, base)
             elif base == "pair_bwd_logits_kernel":
                 key = "bwd:%s/pair_bwd_logits_kernel" % lay
+            elif base.startswith("gemm_tn") and "group" in base:
+                key = "bwd:reduce/gemm_tn_kernel:dW"       # (several per step: the last one's counters are kept)
             elif base.startswith("gemm_tn"):
                 key = "bwd:%s/gemm_tn_kernel:dW" % lay
             elif base.startswith("mlp_bwd_dx"):
