@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
         else if (j.kind == 10) mlp_pack_split_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
         else if (j.kind == 11) mlp_pack_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
         else if (j.kind == 12) mlp_pack_w1dx_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
+        else if (j.kind == 15) mlp_pack_w1dx_split_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
+        else if (j.kind == 16) mlp_pack_w2_split_body(j.W0, (u32x4*)j.dst, j.ncols, j.cout, bid);
         else mlp_pack_w2_bf16_body(j.W0, (u32x4*)j.dst, j.ncols, j.cout, bid);
     } else if (j.kind == 7) pack_plain_bf16_body(j.W0, (unsigned short*)j.dst, j.kdim, bid, nb);
     else if (j.kind == 6) pack_logit_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);

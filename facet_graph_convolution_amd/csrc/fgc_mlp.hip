@@ -518,6 +518,10 @@ int mlp_pack_jobs_f32(const fgc_pack_extra* e, PackJob* jobs, size_t* totals) {
     }
     if (e->mlp_bwd_ws) {
         if (hidden % 256 != 0) return -1;
+        if (mlp_bwd_split_ok(nullptr, nullptr, cin, hidden, cout)) {
+            const int k = mlp_bwd_split_pack_jobs(e, jobs + nj, totals + nj);
+            return k < 0 ? -1 : nj + k;
+        }
         const int kpad = mlp_bwd_kpad(cin);
         jobs[nj] = PackJob{e->mlp_W1, (float*)e->mlp_bwd_ws, 9, cin, cout, kpad, hidden, 0, 0, 0, 0, 0, 0};
         totals[nj++] = (size_t)kpad * hidden;
@@ -546,6 +550,7 @@ extern "C" size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hi
     b += align_up((size_t)1024 * 4 * 4, 256);              // db2 partials
     b += align_up((reduce_tmp_floats(1024, 4) + reduce_tmp_floats((int)gx, (size_t)cin * hidden) +
                    reduce_tmp_floats((int)gx, (size_t)hidden * 5)) * 4 + 256, 256);
+    if (mlp_bwd_split_ok(nullptr, nullptr, cin, hidden, cout)) b = std::max(b, mlp_bwd_split_workspace_bytes(n, cin, hidden));
     return b;
 }
 
@@ -605,6 +610,13 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                   "fgc_mlp_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                   fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));
     hipStream_t st = (hipStream_t)stream;
+    // every 1024-wide product on the bf16 matrix pipe with three-term operand splits (fgc_mlp_bf16.hip) where the shape allows
+    if (mlp_bwd_split_ok(x, dx, cin, hidden, cout) && (uintptr_t)workspace % 16 == 0)
+        return launch_mlp_bwd_split(x, dy, n, cin, hidden, cout, W1, b1, W2, alpha, dx, dW1, db1, dW2, db2, workspace,
+                                    (flags & FGC_MLP_PACKED) != 0, st);
+    // (the operands fgc_conv_pack leaves are the split planes whenever the SHAPE takes the split path)
+    FGC_CHECK_ARG(!(flags & FGC_MLP_PACKED) || !mlp_bwd_split_ok(nullptr, nullptr, cin, hidden, cout),
+                  "fgc_mlp_bwd: FGC_MLP_PACKED needs 16-byte aligned x, dx and workspace for this shape");
     const int kpad = mlp_bwd_kpad(cin);
     const int ctw = mlp_bwd_ctw(cin);
     const int gx = mlp_bwd_gx(n), gy = hidden / (64 * ctw);

@@ -660,6 +660,359 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The fp32 network's MLP BACKWARD on the bf16 matrix pipe (round 5).  mlp_bwd_kernel (fgc_mlp.hip) spends 61 % of its SIMD
+// cycles in v_mfma_f32_16x16x4_f32, which run at the vector FMA rate and keep the vector ALU from issuing (DESIGN.md
+// section 3.1).  Here the two kernels above - the structure whose loop orders fit the two big products - take fp32 x and
+// write fp32 dx, and every operand of a 1024-wide product is a three-term bf16 split (fgc_mlp_split.h): x once per row
+// tile, W1 at pack time, dh = g * lrelu'(h) in registers right where it is produced (4.5 vector instructions per hidden
+// activation against the 64 multiply-adds it then feeds).  g = dy W2^T (K = 3) is ONE MFMA whose 32 k slots hold the six
+// significant term pairs of its three products (split_k3_frag); dW2 = hact^T dy and db2 stay fp32 on the vector ALU (three
+// FMAs per hidden activation - cheaper than splitting hact).  Same results as the fp32-MFMA kernel up to summation order
+// (tests/test_gpu_ops.py holds both against float64 at the same bound).  FGC_NO_MLP_BWD_SPLIT=1 keeps mlp_bwd_kernel.
+// ---------------------------------------------------------------------------------------------
+// split eight fp32 values (two f32x4: fragment elements 0-3 and 4-7) into the three planes of one A / B fragment
+__device__ __forceinline__ void split3_frag(const f32x4& lo, const f32x4& hi, u32x4 (&p)[3]) {
+    u32x2 l[3], h[3];
+    split3(lo, l[0], l[1], l[2]);
+    split3(hi, h[0], h[1], h[2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = u32x4{l[q][0], l[q][1], h[q][0], h[q][1]};
+}
+
+// LDS of a wave of the parameter-gradient kernel: three x planes, the dy rows [32][4] fp32, its W1 fragments [c][ks][plane][lane]
+// (x tile: row = [plane 0 | plane 1 | plane 2 | 32 pad bytes], so that two workgroups of four waves fit a CU's 160 KB)
+#define MBS_XTS(CIN_) (3 * (CIN_) * 2 + 32)
+#define MBS_WAVE_LDS(CIN_) (MB_T * MBS_XTS(CIN_) + MB_T * 16 + MBW_CT * ((CIN_) / 32) * 3 * 1024)
+typedef short mbs_s16x4 __attribute__((ext_vector_type(4)));
+// A fragment of x^T (rows = input channels col0 .. col0 + 15, k = the tile's rows in the order a lane holds its hidden
+// column in the C layout: element j <-> row (j >> 2) * 16 + 4*lq + (j & 3)) out of a row-major plane, by two transposed reads
+__device__ __forceinline__ u32x4 mbs_xT_frag(const char* plane, int stride, int col0, int lq, int lr) {
+    const char* a = plane + (4 * lq + (lr >> 2)) * stride + (col0 + 4 * (lr & 3)) * 2;
+    const mbs_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mbs_s16x4*)a);
+    const mbs_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mbs_s16x4*)(a + 16 * stride));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+__device__ __forceinline__ float keep_if(float v, bool c) { return __uint_as_float(__float_as_uint(v) & (c ? ~0u : 0u)); }
+__device__ __forceinline__ f32x4 keep_if(const f32x4& v, bool c) {
+    return f32x4{keep_if(v[0], c), keep_if(v[1], c), keep_if(v[2], c), keep_if(v[3], c)};
+}
+
+// The weights of a pair of column tiles - 6 KS W1 fragments for h, 2 W2 operands for g, 3 MT W1 fragments for dx: 14 KB at
+// cin = 32 - are the same for every wave: the workgroup stages them in LDS ONCE per pair (each thread moves four 16-byte
+// pieces, requested one pair ahead through registers) and its four waves read them from there.  Loading them per wave, as
+// the bf16 kernel does with a third of the bytes, kept the texture-address path busy with 2 GB per launch and the
+// double-buffered fragments took 128 registers.  One barrier per pair.
+template <int MT>
+__global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
+    const u32x4* __restrict__ Wp16 /* mlp_pack_split_body: three planes */, const u32x4* __restrict__ W1d /* mlp_pack_w1dx_split_body */,
+    const float* __restrict__ b1, const u32x4* __restrict__ W2s /* mlp_pack_w2_split_body */, float alpha, float* __restrict__ dx) {
+    constexpr int CIN = MT * 16;
+    constexpr int KS = CIN / 32;
+    constexpr int NF = 6 * KS + 2 + 3 * MT;     // fragments per pair: bw[c2][ks][p], bg[c2], bt[m][p]
+    constexpr int NI = (NF * 64 + MBB_THREADS - 1) / MBB_THREADS;   // 16-byte pieces per thread
+    __shared__ u32x4 wl[2][NI * MBB_THREADS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int nct = hidden >> 4;
+    const int tile = blockIdx.x * MBB_WAVES + wave;
+    const int row0 = tile * MB_T;               // (a wave past the last row keeps walking: the barriers are the workgroup's)
+    const size_t wplane = (size_t)KS * nct * 64;               // u32x4 per plane of Wp16
+    const size_t dplane = (size_t)(nct >> 1) * MT * 64;        // ... of W1d
+    // this thread's pieces of a pair: source of pair 0 and the step from pair to pair (in u32x4)
+    const u32x4* src[NI];
+    int step[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int item = threadIdx.x + i * MBB_THREADS, f = min(item >> 6, NF - 1), l = item & 63;
+        if (f < 6 * KS) {
+            const int c2 = f / (3 * KS), ks = (f / 3) % KS, p = f % 3;
+            src[i] = Wp16 + p * wplane + ((size_t)ks * nct + c2) * 64 + l;
+            step[i] = 128;
+        } else if (f < 6 * KS + 2) {
+            src[i] = W2s + (f - 6 * KS) * 64 + l;
+            step[i] = 128;
+        } else {
+            const int g = f - 6 * KS - 2, m = g / 3, p = g % 3;
+            src[i] = W1d + p * dplane + (size_t)m * 64 + l;
+            step[i] = MT * 64;
+        }
+    }
+    u32x4 ax[MB_RT][KS][3], gA[MB_RT];
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r) {
+        const int row = row0 + r * 16 + lr;
+        const size_t rc = (size_t)min(row, n - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4* s4 = reinterpret_cast<const f32x4*>(x + rc * CIN + ks * 32 + 8 * lq);
+            // (unconditional loads from the clamped row, zeroed by a bit mask: no load under an exec mask)
+            split3_frag(keep_if(s4[0], row < n), keep_if(s4[1], row < n), ax[r][ks]);
+        }
+        float d[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) d[o] = keep_if(dy[rc * cout + min(o, cout - 1)], row < n && o < cout);
+        gA[r] = split_k3_frag(d, lq, 0);      // rows past n: zero, so their dh is zero
+    }
+    f32x4 dxacc[MB_RT][MT];
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dxacc[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int npairs = nct >> 1;
+    u32x4 stage[NI];
+    f32x4 bbn[2];
+    auto request = [&](int pp) {               // (clamped: the request behind the last pair is a valid, unused load)
+        pp = min(pp, npairs - 1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) stage[i] = src[i][(size_t)pp * step[i]];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) bbn[c2] = *reinterpret_cast<const f32x4*>(b1 + (pp * 2 + c2) * 16 + 4 * lq);
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wl[buf][threadIdx.x + i * MBB_THREADS] = stage[i];
+    };
+    request(0);
+    park(0);
+    __syncthreads();
+    // as mlp_bwd_dx_bf16_kernel: both products that make dh are computed transposed, so that dh leaves the accumulators in
+    // the A layout of dx += dh W1^T
+#pragma unroll 1
+    for (int pp = 0; pp < npairs; ++pp) {
+        const u32x4* w = wl[pp & 1] + lane;
+        const f32x4 bb[2] = {bbn[0], bbn[1]};
+        request(pp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 d[2][MB_RT];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            f32x4 h[MB_RT], g[MB_RT];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 bw[3] = {w[((c2 * KS + ks) * 3 + 0) * 64], w[((c2 * KS + ks) * 3 + 1) * 64], w[((c2 * KS + ks) * 3 + 2) * 64]};
+#pragma unroll
+                for (int r = 0; r < MB_RT; ++r) h[r] = mfma_split(bw, ax[r][ks], h[r]);
+            }
+            const u32x4 bg = w[(6 * KS + c2) * 64];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+                g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bg), __builtin_bit_cast(bf16x8, gA[r]),
+                                                              f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[c2][r][t] = g[r][t] * lrelu01_slope(h[r][t] + bb[c2][t], alpha);
+        }
+        u32x4 ad[MB_RT][3];
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r) split3_frag(d[0][r], d[1][r], ad[r]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const u32x4 bt[3] = {w[(6 * KS + 2 + m * 3 + 0) * 64], w[(6 * KS + 2 + m * 3 + 1) * 64], w[(6 * KS + 2 + m * 3 + 2) * 64]};
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r) dxacc[r][m] = mfma_split(ad[r], bt, dxacc[r][m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        park((pp + 1) & 1);                   // (buffer (pp + 1) & 1 was last read in iteration pp - 1, before its barrier)
+        __syncthreads();
+    }
+    // C layout: column = input channel lr of tile m, rows 4*lq + t
+#pragma unroll
+    for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = row0 + r * 16 + lq * 4 + t;
+            if (row < n) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) dx[(size_t)row * CIN + m * 16 + lr] = dxacc[r][m][t];
+            }
+        }
+}
+
+template <int MT>
+__global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
+    const u32x4* __restrict__ Wp16, const float* __restrict__ b1, const u32x4* __restrict__ W2s, const float* __restrict__ W2,
+    float alpha, float* __restrict__ dW1_slab /* [walkers][cin][hidden] */, float* __restrict__ db1_slab /* [walkers][hidden] */,
+    float* __restrict__ dW2_slab /* [walkers][hidden][4] */, float* __restrict__ db2_slab /* [walkers][4] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int CIN = MT * 16;
+    constexpr int KS = CIN / 32;
+    // a wave's x tile, ROW major as the rows lie in memory: [32 rows][3 planes][CIN bf16], row stride == 32 bytes mod 64 (an odd
+    // multiple of 32: the eight rows a 32-lane half of a transposed read touches land on disjoint 32-byte bank spans)
+    constexpr int XTS = MBS_XTS(CIN);
+    constexpr int XPL = CIN * 2;              // byte offset of a plane within a row
+    constexpr int XTILE = MB_T * XTS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    constexpr int WAVE_LDS = MBS_WAVE_LDS(CIN);
+    char* xT = smem_raw + wave * WAVE_LDS;
+    float* dyw = reinterpret_cast<float*>(xT + XTILE);
+    u32x4* bwl = reinterpret_cast<u32x4*>(xT + XTILE + MB_T * 16);   // the wave's W1 fragments [c][ks][plane][lane]
+    const int hc0 = blockIdx.y * MBW_HCW;
+    const int nct = hidden >> 4;
+    const int ntiles = (n + MB_T - 1) / MB_T;
+    const int walker = blockIdx.x * MBB_WAVES + wave, nwalkers = gridDim.x * MBB_WAVES;
+    const size_t wplane = (size_t)KS * nct * 64;
+    (void)W2;
+
+    // the wave's weights do not change over its walk: the W1 fragments (48 registers as three planes) wait in LDS, one
+    // 16-byte read per MFMA operand; b1 and the W2 operand stay in registers
+    u32x4 bg[MBW_CT];
+    float bb[MBW_CT];
+#pragma unroll
+    for (int c = 0; c < MBW_CT; ++c) {
+        const int ct = (hc0 >> 4) + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bwl[((c * KS + ks) * 3 + p) * 64 + lane] = Wp16[p * wplane + ((size_t)ks * nct + ct) * 64 + lane];
+        bb[c] = b1[ct * 16 + lr];
+        bg[c] = W2s[ct * 64 + lane];
+    }
+    // dW1acc: C layout of x^T dh (column = hidden column lr, row = input channel 4*lq + t of tile m)
+    // dW2acc[c][o], db1acc[c]: this lane's hidden column lr of tile c, summed over the rows the lane holds (its lq)
+    f32x4 dW1acc[MBW_CT][MT];
+    float dW2acc[MBW_CT][3], db1acc[MBW_CT], db2acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < MBW_CT; ++c) {
+        db1acc[c] = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) dW2acc[c][o] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll 1
+    for (int tile = walker; tile < ntiles; tile += nwalkers) {
+        const int row0 = tile * MB_T;
+        u32x4 ax[MB_RT][KS][3];
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r) {
+            const int row = row0 + r * 16 + lr;
+            const size_t rc = (size_t)min(row, n - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(x + rc * CIN + ks * 32 + 8 * lq);
+                // (unconditional loads from the clamped row, zeroed by a bit mask: no load under an exec mask)
+                split3_frag(keep_if(src[0], row < n), keep_if(src[1], row < n), ax[r][ks]);
+                // the tile's planes row major (one 16-byte store per plane) for the transposed reads of the dW1 product
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4*>(xT + p * XPL + (r * 16 + lr) * XTS + (ks * 32 + 8 * lq) * 2) = ax[r][ks][p];
+            }
+        }
+        {   // dy rows of the tile into the wave's LDS tile [32][4]: lane l < 32 owns row l
+            const int rr = row0 + (lane & 31);
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 3; ++o) v[o] = keep_if(dy[(size_t)min(rr, n - 1) * cout + min(o, cout - 1)], rr < n && o < cout);
+            if (lane < 32) *reinterpret_cast<f32x4*>(dyw + lane * 4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // dy of the tile in the two layouts it is needed in: gA[r] = the A operand of g = dy W2^T (this lane's row r*16 + lr);
+        // dyv[j] = the row the lane holds as element j of its hidden column in the C layout: (j >> 2) * 16 + 4*lq + (j & 3)
+        u32x4 gA[MB_RT];
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lr) * 4);
+            const float d3[3] = {d[0], d[1], d[2]};
+            gA[r] = split_k3_frag(d3, lq, 0);
+        }
+        if (blockIdx.y == 0 && lr == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dyw + ((j >> 2) * 16 + 4 * lq + (j & 3)) * 4);
+#pragma unroll
+                for (int o = 0; o < 3; ++o) db2acc[o] += d[o];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MBW_CT; ++c) {
+            __builtin_amdgcn_sched_barrier(0);    // one column tile at a time
+            f32x4 h[MB_RT], g[MB_RT];
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 bw[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bw[p] = bwl[((c * KS + ks) * 3 + p) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < MB_RT; ++r) h[r] = mfma_split(ax[r][ks], bw, h[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+                g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gA[r]), __builtin_bit_cast(bf16x8, bg[c]),
+                                                              f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);    // (phases kept apart: hoisted together their operands do not fit 256 registers)
+#pragma unroll
+            for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    // (the row's dy: re-read per column tile, four addresses per wave - cheaper than 24 registers held)
+                    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + 4 * lq + t) * 4);
+                    const float pre = h[r][t] + bb[c];
+                    const float slope = lrelu01_slope(pre, alpha);
+                    const float ha = pre * slope;            // lrelu(pre) = pre * lrelu'(pre)
+                    g[r][t] *= slope;
+                    db1acc[c] += g[r][t];
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) dW2acc[c][o] = fmaf(ha, dyv[o], dW2acc[c][o]);
+                }
+            // k = r*16 + 4*lq + t: element j of the B fragment of dW1 += x^T dh is (r = j >> 2, t = j & 3)
+            u32x4 bf[3];
+            split3_frag(g[0], g[1], bf);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                u32x4 af[3];                      // x^T fragments of channel tile m (re-read per column tile: registers)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = mbs_xT_frag(xT + p * XPL, XTS, m * 16, lq, lr);
+                dW1acc[c][m] = mfma_split(af, bf, dW1acc[c][m]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile overwrites the LDS tiles
+    }
+    // parameter-gradient slabs of this wave (slab index = its walker id)
+    if (blockIdx.y == 0) {   // db2[o]: lanes (lr = 0, lq) hold the sums of their rows
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float v = db2acc[o];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane == 0) db2_slab[walker * 4 + o] = o < cout ? v : 0.f;
+        }
+        if (lane == 0) db2_slab[walker * 4 + 3] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < MBW_CT; ++c) {
+        const int col = hc0 + c * 16 + lr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dW1_slab[((size_t)walker * CIN + m * 16 + lq * 4 + t) * hidden + col] = dW1acc[c][m][t];
+        float v = db1acc[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) db1_slab[(size_t)walker * hidden + col] = v;
+        float w3[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float u = dW2acc[c][o];
+            u += __shfl_xor(u, 16);
+            u += __shfl_xor(u, 32);
+            w3[o] = o < cout ? u : 0.f;
+        }
+        if (lq == 0) *reinterpret_cast<f32x4*>(dW2_slab + ((size_t)walker * hidden + col) * 4) = f32x4{w3[0], w3[1], w3[2], 0.f};
+    }
+}
+
 }  // namespace fgc
 
 using namespace fgc;
@@ -702,6 +1055,97 @@ int launch_mlp_fwd_split(const float* x, int n, int cin, int hidden, int cout, c
 #undef FGC_MS_FWD
     FGC_CHECK_LAUNCH("fgc_mlp_fwd (split operands)");
     return FGC_OK;
+}
+}  // namespace fgc
+
+namespace fgc {
+// ---- the fp32 network's MLP backward through split operands (called by fgc_mlp_bwd in fgc_mlp.hip) -------------------
+bool mlp_bwd_split_enabled() {
+    static const bool on = mlp_split_enabled() && !(getenv("FGC_NO_MLP_BWD_SPLIT") && getenv("FGC_NO_MLP_BWD_SPLIT")[0] == '1');
+    return on;
+}
+bool mlp_bwd_split_ok(const float* x, const float* dx, int cin, int hidden, int cout) {
+    return mlp_bwd_split_enabled() && cin == 32 && hidden % 256 == 0 && cout <= 3 && (uintptr_t)x % 16 == 0 &&
+           (uintptr_t)dx % 16 == 0;
+}
+// workspace: [W1 fragments, 3 planes][W1 in dx order, 3 planes][dW1 slabs][db1 slabs][dW2 slabs][db2 partials][W2 operand][reduce]
+struct SplitBwdWs {
+    size_t wp, w1d, dW1, db1, dW2, db2, w2s, rtmp, total;
+};
+static SplitBwdWs split_bwd_plan(int n, int cin, int hidden) {
+    const size_t gx = mb_gx(n);
+    SplitBwdWs w;
+    size_t o = 0;
+    w.wp = o, o += align_up((size_t)3 * cin * hidden * 2, 256);
+    w.w1d = o, o += align_up((size_t)3 * cin * hidden * 2, 256);
+    w.dW1 = o, o += align_up(gx * (size_t)cin * hidden * 4, 256);
+    w.db1 = o, o += align_up(gx * (size_t)hidden * 4, 256);
+    w.dW2 = o, o += align_up(gx * (size_t)hidden * 4 * 4, 256);
+    w.db2 = o, o += align_up((size_t)1024 * 4 * 4, 256);
+    w.w2s = o, o += align_up((size_t)(hidden >> 4) * 64 * 16, 256);
+    w.rtmp = o;
+    o += align_up((reduce_tmp_floats(1024, 4) + reduce_tmp_floats((int)gx, (size_t)cin * hidden) +
+                   reduce_tmp_floats((int)gx, (size_t)hidden * 5)) * 4 + 256, 256);
+    w.total = o;
+    return w;
+}
+size_t mlp_bwd_split_workspace_bytes(int n, int cin, int hidden) { return split_bwd_plan(n, cin, hidden).total; }
+// the three operand packs as jobs of the step's housekeeping launch (fgc_conv_pack), laid out as launch_mlp_bwd_split reads them
+int mlp_bwd_split_pack_jobs(const fgc_pack_extra* e, PackJob* jobs, size_t* totals) {
+    const int cin = e->mlp_cin, hidden = e->mlp_hidden, cout = e->mlp_cout;
+    if (e->mlp_n <= 0 || !e->mlp_W2 || (uintptr_t)e->mlp_bwd_ws % 16 != 0) return -1;
+    const SplitBwdWs w = split_bwd_plan(e->mlp_n, cin, hidden);
+    char* base = (char*)e->mlp_bwd_ws;
+    jobs[0] = PackJob{e->mlp_W1, (float*)(base + w.wp), 10, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+    totals[0] = (size_t)cin * hidden;
+    jobs[1] = PackJob{e->mlp_W1, (float*)(base + w.w1d), 15, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+    totals[1] = (size_t)cin * hidden;
+    jobs[2] = PackJob{e->mlp_W2, (float*)(base + w.w2s), 16, cin, cout, 0, hidden, 0, 0, 0, 0, 0, 0};
+    totals[2] = (size_t)cdiv((hidden >> 4) * 64, 256) * 1024;
+    return 3;
+}
+__global__ void mlp_pack_bwd_split_kernel(const float* __restrict__ W1, const float* __restrict__ W2, unsigned short* __restrict__ Wp,
+                                          unsigned short* __restrict__ Wd, u32x4* __restrict__ W2s, int cin, int hidden, int cout,
+                                          int nb) {
+    const int b = blockIdx.x;
+    if (b < nb) mlp_pack_split_body(W1, Wp, cin, hidden, b, nb);
+    else if (b < 2 * nb) mlp_pack_w1dx_split_body(W1, Wd, cin, hidden, b - nb, nb);
+    else mlp_pack_w2_split_body(W2, W2s, hidden, cout, b - 2 * nb);
+}
+int launch_mlp_bwd_split(const float* x, const float* dy, int n, int cin, int hidden, int cout, const float* W1, const float* b1,
+                         const float* W2, float alpha, float* dx, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
+                         bool packed, hipStream_t st) {
+    const SplitBwdWs w = split_bwd_plan(n, cin, hidden);
+    char* base = (char*)workspace;
+    unsigned short* Wp = (unsigned short*)(base + w.wp);
+    unsigned short* W1d = (unsigned short*)(base + w.w1d);
+    float* dW1_slab = (float*)(base + w.dW1);
+    float* db1_slab = (float*)(base + w.db1);
+    float* dW2_slab = (float*)(base + w.dW2);
+    float* db2_part = (float*)(base + w.db2);
+    u32x4* W2s = (u32x4*)(base + w.w2s);
+    float* rtmp = (float*)(base + w.rtmp);
+    const int gx = mb_gx(n), gy = hidden / MBW_HCW;
+    const int nbp = cdiv(cin * hidden, 1024);
+    if (!packed)
+        FGC_LAUNCH("mlp_pack_kernel", st, mlp_pack_bwd_split_kernel, dim3(2 * nbp + cdiv((hidden >> 4) * 64, 256)), dim3(256), 0, W1, W2,
+                   Wp, W1d, W2s, cin, hidden, cout, nbp);
+    const int tiles = cdiv(n, MB_T);
+    constexpr int MT = 2;                      // cin == 32 (mlp_bwd_split_ok)
+    FGC_LAUNCH("mlp_bwd_kernel<dx>", st, (mlp_bwd_dx_split_kernel<MT>), dim3(cdiv(tiles, MBB_WAVES)), dim3(MBB_THREADS), 0, x, dy, n,
+               hidden, cout, (const u32x4*)Wp, (const u32x4*)W1d, b1, W2s, alpha, dx);
+    const size_t smem_w = (size_t)MBB_WAVES * MBS_WAVE_LDS(MT * 16);
+    hipFuncSetAttribute((const void*)mlp_bwd_w_split_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
+    FGC_LAUNCH("mlp_bwd_kernel<w>", st, (mlp_bwd_w_split_kernel<MT>), dim3(gx / 4, gy), dim3(MBB_THREADS), smem_w, x, dy, n, hidden,
+               cout, (const u32x4*)Wp, b1, W2s, W2, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);
+    FGC_CHECK_LAUNCH("fgc_mlp_bwd (split operands)");
+    const RedJob jobs[4] = {
+        {dW1_slab, (size_t)cin * hidden, gx, cin * hidden, hidden, hidden, dW1},
+        {db1_slab, (size_t)hidden, gx, hidden, hidden, hidden, db1},
+        {dW2_slab, (size_t)hidden * 4, gx, hidden * 4, 4, cout, dW2},
+        {db2_part, (size_t)4, gx, 4, 4, cout, db2},
+    };
+    return reduce_jobs("reduce:mlp", jobs, 4, rtmp, st);
 }
 }  // namespace fgc
 

@@ -180,6 +180,64 @@ __device__ __forceinline__ void mlp_pack_w1dx_bf16_body(const float* __restrict_
     }
 }
 
+// ---- the fp32 network's MLP BACKWARD on split operands (fgc_mlp_bf16.hip: mlp_bwd_dx_split_kernel / mlp_bwd_w_split_kernel) ----
+// three-term split of one fp32 value, v = p[0] + p[1] + p[2] (each a bf16, round to nearest even)
+__device__ __forceinline__ void split3_scalar(float v, unsigned short (&p)[3]) {
+    p[0] = f_to_bf(v);
+    const float r1 = v - bf_to_f(p[0]);
+    p[1] = f_to_bf(r1);
+    p[2] = f_to_bf(r1 - bf_to_f(p[1]));
+}
+// The K = 3 product g[row][col] = sum_o dy[row][o] W2[col][o] with fp32-equivalent accuracy in ONE bf16 MFMA: both operands
+// split into three terms, the six products dy_p W2_q that matter (p + q <= 2) times three outputs fill 18 of the 32 k slots.
+//   slot s = pair * 3 + o,  pair -> (dy plane, W2 plane) = (0,0) (0,1) (1,0) (1,1) (0,2) (2,0);  lane (lr, lq) holds slots
+//   8 lq + j, j = 0..7, of row / column lr (slots >= 18: zero).  `side` 0: the dy operand, 1: the W2 operand.
+__device__ __forceinline__ u32x4 split_k3_frag(const float (&v)[3], int lq, int side) {
+    unsigned short p[3][3];   // [o][plane]
+#pragma unroll
+    for (int o = 0; o < 3; ++o) split3_scalar(v[o], p[o]);
+    constexpr int PD[6] = {0, 0, 1, 1, 0, 2}, PW[6] = {0, 1, 0, 1, 2, 0};
+    unsigned w[9];            // slots 2 i, 2 i + 1
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s0 = 2 * i, s1 = 2 * i + 1;
+        w[i] = (unsigned)p[s0 % 3][side ? PW[s0 / 3] : PD[s0 / 3]] | ((unsigned)p[s1 % 3][side ? PW[s1 / 3] : PD[s1 / 3]] << 16);
+    }
+    // lane group lq takes dwords 4 lq .. 4 lq + 3 (bit masks, not branches: the compiler turns a chain of selects on lq into
+    // divergent control flow)
+    const unsigned m0 = lq == 0 ? ~0u : 0u, m1 = lq == 1 ? ~0u : 0u, m2 = lq == 2 ? ~0u : 0u;
+    return u32x4{(w[0] & m0) | (w[4] & m1) | (w[8] & m2), (w[1] & m0) | (w[5] & m1), (w[2] & m0) | (w[6] & m1),
+                 (w[3] & m0) | (w[7] & m1)};
+}
+// W2 [hidden, cout] -> the W2 operand of that product, one 16-byte fragment per (column tile, lane): [hidden / 16][64]
+__device__ __forceinline__ void mlp_pack_w2_split_body(const float* __restrict__ W2, u32x4* __restrict__ W2s, int hidden, int cout,
+                                                       int bid) {
+    const int idx = bid * blockDim.x + threadIdx.x;
+    if (idx >= (hidden >> 4) * 64) return;
+    const int lane = idx & 63, ct = idx >> 6, lr = lane & 15, lq = lane >> 4;
+    float w[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) w[o] = o < cout ? W2[(size_t)(ct * 16 + lr) * cout + o] : 0.f;
+    W2s[idx] = split_k3_frag(w, lq, 1);
+}
+// W1 in the k order of the dx kernel's transposed dh (mlp_pack_w1dx_bf16_body), as three planes of a three-term split
+__device__ __forceinline__ void mlp_pack_w1dx_split_body(const float* __restrict__ W1, unsigned short* __restrict__ Wd, int cin,
+                                                         int hidden, int bid, int nb) {
+    const size_t total = (size_t)cin * hidden;
+    const int mt = cin >> 4;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int m = rest % mt, pp = (int)(rest / mt);
+        const int ch = m * 16 + (lane & 15), col = pp * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
+        unsigned short p[3];
+        split3_scalar(W1[(size_t)ch * hidden + col], p);
+        Wd[idx] = p[0];
+        Wd[total + idx] = p[1];
+        Wd[2 * total + idx] = p[2];
+    }
+}
+
 // one 3-vector times R^T, with the association spelled out (wherever a row is rotated it gets the same bits)
 __device__ __forceinline__ void rot3(const float (&r)[9], float a, float b, float c, float& o0, float& o1, float& o2) {
     o0 = fmaf(r[2], c, fmaf(r[1], b, r[0] * a));
@@ -261,7 +319,8 @@ struct PackJob {
                 // 8: rotate_rows_body (W0 = x, dst = y, aux = R, kdim = 3-vectors);
                 // 14: rotate_logits_body (W0 = x, dst = y, aux = R, kdim = rows, cin = 3-vectors per row, lg_* = the table);
                 // MLP operands, W0 = W1 [cin, ncols]: 9 mlp_pack_body (kdim = kpad), 10 mlp_pack_split_body,
-                // 11 mlp_pack_bf16_body, 12 mlp_pack_w1dx_bf16_body; 13 mlp_pack_w2_bf16_body (W0 = W2 [ncols, cout])
+                // 11 mlp_pack_bf16_body, 12 mlp_pack_w1dx_bf16_body; 13 mlp_pack_w2_bf16_body (W0 = W2 [ncols, cout]);
+                // 15 mlp_pack_w1dx_split_body, 16 mlp_pack_w2_split_body (W0 = W2 [ncols, cout])
     int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
     int block0;
     const float* aux;
