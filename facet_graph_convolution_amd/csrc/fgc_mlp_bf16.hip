@@ -680,10 +680,8 @@ __device__ __forceinline__ void split3_frag(const f32x4& lo, const f32x4& hi, u3
     for (int q = 0; q < 3; ++q) p[q] = u32x4{l[q][0], l[q][1], h[q][0], h[q][1]};
 }
 
-// LDS of a wave of the parameter-gradient kernel: three x planes, the dy rows [32][4] fp32, its W1 fragments [c][ks][plane][lane]
 // (x tile: row = [plane 0 | plane 1 | plane 2 | 32 pad bytes], so that two workgroups of four waves fit a CU's 160 KB)
 #define MBS_XTS(CIN_) (3 * (CIN_) * 2 + 32)
-#define MBS_WAVE_LDS(CIN_) (MB_T * MBS_XTS(CIN_) + MB_T * 16 + MBW_CT * ((CIN_) / 32) * 3 * 1024)
 typedef short mbs_s16x4 __attribute__((ext_vector_type(4)));
 // A fragment of x^T (rows = input channels col0 .. col0 + 15, k = the tile's rows in the order a lane holds its hidden
 // column in the C layout: element j <-> row (j >> 2) * 16 + 4*lq + (j & 3)) out of a row-major plane, by two transposed reads
@@ -834,34 +832,50 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
         }
 }
 
+// Parameter gradients.  A WORKGROUP walks the 32-row tiles; its four waves own 64 hidden columns each (256 per workgroup,
+// blockIdx.y picks the quarter of the hidden layer) and share everything that belongs to the rows: the tile's x split into
+// three planes, dy, and the dy operand of the g product are staged in LDS once per workgroup - each wave splits a
+// quarter of the rows - one tile ahead (requested before the current tile's products, parked behind them, one barrier per
+// tile).  The first version gave every wave its own tiles: 16 column slices each split the same x and built the same dy
+// operand (270 of its 700 vector instructions per tile) and waited for its own loads at the top of every tile.
+//   LDS: 2 x { x [32 rows][plane 0 | plane 1 | plane 2 | pad] bf16, dy [32][4] fp32, dy operand [32][3 lane groups] } +
+//   per wave its W1 fragments [c][ks][plane][lane] (they do not change over the walk; as registers they were 48 of 256).
+#define MBS_TILE_LDS(CIN_) (MB_T * MBS_XTS(CIN_) + MB_T * 16 + MB_T * 48)
+#define MBS_WG_LDS(CIN_) (2 * MBS_TILE_LDS(CIN_) + MBB_WAVES * MBW_CT * ((CIN_) / 32) * 3 * 1024)
+// all nine dwords of the dy operand of one row (split_k3_frag, side 0): lane group lq takes dwords 4 lq .. 4 lq + 3
+__device__ __forceinline__ void split_k3_row(const float (&v)[3], unsigned (&w)[9]) {
+    unsigned short p[3][3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) split3_scalar(v[o], p[o]);
+    constexpr int PD[6] = {0, 0, 1, 1, 0, 2};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s0 = 2 * i, s1 = 2 * i + 1;
+        w[i] = (unsigned)p[s0 % 3][PD[s0 / 3]] | ((unsigned)p[s1 % 3][PD[s1 / 3]] << 16);
+    }
+}
+
 template <int MT>
 __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int n, int hidden, int cout,
-    const u32x4* __restrict__ Wp16, const float* __restrict__ b1, const u32x4* __restrict__ W2s, const float* __restrict__ W2,
-    float alpha, float* __restrict__ dW1_slab /* [walkers][cin][hidden] */, float* __restrict__ db1_slab /* [walkers][hidden] */,
+    const u32x4* __restrict__ Wp16, const float* __restrict__ b1, const u32x4* __restrict__ W2s, float alpha,
+    float* __restrict__ dW1_slab /* [walkers][cin][hidden] */, float* __restrict__ db1_slab /* [walkers][hidden] */,
     float* __restrict__ dW2_slab /* [walkers][hidden][4] */, float* __restrict__ db2_slab /* [walkers][4] */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int CIN = MT * 16;
     constexpr int KS = CIN / 32;
-    // a wave's x tile, ROW major as the rows lie in memory: [32 rows][3 planes][CIN bf16], row stride == 32 bytes mod 64 (an odd
-    // multiple of 32: the eight rows a 32-lane half of a transposed read touches land on disjoint 32-byte bank spans)
-    constexpr int XTS = MBS_XTS(CIN);
+    static_assert(KS == 1, "staging below moves one 16-byte piece of a 32-channel row per lane");
+    constexpr int XTS = MBS_XTS(CIN);         // row stride of the x tile, == 32 bytes mod 64 (conflict-free transposed reads)
     constexpr int XPL = CIN * 2;              // byte offset of a plane within a row
-    constexpr int XTILE = MB_T * XTS;
+    constexpr int TILE = MBS_TILE_LDS(CIN);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    constexpr int WAVE_LDS = MBS_WAVE_LDS(CIN);
-    char* xT = smem_raw + wave * WAVE_LDS;
-    float* dyw = reinterpret_cast<float*>(xT + XTILE);
-    u32x4* bwl = reinterpret_cast<u32x4*>(xT + XTILE + MB_T * 16);   // the wave's W1 fragments [c][ks][plane][lane]
-    const int hc0 = blockIdx.y * MBW_HCW;
+    u32x4* bwl = reinterpret_cast<u32x4*>(smem_raw + 2 * TILE) + wave * (MBW_CT * KS * 3 * 64);
+    const int hc0 = blockIdx.y * (MBB_WAVES * MBW_HCW) + wave * MBW_HCW;
     const int nct = hidden >> 4;
     const int ntiles = (n + MB_T - 1) / MB_T;
-    const int walker = blockIdx.x * MBB_WAVES + wave, nwalkers = gridDim.x * MBB_WAVES;
+    const int walker = blockIdx.x, nwalkers = gridDim.x;
     const size_t wplane = (size_t)KS * nct * 64;
-    (void)W2;
 
-    // the wave's weights do not change over its walk: the W1 fragments (48 registers as three planes) wait in LDS, one
-    // 16-byte read per MFMA operand; b1 and the W2 operand stay in registers
     u32x4 bg[MBW_CT];
     float bb[MBW_CT];
 #pragma unroll
@@ -886,44 +900,55 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
         for (int m = 0; m < MT; ++m) dW1acc[c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
+    // staging share of this lane: row 8 wave + (lane >> 3) of the tile, channels 4 (lane & 7) .. + 3; its dy row if lane < 8
+    const int srow = wave * 8 + (lane >> 3), sch = (lane & 7) * 4, drow = wave * 8 + (lane & 7);
+    f32x4 sx;
+    float sd[3];
+    auto request = [&](int tile) {             // (clamped rows: always valid loads; rows past n are zeroed by bit masks)
+        const int row = tile * MB_T + srow, rd = tile * MB_T + drow;
+        sx = keep_if(*reinterpret_cast<const f32x4*>(x + (size_t)min(row, n - 1) * CIN + sch), row < n);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) sd[o] = keep_if(dy[(size_t)min(rd, n - 1) * cout + min(o, cout - 1)], rd < n && o < cout);
+    };
+    auto park = [&](int buf) {
+        char* t = smem_raw + buf * TILE;
+        u32x2 pl[3];
+        split3(sx, pl[0], pl[1], pl[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(t + srow * XTS + p * XPL + sch * 2) = pl[p];
+        unsigned w9[9];
+        split_k3_row(sd, w9);
+        {   // (no `lane < 8`: the eight lanes that share a dy row store the same bytes - a branch here, with every accumulator
+            //  live across it, made the register allocator spill 129 of them)
+            *reinterpret_cast<f32x4*>(t + MB_T * XTS + drow * 16) = f32x4{sd[0], sd[1], sd[2], 0.f};
+            u32x4* fr = reinterpret_cast<u32x4*>(t + MB_T * XTS + MB_T * 16 + drow * 48);
+            fr[0] = u32x4{w9[0], w9[1], w9[2], w9[3]};
+            fr[1] = u32x4{w9[4], w9[5], w9[6], w9[7]};
+            fr[2] = u32x4{w9[8], 0u, 0u, 0u};
+        }
+    };
+    const int my_tiles = walker < ntiles ? (ntiles - walker + nwalkers - 1) / nwalkers : 0;
+    if (my_tiles > 0) {
+        request(walker);
+        park(0);
+    }
+    __syncthreads();
 #pragma unroll 1
-    for (int tile = walker; tile < ntiles; tile += nwalkers) {
-        const int row0 = tile * MB_T;
-        u32x4 ax[MB_RT][KS][3];
-#pragma unroll
-        for (int r = 0; r < MB_RT; ++r) {
-            const int row = row0 + r * 16 + lr;
-            const size_t rc = (size_t)min(row, n - 1);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(x + rc * CIN + ks * 32 + 8 * lq);
-                // (unconditional loads from the clamped row, zeroed by a bit mask: no load under an exec mask)
-                split3_frag(keep_if(src[0], row < n), keep_if(src[1], row < n), ax[r][ks]);
-                // the tile's planes row major (one 16-byte store per plane) for the transposed reads of the dW1 product
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<u32x4*>(xT + p * XPL + (r * 16 + lr) * XTS + (ks * 32 + 8 * lq) * 2) = ax[r][ks][p];
-            }
-        }
-        {   // dy rows of the tile into the wave's LDS tile [32][4]: lane l < 32 owns row l
-            const int rr = row0 + (lane & 31);
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < 3; ++o) v[o] = keep_if(dy[(size_t)min(rr, n - 1) * cout + min(o, cout - 1)], rr < n && o < cout);
-            if (lane < 32) *reinterpret_cast<f32x4*>(dyw + lane * 4) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // dy of the tile in the two layouts it is needed in: gA[r] = the A operand of g = dy W2^T (this lane's row r*16 + lr);
-        // dyv[j] = the row the lane holds as element j of its hidden column in the C layout: (j >> 2) * 16 + 4*lq + (j & 3)
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = walker + it * nwalkers;
+        const char* t = smem_raw + (it & 1) * TILE;
+        const float* dyw = reinterpret_cast<const float*>(t + MB_T * XTS);
+        request(min(tile + nwalkers, ntiles - 1));      // (the tile behind the last: a valid load, parked and never read)
+        __builtin_amdgcn_sched_barrier(0);
+        // gA[r] = the A operand of g = dy W2^T (this lane's row r*16 + lr; lane groups 0-2 carry slots, group 3 zeros)
         u32x4 gA[MB_RT];
 #pragma unroll
         for (int r = 0; r < MB_RT; ++r) {
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + lr) * 4);
-            const float d3[3] = {d[0], d[1], d[2]};
-            gA[r] = split_k3_frag(d3, lq, 0);
+            const u32x4 f = *reinterpret_cast<const u32x4*>(t + MB_T * XTS + MB_T * 16 + (r * 16 + lr) * 48 + min(lq, 2) * 16);
+            const unsigned keep = lq < 3 ? ~0u : 0u;
+            gA[r] = u32x4{f[0] & keep, f[1] & keep, f[2] & keep, f[3] & keep};
         }
-        if (blockIdx.y == 0 && lr == 0) {
+        if (blockIdx.y == 0 && wave == 0 && lr == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4 d = *reinterpret_cast<const f32x4*>(dyw + ((j >> 2) * 16 + 4 * lq + (j & 3)) * 4);
@@ -934,6 +959,8 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
         for (int c = 0; c < MBW_CT; ++c) {
             __builtin_amdgcn_sched_barrier(0);    // one column tile at a time
+            asm volatile("" ::: "memory");        // (and its LDS operands re-read: kept from the previous column tile - the
+                                                  //  addresses are the same - they would be 60 registers held across the loop)
             f32x4 h[MB_RT], g[MB_RT];
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -943,7 +970,13 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bw[p] = bwl[((c * KS + ks) * 3 + p) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < MB_RT; ++r) h[r] = mfma_split(ax[r][ks], bw, h[r]);
+                for (int r = 0; r < MB_RT; ++r) {
+                    u32x4 ax[3];                  // x fragments: row r*16 + lr, channels ks*32 + 8*lq .. + 7, plane by plane
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        ax[p] = *reinterpret_cast<const u32x4*>(t + (r * 16 + lr) * XTS + p * XPL + (ks * 32 + 8 * lq) * 2);
+                    h[r] = mfma_split(ax, bw, h[r]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
@@ -953,14 +986,14 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t4 = 0; t4 < 4; ++t4) {
                     // (the row's dy: re-read per column tile, four addresses per wave - cheaper than 24 registers held)
-                    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + 4 * lq + t) * 4);
-                    const float pre = h[r][t] + bb[c];
+                    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + 4 * lq + t4) * 4);
+                    const float pre = h[r][t4] + bb[c];
                     const float slope = lrelu01_slope(pre, alpha);
                     const float ha = pre * slope;            // lrelu(pre) = pre * lrelu'(pre)
-                    g[r][t] *= slope;
-                    db1acc[c] += g[r][t];
+                    g[r][t4] *= slope;
+                    db1acc[c] += g[r][t4];
 #pragma unroll
                     for (int o = 0; o < 3; ++o) dW2acc[c][o] = fmaf(ha, dyv[o], dW2acc[c][o]);
                 }
@@ -972,14 +1005,19 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
             for (int m = 0; m < MT; ++m) {
                 u32x4 af[3];                      // x^T fragments of channel tile m (re-read per column tile: registers)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[p] = mbs_xT_frag(xT + p * XPL, XTS, m * 16, lq, lr);
+                for (int p = 0; p < 3; ++p) af[p] = mbs_xT_frag(t + p * XPL, XTS, m * 16, lq, lr);
                 dW1acc[c][m] = mfma_split(af, bf, dW1acc[c][m]);
+                // (volatile statements keep their order: this column tile's last product comes before the next one's first
+                //  LDS read; left free, the compiler runs two column tiles' phases side by side and spills the accumulators)
+                asm volatile("" : "+v"(dW1acc[c][m])::"memory");
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile overwrites the LDS tiles
+        __builtin_amdgcn_sched_barrier(0);
+        park((it + 1) & 1);                   // (that buffer was last read in iteration it - 1, before its barrier)
+        __syncthreads();
     }
-    // parameter-gradient slabs of this wave (slab index = its walker id)
-    if (blockIdx.y == 0) {   // db2[o]: lanes (lr = 0, lq) hold the sums of their rows
+    // parameter-gradient slabs of this wave (slab index = the workgroup's walker id)
+    if (blockIdx.y == 0 && wave == 0) {   // db2[o]: lanes (lr = 0, lq) hold the sums of their rows
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             float v = db2acc[o];
@@ -995,8 +1033,8 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dW1_slab[((size_t)walker * CIN + m * 16 + lq * 4 + t) * hidden + col] = dW1acc[c][m][t];
+            for (int t4 = 0; t4 < 4; ++t4)
+                dW1_slab[((size_t)walker * CIN + m * 16 + lq * 4 + t4) * hidden + col] = dW1acc[c][m][t4];
         float v = db1acc[c];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
@@ -1134,10 +1172,10 @@ int launch_mlp_bwd_split(const float* x, const float* dy, int n, int cin, int hi
     constexpr int MT = 2;                      // cin == 32 (mlp_bwd_split_ok)
     FGC_LAUNCH("mlp_bwd_kernel<dx>", st, (mlp_bwd_dx_split_kernel<MT>), dim3(cdiv(tiles, MBB_WAVES)), dim3(MBB_THREADS), 0, x, dy, n,
                hidden, cout, (const u32x4*)Wp, (const u32x4*)W1d, b1, W2s, alpha, dx);
-    const size_t smem_w = (size_t)MBB_WAVES * MBS_WAVE_LDS(MT * 16);
+    const size_t smem_w = MBS_WG_LDS(MT * 16);
     hipFuncSetAttribute((const void*)mlp_bwd_w_split_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
-    FGC_LAUNCH("mlp_bwd_kernel<w>", st, (mlp_bwd_w_split_kernel<MT>), dim3(gx / 4, gy), dim3(MBB_THREADS), smem_w, x, dy, n, hidden,
-               cout, (const u32x4*)Wp, b1, W2s, W2, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);
+    FGC_LAUNCH("mlp_bwd_kernel<w>", st, (mlp_bwd_w_split_kernel<MT>), dim3(gx, hidden / (MBB_WAVES * MBW_HCW)), dim3(MBB_THREADS), smem_w,
+               x, dy, n, hidden, cout, (const u32x4*)Wp, b1, W2s, alpha, dW1_slab, db1_slab, dW2_slab, db2_part);
     FGC_CHECK_LAUNCH("fgc_mlp_bwd (split operands)");
     const RedJob jobs[4] = {
         {dW1_slab, (size_t)cin * hidden, gx, cin * hidden, hidden, hidden, dW1},

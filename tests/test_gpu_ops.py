@@ -56,6 +56,42 @@ def test_mlp_forward_split_operands_are_as_accurate_as_the_fp32_mfma():
     assert errs["split"] < 2.0 * errs["fp32"] + 2e-7, errs
 
 
+def test_mlp_backward_split_operands_are_as_accurate_as_the_fp32_mfma():
+    """fgc_mlp_bwd with 32 input channels (the network's head) runs every 1024-wide product on the bf16 matrix pipe with
+    three-term operand splits (mlp_bwd_dx_split_kernel / mlp_bwd_w_split_kernel, fgc_mlp_bf16.hip) and keeps the fused
+    fp32-MFMA kernel behind FGC_NO_MLP_BWD_SPLIT=1.  Both against float64 on the same inputs, 5 000 rows (several tiles per
+    walker, a ragged last tile): the split form must be as close as the fp32 MFMA is."""
+    import subprocess, sys, textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import numpy as np, torch
+        from facet_graph_convolution_amd import ops
+        rs = np.random.RandomState(11)
+        n = 5003
+        f = lambda *a, **k: torch.from_numpy(rs.normal(*a, **k).astype(np.float32))
+        x = f(size=(n, 32)); dy = f(size=(n, 3))
+        W1 = f(0, 0.05, (32, 1024)); b1 = f(0, 0.01, 1024); W2 = f(0, 0.05, (1024, 3))
+        xd = x.double().requires_grad_(True)
+        pd = [t.double().requires_grad_(True) for t in (W1, b1, W2)]
+        h = xd @ pd[0] + pd[1]
+        y = torch.where(h > 0, h, 0.1 * h) @ pd[2]
+        (y * dy.double()).sum().backward()
+        got = ops.mlp_bwd(x.cuda(), dy.cuda(), W1.cuda(), b1.cuda(), W2.cuda(), 0.1)
+        refs = [xd.grad, pd[0].grad, pd[1].grad, pd[2].grad, dy.double().sum(0)]
+        for name, g, r in zip(["dx", "dW1", "db1", "dW2", "db2"], got, refs):
+            print("ERR", name, "%.6e" % ((g.cpu().double() - r).abs().max().item() / max(1.0, r.abs().max().item())))
+    """)
+    errs = {}
+    for tag, env in (("split", {}), ("fp32", {"FGC_NO_MLP_BWD_SPLIT": "1"})):
+        out = subprocess.run([sys.executable, "-c", code], cwd=repo, env=dict(os.environ, **env), capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        errs[tag] = {l.split()[1]: float(l.split()[2]) for l in out.stdout.splitlines() if l.startswith("ERR")}
+    for name in ("dx", "dW1", "db1", "dW2", "db2"):
+        assert errs["fp32"][name] < 5e-6 and errs["split"][name] < 5e-6, (name, errs)
+        assert errs["split"][name] < 2.0 * errs["fp32"][name] + 3e-7, (name, errs)
+
+
 @pytest.mark.parametrize("n,cin", [(1000, 32), (300, 64), (130, 128), (70, 48)])
 def test_mlp_operands_packed_by_the_step_prologue(n, cin):
     """fgc_conv_pack with an fgc_pack_extra leaves the MLP's operands (split planes or the fp32 operand, whichever the shape
