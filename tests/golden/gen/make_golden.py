@@ -243,6 +243,62 @@ def net_case(tag, x_np, adjs_np, gt_np, seed, multi_scale):
     save("net_%s%s%s.npz" % (tag, "_ms" if multi_scale else "", "_f64" if F64 else ""), **out)
 
 
+def net_case_patch_size(tag, subdiv, seed):
+    """One training step of the reference network at the reference's OWN patch size (settings.py:20: 20 000 faces): icosphere
+    subdivision 5 = 20 480 faces through the reference preprocessing (its own coarsening draw, np.random.seed(seed)) and the
+    reference model / loss, forward + backward.  Self-contained fixture: the inputs as the float32 / int placeholders see
+    them (train.py:409-427), the three K-lists (int16 / int32), loss, normalised output, the 44 gradients."""
+    Vc, F = icosphere(subdiv)
+    V = add_noise(Vc, F, 0.2, seed=1)
+    np.random.seed(seed)
+    ds = ref_data.PreprocessedData(10 ** 9, 2, 3)
+    t0 = time.time()
+    ds.addMesh_TimeEfficient(V, F, GTV=Vc)
+    print("reference preprocessing of %d faces: %.1f s" % (F.shape[0], time.time() - t0))
+    assert len(ds.in_list) == 1
+    x_np, adjs_np, gt_np = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    x32 = np.asarray(x_np).astype(np.float32)
+    gt32 = np.asarray(gt_np).astype(np.float32)
+    x_in = torch.tensor(x32, dtype=FDT)
+    adjs = [torch.tensor(np.asarray(a), dtype=torch.int32) for a in adjs_np]
+    gt = torch.tensor(gt32, dtype=FDT)
+    n0 = x32.shape[1]
+    sample_ind = np.random.RandomState(2).randint(n0, size=4000)
+    R = ref_utils.rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    rot = torch.tensor(np.tile(R.reshape(1, 1, 3, 3), (1, n0, 1, 1)).astype(np.float32), dtype=FDT)
+    keep = {}
+
+    def fn():
+        # (train.py:439-451, 509-517 restated with the same tf ops as in net_case; the network and the loss are reference code)
+        tfn_rot = tf.reshape(tf.matmul(rot, tf.reshape(gt, [1, -1, 3, 1])), [1, -1, 3])
+        fn_rot = tf.reshape(x_in, [1, -1, 2, 3])
+        fn_rot = tf.transpose(fn_rot, [0, 1, 3, 2])
+        fn_rot = tf.matmul(rot, fn_rot)
+        fn_rot = tf.reshape(tf.transpose(fn_rot, [0, 1, 3, 2]), [1, -1, 6])
+        y0 = ref_model.get_model_reg_multi_scale(fn_rot, adjs, 1.0, multiScale=False)
+        keep["y0"] = y0
+        n_conv = ref_utils.normalizeTensor(y0)
+        keep["n_conv"] = n_conv
+        samp_n = tf.transpose(tf.gather(tf.transpose(n_conv, [1, 0, 2]), torch.tensor(sample_ind)), [1, 0, 2])
+        samp_gt = tf.transpose(tf.gather(tf.transpose(tfn_rot, [1, 0, 2]), torch.tensor(sample_ind)), [1, 0, 2])
+        return ref_train.faceNormalsLoss(samp_n, samp_gt)
+
+    t0 = time.time()
+    loss, variables = run_with_params(fn, seed)
+    loss.backward()
+    print("reference forward + backward at N0 = %d: %.1f s" % (n0, time.time() - t0))
+    out = dict(seed=np.int64(seed), num_faces=np.int64(ds.num_faces[0]), sample_ind=sample_ind.astype(np.int32), R=R,
+               x=x32, gt=gt32, loss=np.float64(loss.item()), n_vars=np.int64(len(variables)),
+               y0=keep["y0"].detach().numpy().astype(np.float32), n_conv=keep["n_conv"].detach().numpy().astype(np.float32))
+    for l, a in enumerate(adjs_np):
+        a = np.asarray(a)
+        assert a.min() >= 0
+        out["adj%d" % l] = a.astype(np.int16 if a.max() < 2 ** 15 else np.int32)
+    for i, (name, v) in enumerate(variables):
+        out["g%02d" % i] = v.grad.numpy().astype(np.float32)
+    save("net_%s%s.npz" % (tag, "_f64" if F64 else ""), **out)
+
+
 def infer_case(tag, x_np, adjs_np, ds, seed):
     """Forward without rotation + inference epilogue of inferNetOld (train.py:72-75,115-121,136)."""
     x_in = torch.tensor(np.asarray(x_np).astype(np.float32), dtype=FDT)
@@ -410,6 +466,9 @@ def main():
         if not F64:  # the float64 run (error-budget reference) is kept for one net only
             net_case("ico3", x, adjs, gt, seed=0, multi_scale=True)
             net_case("torus640", xt, adjst, gtt, seed=1, multi_scale=False)
+    if want("net20k") and not F64:
+        # the reference's own patch size (settings.py:20): ~800 level-0 tiles of 32 nodes, more workgroups than CUs
+        net_case_patch_size("ico5_20k", 5, seed=3)
     if want("infer") and not F64:
         infer_case("ico3", x, adjs, ds, seed=0)
     if want("msvertex"):

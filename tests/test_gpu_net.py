@@ -45,6 +45,36 @@ def test_train_forward_backward_matches_reference(golden_dir, name, tag, seed):
     print("worst relative gradient error over 44 variables: %.3e" % worst)
 
 
+def test_train_step_matches_the_reference_at_its_patch_size(golden_dir):
+    """The HIP step against the FIXTURE (not the oracle) at the reference's own patch size (settings.py:20): net_ico5_20k.npz
+    is the reference source - preprocessing with its own coarsening draw, network, loss, backward - executed on an icosphere
+    of 20 480 faces (N0 = 25 024: 782 level-0 tiles, more workgroups than the chip has CUs).  Same fp32 tolerances as the
+    small fixtures."""
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    z = np.load(os.path.join(golden_dir, "net_ico5_20k.npz"))
+    adjs = [z["adj%d" % l].astype(np.int32) for l in range(3)]
+    net = FacetDenoiser("cuda:0", seed=int(z["seed"]))
+    net.bind_mesh(z["x"], adjs, gt=z["gt"])
+    assert len(net.params.spec) == int(z["n_vars"])
+    net.set_rotation(z["R"])
+    net.set_samples(z["sample_ind"].astype(np.int64))
+    loss = net.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    B = net.buffers
+    ref = z["y0"][0]
+    np.testing.assert_allclose(B["y0"].cpu().numpy(), ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(B["nconv"].cpu().numpy(), z["n_conv"][0], rtol=0, atol=2e-5)
+    assert abs(loss[0].item() - float(z["loss"])) < 1e-4 * float(z["loss"])
+    worst = 0.0
+    for i, g in enumerate(net.params.grads):
+        ref = z["g%02d" % i]
+        scale = max(np.abs(ref).max(), 1e-3)
+        err = np.abs(g.cpu().numpy() - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
+    print("20 480 faces: worst relative gradient error over 44 variables %.3e" % worst)
+
+
 def test_gradients_vs_float64_truth(golden_dir):
     """Error budget: the GPU fp32 gradients are as close to the float64 gradients as the reference's own fp32 run."""
     z32 = np.load(os.path.join(golden_dir, "net_ico3.npz"))

@@ -179,3 +179,47 @@ def test_csr_oracle_multi_scale_matches_the_reference_shaped_oracle(golden_dir):
     for i, (a, b) in enumerate(zip(pr, pc)):
         scale = max(a.grad.abs().max().item(), 1e-3)
         assert (a.grad - b.grad).abs().max().item() < 1e-9 * scale, i
+
+
+# ---- the reference's own patch size (settings.py:20): 20 480 faces, N0 = 25 024, ~800 level-0 tiles ------------------------
+def _net20k(golden_dir):
+    z = _load(golden_dir, "net_ico5_20k.npz")
+    return z, [z["adj%d" % l].astype(np.int32) for l in range(3)]
+
+
+def test_reference_shaped_oracle_matches_the_reference_at_its_patch_size(golden_dir):
+    """oracle/model_ref.py against net_ico5_20k.npz - the reference source itself (preprocessing, coarsening draw, network,
+    loss, backward) executed on an icosphere of 20 480 faces: normals, loss, all 44 gradients, fp32 against fp32 (same op
+    sequence: summation order only)."""
+    z, adjs = _net20k(golden_dir)
+    params = [p.requires_grad_(True) for p in R.init_params(int(z["seed"]))]
+    loss, n_conv = R.train_loss(torch.tensor(z["x"]), [torch.tensor(a) for a in adjs], torch.tensor(z["gt"]), params,
+                                z["sample_ind"].astype(np.int64), torch.tensor(z["R"].astype(np.float32)))
+    np.testing.assert_allclose(n_conv.detach().numpy(), z["n_conv"], rtol=0, atol=2e-5)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * float(z["loss"])
+    loss.backward()
+    for i, p in enumerate(params):
+        ref = z["g%02d" % i]
+        scale = max(np.abs(ref).max(), 1e-3)
+        assert np.abs(p.grad.numpy() - ref).max() < 2e-3 * scale, "grad %d" % i
+
+
+def test_csr_oracle_matches_the_reference_at_its_patch_size(golden_dir):
+    """oracle/model_csr_ref.py (float64 closed form) against the same fixture: the reference's fp32 run sits within its fp32
+    budget of it (the bounds the GPU tests use: normals 2e-5, loss 1e-4 relative, gradients 2e-3 of each tensor's largest
+    entry; measured an order of magnitude inside)."""
+    from oracle import model_csr_ref as C
+    z, adjs = _net20k(golden_dir)
+    params = C.init_params(int(z["seed"]))
+    loss, n_conv = C.train_loss(z["x"], adjs, z["gt"], params, z["sample_ind"].astype(np.int64), z["R"].astype(np.float32))
+    err_n = np.abs(n_conv.detach().numpy() - z["n_conv"]).max()
+    assert err_n < 2e-5, err_n
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * float(z["loss"])
+    loss.backward()
+    worst = 0.0
+    for i, p in enumerate(params):
+        ref = z["g%02d" % i]
+        scale = max(np.abs(ref).max(), 1e-3)
+        worst = max(worst, np.abs(p.grad.numpy() - ref).max() / scale)
+    print("float64 closed form vs the reference fp32 run at 20 480 faces: normals %.2e, worst gradient %.2e" % (err_n, worst))
+    assert worst < 2e-3, worst
