@@ -534,7 +534,7 @@ def main(argv=None):
         if not train:
             net.forward_multi_scale() if args.multi_scale else net.forward(rotate=False)
             return
-        net.set_step_inputs_packed(SR_all[k], S_loc[k] if S_loc else None)
+        net.set_step_inputs_packed(SR_all[k], S_loc[k] if S_loc else None, in_place=True)
         net.forward_backward(rotate=True, capture=bool(args.graph) or graph_mode[0])
         if world > 1 and not shard:
             if backend == "nccl":
@@ -591,13 +591,13 @@ def main(argv=None):
 
         def walk(nn, capture):
             for k in range(args.warmup):
-                nn.set_step_inputs_packed(SR_all[k])
+                nn.set_step_inputs_packed(SR_all[k], in_place=True)
                 nn.forward_backward(rotate=True, capture=capture)
                 nn.adam_step()
             torch.cuda.synchronize()
             t = time.perf_counter()
             for k in range(args.warmup, nsteps_total):
-                nn.set_step_inputs_packed(SR_all[k])
+                nn.set_step_inputs_packed(SR_all[k], in_place=True)
                 nn.forward_backward(rotate=True, capture=capture)
                 nn.adam_step()
             torch.cuda.synchronize()
@@ -650,7 +650,7 @@ def main(argv=None):
         net.profile_start()
         for k in range(args.steps):
             kk = k % nsteps_total
-            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None)
+            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None, in_place=True)
             net.forward_backward(rotate=True, capture=False)
             net.adam_step()
         prof = net.profile_stop()

@@ -12,6 +12,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FGC_LIB", os.path.join(_HERE, "csrc", "libfgc.so"))  # FGC_LIB: developer A/B builds
 
+ABI_VERSION = 102   # FGC_ABI_VERSION of the include/fgc.h this binding was written against
 FGC_M = 9
 AG_LD = 24
 DL_LD = 12
@@ -78,6 +79,10 @@ CONV_BF16 = 8
 _SIGS = {
     "fgc_last_error": (C.c_char_p, []),
     "fgc_version": (C.c_int, []),
+    "fgc_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "fgc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+    "fgc_option_count": (C.c_int32, []),
+    "fgc_option_name": (C.c_char_p, [C.c_int32]),
     "fgc_struct_size": (C.c_size_t, [C.c_int32]),
     "fgc_crc32c": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "fgc_profile_enable": (C.c_int, [C.c_int]),
@@ -208,8 +213,50 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        # a library built from another header would take the arguments below in another order: refuse it here
+        if L.fgc_version() != ABI_VERSION:
+            raise RuntimeError("libfgc.so has ABI version %d, this binding was written for %d (include/fgc.h: FGC_ABI_VERSION)"
+                               % (L.fgc_version(), ABI_VERSION))
+        for which, mirror in ((0, ConvDesc), (1, ConvBwdIO), (2, PackExtra)):
+            if L.fgc_struct_size(which) != C.sizeof(mirror):
+                raise RuntimeError("libfgc.so: struct %d is %d bytes, the ctypes mirror %s %d" %
+                                   (which, L.fgc_struct_size(which), mirror.__name__, C.sizeof(mirror)))
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """fgc_set_option: a process-level switch of the library (include/fgc.h; names with or without 'FGC_').  The library reads
+    FGC_<NAME> environment variables once, as initial values; afterwards this call is the only way to change one."""
+    check(lib().fgc_set_option(name.encode(), int(value)), "fgc_set_option")
+
+
+def get_option(name):
+    v = C.c_int64(0)
+    check(lib().fgc_get_option(name.encode(), C.byref(v)), "fgc_get_option")
+    return v.value
+
+
+def option_names():
+    L = lib()
+    return [L.fgc_option_name(i).decode() for i in range(L.fgc_option_count())]
+
+
+class options:
+    """with _lib.options(NO_PAIRS=1, W8_DATA16_MIN_N=0): ...  - set, then restore on exit."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            set_option(k, v)
 
 
 def check(rc, what="libfgc"):

@@ -50,6 +50,40 @@ struct ProfScope {
         hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);           \
     } while (0)
 
+// ---- process-level options (fgc_set_option / fgc_get_option, include/fgc.h): which kernel form a launch takes where the
+// ---- library has more than one.  No launch path reads the environment: the table is filled once from FGC_<NAME> variables
+// ---- the first time an option is read (fgc_host.hip), after that only fgc_set_option changes it.
+#define FGC_OPTION_LIST(X)                                                                                                     \
+    X(NO_W8, 0)               /* 1: never the eight-wave conv kernels (fgc_conv_w8.hip) */                                       \
+    X(NO_W8FAST, 0)           /* 1: their generic form (per-lane degree tests) also for the fast shapes */                       \
+    X(W8_NT16, 1)             /* half tiles: 0 never, 1 forward + big-level data gradient, 2 data gradient always */              \
+    X(W8_DATA16_MIN_N, 81920) /* nodes from which the data-gradient kernel takes half tiles */                                   \
+    X(W8_DATA_SMEM_PAD, 0)    /* developer knob: extra LDS bytes per data-gradient workgroup (fewer resident workgroups) */       \
+    X(NO_PAIRS, 0)            /* 1: up-convolutions in the fine form (fgc_conv_pair.hip off) */                                  \
+    X(NO_NARROW, 0)           /* 1: the first layer through the tiled kernels */                                                 \
+    X(NO_NARROW_MMA, 0)       /* 1: the first layer's per-node products on the vector ALU */                                      \
+    X(NO_NARROW_FUSED_DS, 0)  /* 1: the first layer's s = dy lrelu'(y) / deg as a launch of its own */                            \
+    X(NO_FUSED_DS, 0)         /* 1: ds_db_kernel launches instead of the d-logits prologue (fp32) */                             \
+    X(NO_FUSED_DS_BF16, 0)    /* ... (bf16) */                                                                                   \
+    X(NO_FUSED_DS128, 0)      /* ... for the 128-wide layers only */                                                             \
+    X(NO_DS_VEC, 0)           /* 1: ds_db_kernel one element per thread */                                                       \
+    X(NO_K1M, 0)              /* 1: d-logits per-edge products on the vector ALU */                                              \
+    X(NO_K1DEEP, 0)           /* 1: d-logits kernel without the deep gather */                                                   \
+    X(K1_NT16, 1)             /* 0: d-logits kernel on 32-node tiles */                                                          \
+    X(NO_TNBF16, 0)           /* 1: bf16 weight gradients on the fp32 MFMA */                                                    \
+    X(NO_TNSTREAM, 0)         /* 1: the LDS-staged weight-gradient GEMM */                                                       \
+    X(TN_SLOTS, 64)           /* workgroup slots per XCD of the streaming weight-gradient GEMM */                                \
+    X(TNB_WGS, 256)           /* workgroups of the bf16 weight-gradient GEMM */                                                  \
+    X(NO_MLP_SPLIT, 0)        /* 1: the MLP's 1024-wide products on the fp32 MFMA (forward and backward) */                      \
+    X(NO_MLP_BWD_SPLIT, 0)    /* 1: ... the backward only */
+enum Opt {
+#define FGC_OPT_ENUM(name, def) OPT_##name,
+    FGC_OPTION_LIST(FGC_OPT_ENUM)
+#undef FGC_OPT_ENUM
+    OPT_COUNT
+};
+int64_t opt(Opt o);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(TNB_THREADS, 2) void gemm_tn_bf16_group_kernel(TnJo
 }
 
 static bool tn_bf16_ok(int P, int c0, int c1) {
-    if (getenv("FGC_NO_TNBF16") && getenv("FGC_NO_TNBF16")[0] == '1') return false;
+    if (opt(OPT_NO_TNBF16) == 1) return false;
     const int Q = c0 + c1;
     return P % 8 == 0 && c0 % 8 == 0 && c1 % 8 == 0 && Q % 32 == 0 && (c1 == 0 || c0 % 16 == 0) && c0 >= 8 && (c1 == 0 || c1 >= 8);
 }
@@ -1851,7 +1851,7 @@ static int tn_splits(int P, int Q, int rows) {
     // (measured over 32 ... 256 slots: 64 is the minimum of the step, 2.192 -> 2.179 ms; the GEMMs 1-2 us faster each, the
     // sums 17 -> 12 us per launch).  Layers with more than 32 output tiles (the 128 -> 128 layer of the coarsest level)
     // would get one slab per XCD that way and keep 128 slots (32 -> 39 us otherwise).  FGC_TN_SLOTS: developer knob.
-    static const int slots = getenv("FGC_TN_SLOTS") ? atoi(getenv("FGC_TN_SLOTS")) : 64;
+    const int slots = (int)opt(OPT_TN_SLOTS);
     int per = slots / tiles;
     if (per < 2) per = std::max(1, 2 * slots / tiles);
     return tn_balanced_splits(8 * per, cdiv(rows, 128), rows);
@@ -1864,9 +1864,9 @@ static int tn_splits(int P, int Q, int rows) {
 static int k1_nodes(const fgc_conv_desc* d) {
     // (read on every call, like the launch code reads FGC_NO_K1M / FGC_NO_K1DEEP: a process that changes a switch between
     //  two calls gets slot counts and kernels that agree)
-    const bool on = !(getenv("FGC_K1_NT16") && getenv("FGC_K1_NT16")[0] == '0');
-    const bool k1m = !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1');
-    const bool k1deep = !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+    const bool on = !(opt(OPT_K1_NT16) == 0);
+    const bool k1m = !(opt(OPT_NO_K1M) == 1);
+    const bool k1deep = !(opt(OPT_NO_K1DEEP) == 1);
     if (!on || !k1m || !k1deep) return TILE;
     const int cin = d->c0 + d->c1;
     const ConvGeom g1 = conv_geom(cin, d->cout);
@@ -1989,7 +1989,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
     w.splitW = tn_splits(FGC_M * d->cout + 24, cin, nred);
     if ((d->flags & FGC_CONV_BF16) && tn_bf16_ok(FGC_M * d->cout + 24, d->c0, d->c1)) {
         // the bf16 kernel's workgroups own up to 320 x 64 of the product: one or two per CU in all
-        static const int target = getenv("FGC_TNB_WGS") ? atoi(getenv("FGC_TNB_WGS")) : 256;   // (developer knob)
+        const int target = (int)opt(OPT_TNB_WGS);   // (developer knob)
         const int tiles = cdiv(FGC_M * d->cout + 24, TNB_PC) * cdiv(cin, 64);
         w.splitW = tn_balanced_splits(target / tiles, cdiv(nred, 256), nred);
     }
@@ -2013,7 +2013,7 @@ static TnPlan layer_tn_plan(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, c
         return tn_plan_of(bf16, true, true, io->r, PL, d->x0, nullptr, d->c0, 0, 0, nc, tn_rows_per_slab(nc, w.splitW), w.slab);
     }
     const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0);
-    const bool stream_ok = v4 && !(getenv("FGC_NO_TNSTREAM") && getenv("FGC_NO_TNSTREAM")[0] == '1');
+    const bool stream_ok = v4 && !(opt(OPT_NO_TNSTREAM) == 1);
     (void)cin;
     return tn_plan_of(bf16, v4, stream_ok, io->r, PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, tn_rows_per_slab(d->n, w.splitW),
                       w.slab);
@@ -2166,8 +2166,8 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     const bool narrow_path = io->dx0 == nullptr && w.narrow;
     const bool deep_ok = !narrow_path && g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX && conv_vec4_ok(d) &&
                          cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) && (size_t)d->n * 4 * 128 < 0xFFFFFFFFull &&
-                         !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1') &&
-                         !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+                         !(opt(OPT_NO_K1M) == 1) &&
+                         !(opt(OPT_NO_K1DEEP) == 1);
     FGC_CHECK_ARG(!bf16 || narrow_path || (deep_ok && cout % 32 == 0),
                   "fgc_conv_bwd: FGC_CONV_BF16 needs widths that are multiples of 32, 16-byte aligned tensors and degrees <= %d "
                   "(cin=%d cout=%d max_deg=%d)", KMAX, cin, cout, d->max_deg);
@@ -2176,14 +2176,14 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     // (the bf16 kernel: any width it supports - 32, 64, 128 - and both degree forms keep the LDS copy)
     const bool fuse_ds = (stages & 3) == 3 && deep_ok && w.nb_db == cdiv(d->n, k1_nodes(d)) &&
                          (bf16 ? (!narrow_path && (cout == 32 || cout == 64 || cout == 128) &&
-                                  !(getenv("FGC_NO_FUSED_DS_BF16") && getenv("FGC_NO_FUSED_DS_BF16")[0] == '1'))
+                                  !(opt(OPT_NO_FUSED_DS_BF16) == 1))
                                : ((cout == 32 || cout == 64 || (cout == 128 && k1_nodes(d) == 16 &&
-                                                                   !(getenv("FGC_NO_FUSED_DS128") && getenv("FGC_NO_FUSED_DS128")[0] == '1'))) &&
+                                                                   !(opt(OPT_NO_FUSED_DS128) == 1))) &&
                                   !(d->max_deg > 16 && cout > 32))) &&   // that form keeps no LDS copy of the tile (a_global)
                          ((uintptr_t)io->ds % 16) == 0 && ((uintptr_t)io->dy % 16) == 0 &&
                          (!d->act || ((uintptr_t)io->y % 16) == 0) &&
                          (!io->pool_dy || (((uintptr_t)io->y | (uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % 16) == 0) &&
-                         !(getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1');
+                         !(opt(OPT_NO_FUSED_DS) == 1);
     // s = dy*lrelu'(y)/deg, db partials
     if ((stages & 1) && !fuse_ds && !(narrow_path && narrow_fuses_ds(d, io))) {
         int cp2 = 1;
@@ -2193,7 +2193,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         const bool vec = cout % vw == 0 && 256 % (cout / vw) == 0 && cout <= 256 &&
                          (((uintptr_t)io->dy | (uintptr_t)yy | (uintptr_t)io->ds) % 16) == 0 &&
                          (!io->pool_dy || (((uintptr_t)io->pool_y | (uintptr_t)io->pool_dy) % 16) == 0) &&
-                         !(getenv("FGC_NO_DS_VEC") && getenv("FGC_NO_DS_VEC")[0] == '1');
+                         !(opt(OPT_NO_DS_VEC) == 1);
 #define FGC_DS_VEC(BI, BO)                                                                                                  \
     FGC_LAUNCH("ds_db_kernel", st, (ds_db_vec_kernel<BI, BO>), dim3(w.nb_db), dim3(256), 0, io->dy, yy, d->rowptr, d->n, cout,   \
                d->act, d->alpha, d->bias_mask, w.rows_per_db, io->ds, w.db_part, io->pool_dy ? io->pool_y : nullptr, io->pool_dy)
@@ -2283,7 +2283,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             FGC_CHECK_LAUNCH("fgc_conv_bwd/logits_bf16");
             rc = 0;
         } else if (g1.lpn == 8 && d->max_deg > 0 && d->max_deg <= KMAX &&
-            !(getenv("FGC_NO_K1M") && getenv("FGC_NO_K1M")[0] == '1')) {
+            !(opt(OPT_NO_K1M) == 1)) {
             static bool attr = false;
             if (!attr) {
                 hipFuncSetAttribute((const void*)conv_bwd_logits_mfma_kernel<true>,
@@ -2294,7 +2294,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             }
             const bool deep = vec4 && cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0) &&
                               (size_t)d->n * 4 * 128 < 0xFFFFFFFFull &&
-                              !(getenv("FGC_NO_K1DEEP") && getenv("FGC_NO_K1DEEP")[0] == '1');
+                              !(opt(OPT_NO_K1DEEP) == 1);
             if (deep) {
                 // (__syncthreads_or owns 256 B of static LDS: ask for exactly what this launch needs)
 #define FGC_DEEP_LAUNCH(LONG_, OKG_)                                                                                  \

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(NB) void conv_narrow_bwd_kernel(NarrowBwd p) {
 static int narrow_cin_pad(int cin) { return cin; }   // kernels are instantiated for the exact width 1..8
 
 bool narrow_supported(const fgc_conv_desc* d) {
-    if (getenv("FGC_NO_NARROW") && getenv("FGC_NO_NARROW")[0] == '1') return false;
+    if (opt(OPT_NO_NARROW) == 1) return false;
     const int cin = d->c0 + d->c1;
     return d->c1 == 0 && d->x1 == nullptr && d->shift == 0 && cin <= 8 && d->cout <= 64 && d->cout % 4 == 0 &&
            (size_t)d->n * 4 * 128 < 0xFFFFFFFFull;
@@ -674,7 +674,7 @@ int launch_narrow_fwd(const fgc_conv_desc* d, const float* ag, float* y, float* 
     NarrowFwd p{d->n,    d->rowptr,    d->col, d->x0,   ag, d->W0, d->b, d->c0, d->cout, d->bias_mask, d->act,
                 d->alpha, y, y_pool, zsave, narrow_zld(d->c0), d->tile_list, d->n_tiles, out_bf16 ? 1 : 0};
     // the network's first layer (6 -> 32) and its 3-channel sibling: per-node products on the matrix cores
-    const bool mma = !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
+    const bool mma = !(opt(OPT_NO_NARROW_MMA) == 1) && d->cout == 32 &&
                      ((uintptr_t)zsave % 16) == 0;
     if (mma && d->c0 == 6) return launch_narrow_fwd_mma_t<6, 2>(p, st);
     if (mma && d->c0 == 3) return launch_narrow_fwd_mma_t<3, 2>(p, st);
@@ -696,14 +696,14 @@ int narrow_splits(const fgc_conv_desc* d) {
 }
 
 static bool narrow_bwd_mma(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
-    return !(getenv("FGC_NO_NARROW_MMA") && getenv("FGC_NO_NARROW_MMA")[0] == '1') && d->cout == 32 &&
+    return !(opt(OPT_NO_NARROW_MMA) == 1) && d->cout == 32 &&
            ((uintptr_t)io->ds % 16) == 0 && (d->c0 == 6 || d->c0 == 3);
 }
 // stage 1 (s and the db partials) folded into the stage-2 kernel: a function of descriptor, io and environment alone, so that
 // every stage call and the reduction agree on where the db partials are and how many there are
 bool narrow_fuses_ds(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
-    if (getenv("FGC_NO_FUSED_DS") && getenv("FGC_NO_FUSED_DS")[0] == '1') return false;
-    if (getenv("FGC_NO_NARROW_FUSED_DS") && getenv("FGC_NO_NARROW_FUSED_DS")[0] == '1') return false;
+    if (opt(OPT_NO_FUSED_DS) == 1) return false;
+    if (opt(OPT_NO_NARROW_FUSED_DS) == 1) return false;
     if (!narrow_bwd_mma(d, io) || !io->dy) return false;
     const uintptr_t al = (d->flags & FGC_CONV_BF16) ? 8 : 16;
     const float* yy = io->y ? io->y : io->dy;

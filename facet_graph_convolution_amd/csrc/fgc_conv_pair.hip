@@ -27,9 +27,9 @@ constexpr int PQ_SLOTS = 16;              // pairs per chunk
 constexpr int PQ_STRIDE = PQ_SLOTS * PQ_LD + 4;   // (+4: consecutive blocks start on different banks)
 
 bool pairs_ok(const fgc_conv_desc* d) {
-    if (getenv("FGC_NO_PAIRS") && getenv("FGC_NO_PAIRS")[0] == '1') return false;
+    if (opt(OPT_NO_PAIRS) == 1) return false;
     // (developer switches that take the eight-wave fast kernels away take the pair form's data-gradient kernel with them)
-    if ((getenv("FGC_NO_W8") && getenv("FGC_NO_W8")[0] == '1') || (getenv("FGC_NO_W8FAST") && getenv("FGC_NO_W8FAST")[0] == '1'))
+    if ((opt(OPT_NO_W8) == 1) || (opt(OPT_NO_W8FAST) == 1))
         return false;
     if (!d || !d->pair_rowptr || !d->pair_col || !d->pair_mul || !d->hc) return false;
     if (d->shift != 2 || d->c1 != 0 || d->x1 != nullptr || (d->n & 3)) return false;

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
 }
 
 bool w8_supported(const CoreParams& p, int max_deg) {
-    if (getenv("FGC_NO_W8") && getenv("FGC_NO_W8")[0] == '1') return false;
+    if (opt(OPT_NO_W8) == 1) return false;
     const int nct = p.npad >> 4;
     if (!(nct == 1 || nct == 2 || nct == 4 || nct == 8)) return false;
     if (max_deg <= 0 || max_deg > KMAX) return false;
@@ -611,7 +611,7 @@ bool w8_supported(const CoreParams& p, int max_deg) {
 }
 
 static bool w8_fast(const CoreParams& p) {
-    if (getenv("FGC_NO_W8FAST") && getenv("FGC_NO_W8FAST")[0] == '1') return false;
+    if (opt(OPT_NO_W8FAST) == 1) return false;
     return p.cg % 32 == 0 && (p.c1 == 0 || p.c0 % 32 == 0) && (size_t)p.n * 4 * 128 < 0xFFFFFFFFull;
 }
 
@@ -626,10 +626,7 @@ static bool w8_fast(const CoreParams& p) {
 // workgroups).  FGC_W8_NT16 = 0: never, 2: the data kernel always (developer switch).
 template <bool DATA>
 static bool w8_half_tiles(const CoreParams& p) {
-    // (read at every launch: a test switches them between two calls of one process)
-    const char* em = getenv("FGC_W8_NT16");
-    const char* en = getenv("FGC_W8_DATA16_MIN_N");
-    const int mode = em ? atoi(em) : 1, min_n = en ? atoi(en) : 81920;
+    const int mode = (int)opt(OPT_W8_NT16), min_n = (int)opt(OPT_W8_DATA16_MIN_N);
     if ((p.npad >> 4) > 4 || mode < 1) return false;
     return !DATA || mode >= 2 || p.n >= min_n;
 }
@@ -647,7 +644,7 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
             constexpr int NT = 16;
             const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
             size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
-            if (DATA && getenv("FGC_W8_DATA_SMEM_PAD")) smem16 += (size_t)atoi(getenv("FGC_W8_DATA_SMEM_PAD"));   // (developer knob: fewer resident workgroups)
+            if (DATA) smem16 += (size_t)opt(OPT_W8_DATA_SMEM_PAD);   // (developer knob: fewer resident workgroups)
             FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT, EROW>),
                        dim3(2 * core_grid(p)), dim3(NT * 16), smem16, p, fe, de);
             FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles)");

@@ -2,6 +2,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -94,8 +96,61 @@ extern "C" int fgc_profile_collect(char* buf, int32_t buf_bytes) {
     return off;
 }
 
+// ---- process-level options ---------------------------------------------------------------------
+namespace fgc {
+struct OptEntry {
+    const char* name;
+    int64_t def;
+};
+static const OptEntry g_opt_table[OPT_COUNT] = {
+#define FGC_OPT_ROW(name, def) {#name, def},
+    FGC_OPTION_LIST(FGC_OPT_ROW)
+#undef FGC_OPT_ROW
+};
+static std::atomic<int64_t> g_opt[OPT_COUNT];
+static std::once_flag g_opt_once;
+// the ONE place the library reads its environment: FGC_<NAME>, once per process, as the initial value of option NAME
+static void opt_init() {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        char var[64];
+        snprintf(var, sizeof(var), "FGC_%s", g_opt_table[i].name);
+        const char* e = getenv(var);
+        g_opt[i].store((e && *e) ? strtoll(e, nullptr, 10) : g_opt_table[i].def, std::memory_order_relaxed);
+    }
+}
+int64_t opt(Opt o) {
+    std::call_once(g_opt_once, opt_init);
+    return g_opt[o].load(std::memory_order_relaxed);
+}
+static int opt_index(const char* name) {
+    if (!name) return -1;
+    if (!strncmp(name, "FGC_", 4)) name += 4;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_table[i].name)) return i;
+    return -1;
+}
+}  // namespace fgc
+
+extern "C" int fgc_set_option(const char* name, int64_t value) {
+    const int i = fgc::opt_index(name);
+    FGC_CHECK_ARG(i >= 0, "fgc_set_option: unknown option '%s'", name ? name : "(null)");
+    std::call_once(fgc::g_opt_once, fgc::opt_init);
+    fgc::g_opt[i].store(value, std::memory_order_relaxed);
+    return FGC_OK;
+}
+extern "C" int fgc_get_option(const char* name, int64_t* value) {
+    const int i = fgc::opt_index(name);
+    FGC_CHECK_ARG(i >= 0 && value, "fgc_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = fgc::opt((fgc::Opt)i);
+    return FGC_OK;
+}
+extern "C" int32_t fgc_option_count(void) { return fgc::OPT_COUNT; }
+extern "C" const char* fgc_option_name(int32_t index) {
+    return index >= 0 && index < fgc::OPT_COUNT ? fgc::g_opt_table[index].name : nullptr;
+}
+
 extern "C" const char* fgc_last_error(void) { return fgc::g_err; }
-extern "C" int fgc_version(void) { return 101; }
+extern "C" int fgc_version(void) { return FGC_ABI_VERSION; }
 extern "C" size_t fgc_struct_size(int32_t which) {
     return which == 0 ? sizeof(fgc_conv_desc) : (which == 1 ? sizeof(fgc_conv_bwd_io) : (which == 2 ? sizeof(fgc_pack_extra) : 0));
 }

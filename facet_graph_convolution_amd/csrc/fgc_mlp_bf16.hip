@@ -1064,10 +1064,7 @@ static int mb_gx(int n) {
 
 namespace fgc {
 // ---- the fp32 network's MLP through split operands (called by fgc_mlp_fwd in fgc_mlp.hip) ----------------
-bool mlp_split_enabled() {
-    static const bool on = !(getenv("FGC_NO_MLP_SPLIT") && getenv("FGC_NO_MLP_SPLIT")[0] == '1');
-    return on;
-}
+bool mlp_split_enabled() { return opt(OPT_NO_MLP_SPLIT) != 1; }
 size_t mlp_split_pack_bytes(int cin, int hidden) { return align_up((size_t)3 * cin * hidden * 2, 256); }
 bool mlp_fwd_split_ok(const float* x, int cin, int hidden, int cout) {
     return mlp_split_enabled() && (cin == 32 || cin == 64) && hidden % 256 == 0 && cout <= 4 && (uintptr_t)x % 16 == 0;
@@ -1098,10 +1095,7 @@ int launch_mlp_fwd_split(const float* x, int n, int cin, int hidden, int cout, c
 
 namespace fgc {
 // ---- the fp32 network's MLP backward through split operands (called by fgc_mlp_bwd in fgc_mlp.hip) -------------------
-bool mlp_bwd_split_enabled() {
-    static const bool on = mlp_split_enabled() && !(getenv("FGC_NO_MLP_BWD_SPLIT") && getenv("FGC_NO_MLP_BWD_SPLIT")[0] == '1');
-    return on;
-}
+bool mlp_bwd_split_enabled() { return mlp_split_enabled() && opt(OPT_NO_MLP_BWD_SPLIT) != 1; }
 bool mlp_bwd_split_ok(const float* x, const float* dx, int cin, int hidden, int cout) {
     return mlp_bwd_split_enabled() && cin == 32 && hidden % 256 == 0 && cout <= 3 && (uintptr_t)x % 16 == 0 &&
            (uintptr_t)dx % 16 == 0;

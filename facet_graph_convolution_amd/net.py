@@ -195,8 +195,9 @@ class FacetDenoiser:
         # the loss end of an unsharded training step (normalise, rotate the ground truth, sampled loss, both gradients) in
         # two launches instead of seven (fgc_loss_step); FGC_NO_FUSED_LOSS=1: the separate entry points
         self.fused_loss = os.environ.get("FGC_NO_FUSED_LOSS", "0") != "1"
-        # the two up-convolutions on their coarse source rows (pair form, include/fgc.h); FGC_NO_PAIRS=1: the fine form
-        self.pairs = os.environ.get("FGC_NO_PAIRS", "0") != "1"
+        # the two up-convolutions on their coarse source rows (pair form, include/fgc.h); library option NO_PAIRS = 1
+        # (fgc_set_option; initial value from FGC_NO_PAIRS): the fine form
+        self.pairs = _lib.get_option("NO_PAIRS") != 1
         # parameter slots
         k = 0
         self.slot = {}
@@ -369,7 +370,14 @@ class FacetDenoiser:
             # a layer over a 4x-upsampled input (the two up-convolutions) runs on its COARSE source rows: the pair graph
             # of its level + the table of transformed coarse rows (include/fgc.h: fgc_conv_desc.pair_rowptr)
             pg = None
-            if lay.shift == 2 and self.pairs:
+            use_pairs = lay.shift == 2 and self.pairs
+            if use_pairs and plan is not None:
+                # facet-sharded: the graph-dependent limits of the pair form on the GLOBAL pair graph - a rank-local test
+                # lets ranks disagree (one shard with a coarse row of 25 in-pairs), and the two forms exchange different
+                # tensors in the backward pass
+                from .shard import pair_form_allowed
+                use_pairs = pair_form_allowed(g.pair, W0.shape[1])
+            if use_pairs:
                 # (facet-sharded: the level's LOCAL pair graph, whose columns address [owned coarse rows | unique halo parents])
                 pg = g.pairs() if plan is None else g.pair
                 hc = torch.empty(B[lay.x0].shape[0], FGC_M * d.cout, **act)      # (bf16 storage: a bf16 table)
@@ -378,6 +386,11 @@ class FacetDenoiser:
                 d.hc = hc.data_ptr()
                 if self.L.fgc_conv_uses_pairs(C.byref(d)):
                     B["hc_" + lay.name] = hc
+                elif plan is not None and not any(_lib.get_option(k) == 1 for k in ("NO_PAIRS", "NO_W8", "NO_W8FAST")):
+                    # the job-wide test passed and the switches are on: a rank that still refuses would leave the others
+                    # waiting for messages of the pair form
+                    raise RuntimeError("layer %s: the pair form is allowed job-wide but refused on this rank (n_pairs=%d, "
+                                       "max in-degree %d)" % (lay.name, pg.n_pairs, pg.max_in_deg))
                 else:
                     d.pair_rowptr = d.pair_col = d.pair_mul = d.hc = None
                     d.n_pairs = d.max_pair_deg = d.max_pair_in_deg = 0
@@ -1058,14 +1071,16 @@ class FacetDenoiser:
         out[:, S.shape[1]:S.shape[1] + 9] = R
         return torch.from_numpy(out).to(device)
 
-    def set_step_inputs_packed(self, packed_row, sample_local_dev=None):
-        """Samples and rotation of the next step(s) = a row of pack_step_inputs.  With eager launches the step reads the row
-        where it is (the caller keeps it alive and unchanged while steps that use it are queued); once a hipGraph holds the
-        address of the network's own buffer, one device-to-device copy refreshes that."""
+    def set_step_inputs_packed(self, packed_row, sample_local_dev=None, in_place=False):
+        """Samples and rotation of the next step(s) = a row of pack_step_inputs, COPIED into the network's own buffer (one
+        device-to-device copy; the caller may reuse the row at once).  in_place=True: with eager launches the step reads the
+        row where it is - no copy launch, and the caller must keep the row alive and unchanged until every queued step that
+        uses it has run (bench.py, whose rows are a window bound once); a network whose step is held by a hipGraph copies
+        anyway, because the graph holds the address of the own buffer."""
         B = self._mesh["B"]
-        if (self._graph_fb is None and packed_row.dtype == torch.int32 and packed_row.is_contiguous()
+        if (in_place and self._graph_fb is None and packed_row.dtype == torch.int32 and packed_row.is_contiguous()
                 and packed_row.numel() == B["step_in_own"].numel() and packed_row.device == B["step_in_own"].device
-                and packed_row.data_ptr() % 4 == 0 and os.environ.get("FGC_COPY_STEP_INPUTS", "0") != "1"):
+                and packed_row.data_ptr() % 4 == 0):
             self._bind_step_inputs(B, packed_row)
         else:
             if B["step_in"] is not B["step_in_own"]:

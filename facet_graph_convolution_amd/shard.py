@@ -173,6 +173,14 @@ class ShardPlan:
             PP = build_level_plan(prow, pcol, self.ranges[l + 1], rank)
             e0 = int(prow[self.ranges[l + 1][rank][0]])
             PP.pmul = np.ascontiguousarray(pmul[e0:e0 + PP.nnz])
+            # Whether a layer runs in the pair form is a decision of the WHOLE job, not of a rank: the two forms exchange
+            # different tensors in the backward pass (pair: dt + per-pair d-logits; fine: ds rows + per-edge d-logits), so
+            # ranks that disagree send each other messages of the wrong size and content.  The quantities the library's
+            # test looks at (include/fgc.h: fgc_conv_uses_pairs) are therefore taken over the GLOBAL pair graph - every
+            # rank has it - and a rank's own values can only be smaller: all ranks get the same answer.
+            PP.global_max_in_deg = int(np.bincount(pcol, minlength=len(prow) - 1).max()) if len(pcol) else 0
+            PP.global_n_pairs = int(len(pcol))
+            PP.global_rows = int(len(prow) - 1)
             L = self.levels[l]
             assert np.array_equal(PP.halo_ids, np.unique(L.halo_ids >> 2)), "pair halo != parents of the level's halo"
             loc = L.col.astype(np.int64)
@@ -189,6 +197,17 @@ class ShardPlan:
         return np.concatenate([np.arange(P.lo, P.hi, dtype=np.int64), P.halo_ids])
 
 
+PAIR_KMAX = 24                          # edge slots of the data-gradient kernel (csrc: KMAX)
+PAIR_ID_LIMIT = (1 << 24) - (1 << 20)   # pair ids / coarse row ids go through 24-bit multiplies (fgc_conv_pair.hip: pairs_ok)
+
+
+def pair_form_allowed(PP, cout):
+    """The job-wide half of fgc_conv_uses_pairs for a facet-sharded layer: the limits that depend on the graph, evaluated on
+    the GLOBAL pair graph (ShardPlan) so that every rank decides alike.  `cout`: the layer's output width."""
+    return (PP.global_max_in_deg <= PAIR_KMAX and PP.global_n_pairs < PAIR_ID_LIMIT and PP.global_rows < (1 << 24)
+            and PP.global_rows * 9 * cout * 4 < 0xFFFFFFFF and PP.global_n_pairs * cout * 4 < 0xFFFFFFFF)
+
+
 class LocalPairGraph:
     """Device-resident local pair graph of a level (graph.PairGraph's attributes) with its halo of unique parents: which
     coarse rows go to / come from every peer, and which pairs' dt / d-logit rows cross shards in the backward pass."""
@@ -198,6 +217,7 @@ class LocalPairGraph:
         up = lambda a: torch.from_numpy(np.ascontiguousarray(pad(a))).to(device)
         self.n_pairs, self.n_halo, self.n_cross_in = PP.nnz, PP.n_halo, PP.n_cross_in
         self.max_deg, self.max_in_deg = PP.max_deg, PP.max_in_deg
+        self.global_max_in_deg, self.global_n_pairs, self.global_rows = PP.global_max_in_deg, PP.global_n_pairs, PP.global_rows
         self.prow, self.pcol = up(PP.rowptr), up(PP.col)
         self.pmul = up(PP.pmul.view(np.int32))
         self.trow, self.tcol, self.tedge = up(PP.trowptr), up(PP.tcol), up(PP.tedge)

@@ -40,8 +40,24 @@ extern "C" {
 #define FGC_ENOMEM (-12)
 #define FGC_EHIP (-5)
 
+/* ABI version of this header.  fgc_version() returns the value the LIBRARY was built with: a binding compares the two
+ * (and the struct sizes below) before its first call.  102: fgc_set_option / fgc_get_option; fgc_conv_pack(extra),
+ * flags of fgc_mlp_fwd / fgc_mlp_bwd and their _bf16 forms, larger fgc_conv_desc / fgc_conv_bwd_io (all since 101). */
+#define FGC_ABI_VERSION 102
+
 const char* fgc_last_error(void);
 int fgc_version(void);
+/* Process-level options: which kernel form a launch takes where the library has more than one (A/B switches and
+ * developer knobs; the defaults are the measured best).  Names are those of csrc/fgc_common.h's FGC_OPTION_LIST, with or
+ * without an "FGC_" prefix ("NO_PAIRS", "FGC_W8_DATA16_MIN_N", ...).  The table is filled ONCE per process, the first time
+ * any option is read, from environment variables FGC_<NAME>; after that only fgc_set_option changes it and no launch path
+ * reads the environment.  Values apply to the calls that follow; do not change an option between a call that packs or
+ * plans (fgc_conv_pack, the *_workspace_bytes queries, fgc_conv_uses_pairs) and the calls that consume its result.
+ * fgc_option_name(i), 0 <= i < fgc_option_count(), enumerates the names.  Unknown name: FGC_EINVAL. */
+int fgc_set_option(const char* name, int64_t value);
+int fgc_get_option(const char* name, int64_t* value);
+int32_t fgc_option_count(void);
+const char* fgc_option_name(int32_t index);
 /* sizeof the descriptor structs as this library was compiled (which = 0: fgc_conv_desc, 1: fgc_conv_bwd_io,
  * 2: fgc_pack_extra; else 0):
  * lets a foreign-language binding check its mirror of the layouts before the first call */
@@ -306,9 +322,23 @@ size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
  * cross-shard edges between its stages; 0 for a first layer over a narrow input (dx0 == NULL, cin <= 8), whose
  * parameter gradients are sums over the owned nodes only (stages 1, 2, 8; stage 4 is empty). */
 int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* io);
-/* 1 if fgc_conv_fwd / fgc_conv_bwd run this descriptor in the pair form: pair graph and hc given, shift == 2, one
- * source, cin 32, 64 or 128, cout 32 or 64, fp32 storage, max_pair_in_deg <= 24, no partial (tile_list / proj_rows) call.
- * fgc_conv_bwd then REQUIRES the transposed pair graph and dt in its io.  FGC_NO_PAIRS=1 in the environment: never. */
+/* 1 if fgc_conv_fwd / fgc_conv_bwd run this descriptor in the pair form.  All of:
+ *   - pair_rowptr, pair_col, pair_mul and hc given; shift == 2; ONE source (x1 == NULL, c1 == 0); n % 4 == 0;
+ *   - cin (= c0) 32, 64 or 128, cout 32 or 64; fp32 or bf16 storage (FGC_CONV_BF16: hc and dt are then bf16);
+ *   - n_pairs > 0, max_pair_deg > 0, 0 <= max_pair_in_deg <= 24 (the data-gradient kernel's edge-slot limit);
+ *   - rows of hc (src_rows, or n / 4) < 2^24 and rows * 9 * cout * 4 < 2^32; n_pairs < 2^24 - 2^20 and
+ *     n_pairs * cout * 4 < 2^32 (row ids go through 24-bit multiplies and 32-bit buffer offsets; the margin leaves room for
+ *     a facet-sharded rank's incoming cross-shard pairs behind its own in dt);
+ *   - x0 and hc 16-byte aligned;
+ *   - the whole layer in one call, OR one of the two partial forward calls a facet-sharded caller makes: "transform +
+ *     logits of the source rows [proj_row0, proj_row0 + proj_rows) only" (tile_list != NULL with n_tiles == 0) and "the rest
+ *     of the source rows, then every block" (tile_list == NULL, proj_row0 / proj_rows naming the rest).  A tile list WITH
+ *     tiles (an interior / boundary split of the blocks) selects the fine form;
+ *   - options NO_PAIRS, NO_W8 and NO_W8FAST all 0 (fgc_set_option; the last two take the pair form's data-gradient kernel
+ *     away).
+ * Anything else: 0, and the layer runs in the fine form without an error.  fgc_conv_bwd of a pair-form layer REQUIRES the
+ * transposed pair graph and dt in its io.  Ranks of a facet-sharded job must agree on the answer per layer (they exchange
+ * different tensors in the two forms): decide it on the GLOBAL pair graph (largest in-degree, pair counts), not per rank. */
 int fgc_conv_uses_pairs(const fgc_conv_desc* d);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);

@@ -17,3 +17,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def fgc_option():
+    """fgc_option(name, value): set a process-level library option (fgc_set_option) for the rest of the test; the old value
+    comes back at teardown.  (The library reads FGC_* environment variables only once, as initial values.)"""
+    from facet_graph_convolution_amd import _lib
+    saved = {}
+
+    def setter(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+
+    yield setter
+    for name, value in saved.items():
+        _lib.set_option(name, value)

@@ -25,7 +25,8 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(L, n), "libfgc.so does not export %s" % n
     assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
-    assert _lib.lib().fgc_version() >= 100
+    hdr = open(os.path.join(REPO, "include", "fgc.h")).read()
+    assert _lib.lib().fgc_version() == _lib.ABI_VERSION == int(re.search(r"#define FGC_ABI_VERSION (\d+)", hdr).group(1))
     # the ctypes mirrors of the descriptor structs have the layout the library was compiled with
     assert _lib.lib().fgc_struct_size(0) == C.sizeof(_lib.ConvDesc)
     assert _lib.lib().fgc_struct_size(1) == C.sizeof(_lib.ConvBwdIO)
@@ -60,3 +61,22 @@ def test_gpu_ops_refuse_cpu_tensors():
     p = [torch.zeros(9, 8, 6), torch.zeros(8), torch.zeros(9, 6), torch.zeros(9), torch.zeros(9, 6)]
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv_fwd(g, x, None, 0, p)
+
+
+def test_options_are_a_table_not_the_environment(monkeypatch):
+    """fgc_set_option / fgc_get_option: process-level switches; the environment is read ONCE (initial values), no launch path
+    reads it afterwards; unknown names are refused; the sources hold one getenv (the table's initialiser)."""
+    import glob
+    L = _lib.lib()
+    names = _lib.option_names()
+    assert "NO_PAIRS" in names and "W8_DATA16_MIN_N" in names and len(names) == L.fgc_option_count()
+    assert _lib.get_option("FGC_W8_DATA16_MIN_N") == _lib.get_option("W8_DATA16_MIN_N")
+    old = _lib.get_option("NO_PAIRS")
+    monkeypatch.setenv("FGC_NO_PAIRS", str(1 - old))          # too late: the table was filled at the first read
+    assert _lib.get_option("NO_PAIRS") == old
+    with _lib.options(NO_PAIRS=1 - old):
+        assert _lib.get_option("NO_PAIRS") == 1 - old
+    assert _lib.get_option("NO_PAIRS") == old
+    assert L.fgc_set_option(b"NO_SUCH_OPTION", 1) == -22 and b"NO_SUCH_OPTION" in L.fgc_last_error()
+    n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(REPO, "facet_graph_convolution_amd", "csrc", "*.h*")))
+    assert n_getenv == 1, n_getenv

@@ -50,14 +50,14 @@ def test_bf16_train_step_within_stated_tolerance_of_the_reference(golden_dir, na
 
 
 @pytest.mark.parametrize("tag,seed", [("ico3", 0), ("torus640", 1)])
-def test_bf16_fused_ds_prologue_matches_the_separate_launch(golden_dir, tag, seed, monkeypatch):
+def test_bf16_fused_ds_prologue_matches_the_separate_launch(golden_dir, tag, seed, fgc_option):
     """The bf16 d-logits kernel computes s = dy * lrelu'(y) / deg (and folds the pooling gradient in) in its prologue;
-    FGC_NO_FUSED_DS_BF16=1 runs ds_db_kernel instead.  Same operations on the same inputs: every tensor that does not
+    the library option NO_FUSED_DS_BF16 = 1 (fgc_set_option) runs ds_db_kernel instead.  Same operations on the same inputs: every tensor that does not
     pass through the bias-gradient partial sums is identical bit for bit, the bias gradients agree to fp32 rounding."""
     z = np.load(os.path.join(golden_dir, ("net_%s" % tag) + ".npz"))
     grads = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("FGC_NO_FUSED_DS_BF16", mode)
+        fgc_option("NO_FUSED_DS_BF16", int(mode))
         net, _ = _bind(golden_dir, tag, seed, "bf16")
         net.set_rotation(z["R"])
         net.set_samples(z["sample_ind"])

@@ -365,9 +365,9 @@ def test_whole_network_pack_and_reduce_match_the_per_layer_path():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_first_layer_backward_computes_s_itself(dtype, monkeypatch):
+def test_first_layer_backward_computes_s_itself(dtype, fgc_option):
     """The first layer's backward kernel computes s = (dy + pooled gradient) * lrelu'(y) / deg in its prologue and leaves one
-    bias-gradient partial per workgroup (no ds_db launch); FGC_NO_NARROW_FUSED_DS=1 keeps the separate launch.  Same
+    bias-gradient partial per workgroup (no ds_db launch); the library option NO_NARROW_FUSED_DS = 1 keeps the separate launch.  Same
     operations per element: every gradient is bit-identical except the first layer's bias gradient, whose partial sums group
     the rows differently."""
     from facet_graph_convolution_amd.net import FacetDenoiser
@@ -382,7 +382,7 @@ def test_first_layer_backward_computes_s_itself(dtype, monkeypatch):
     Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
     out = []
     for off in ("0", "1"):
-        monkeypatch.setenv("FGC_NO_NARROW_FUSED_DS", off)
+        fgc_option("NO_NARROW_FUSED_DS", int(off))
         net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
         loss = net.train_step(sample_ind=samp, R=Rm)[0].item()
         out.append((loss, [g.clone() for g in net.params.grads]))
@@ -396,10 +396,11 @@ def test_first_layer_backward_computes_s_itself(dtype, monkeypatch):
             assert torch.equal(a, b), "gradient %d" % i
 
 
-def test_packed_step_inputs_are_read_in_place_until_a_graph_is_captured():
-    """set_step_inputs_packed lets eager steps read the caller's row where it is (no copy launch); FGC_COPY_STEP_INPUTS=1 and a
-    captured hipGraph use the network's own buffer.  Same steps either way, and set_rotation afterwards must not write into
-    the caller's window."""
+def test_packed_step_inputs_are_copied_unless_the_caller_opts_into_reading_in_place():
+    """set_step_inputs_packed copies the caller's row by default (the caller may overwrite it right after the call: checked by
+    poisoning the row before the step is enqueued); in_place=True lets eager steps read the row where it is (no copy launch)
+    until a hipGraph holds the own buffer.  Same steps every way, and set_rotation afterwards must not write into the
+    caller's window."""
     from facet_graph_convolution_amd.net import FacetDenoiser
     from facet_graph_convolution_amd.dataClasses import TrainingSet
     from facet_graph_convolution_amd.meshgen import icosphere, add_noise
@@ -415,23 +416,24 @@ def test_packed_step_inputs_are_read_in_place_until_a_graph_is_captured():
     keep = window.clone()
     out = []
     for mode in ("alias", "copy", "graph"):
-        os.environ["FGC_COPY_STEP_INPUTS"] = "1" if mode == "copy" else "0"
-        try:
-            net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
-            losses = []
-            for k in range(4):
-                net.set_step_inputs_packed(window[k])
-                own = net.buffers["step_in"].data_ptr() == net.buffers["step_in_own"].data_ptr()
-                assert own == (mode == "copy" or net._graph_fb is not None)
-                net.forward_backward(rotate=True, capture=(mode == "graph"))
-                net.adam_step()
-                losses.append(net.buffers["loss"][0].item())
-            out.append((losses, net.params.theta.clone()))
-            net.set_rotation(np.eye(3))
-            torch.cuda.synchronize()
-            assert torch.equal(window, keep)
-        finally:
-            os.environ.pop("FGC_COPY_STEP_INPUTS", None)
+        net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
+        losses = []
+        for k in range(4):
+            if mode == "copy":
+                row = window[k].clone()
+                net.set_step_inputs_packed(row)
+                row.zero_()                    # the old staging-buffer pattern: refill the row right after the call
+            else:
+                net.set_step_inputs_packed(window[k], in_place=True)
+            own = net.buffers["step_in"].data_ptr() == net.buffers["step_in_own"].data_ptr()
+            assert own == (mode == "copy" or net._graph_fb is not None)
+            net.forward_backward(rotate=True, capture=(mode == "graph"))
+            net.adam_step()
+            losses.append(net.buffers["loss"][0].item())
+        out.append((losses, net.params.theta.clone()))
+        net.set_rotation(np.eye(3))
+        torch.cuda.synchronize()
+        assert torch.equal(window, keep)
     for o in out[1:]:
         assert o[0] == out[0][0] and torch.equal(o[1], out[0][1])
 

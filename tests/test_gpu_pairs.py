@@ -119,13 +119,11 @@ def test_no_pairs_switch_and_unsupported_shapes_fall_back_to_the_fine_form():
     g = FacetGraph(adj, dev)
     xc = torch.tensor(rs.normal(size=(n // 4, 64)).astype(np.float32)).to(dev)
     pd = [t.to(dev) for t in R.conv_params(64, 32, 5)]
-    os.environ["FGC_NO_PAIRS"] = "1"
-    try:
+    from facet_graph_convolution_amd import _lib
+    with _lib.options(NO_PAIRS=1):
         pairs = {}
         y0, _, _ = ops.conv_fwd(g, xc, None, 2, pd, pairs=pairs)
         assert not pairs["used"]
-    finally:
-        del os.environ["FGC_NO_PAIRS"]
     pairs = {}
     y1, _, _ = ops.conv_fwd(g, xc, None, 2, pd, pairs=pairs)
     assert pairs["used"]
@@ -172,8 +170,8 @@ def test_facet_sharded_network_uses_the_pair_form_too(golden_dir):
                 assert d.src_rows == d.n // 4 + g.pair.n_halo and g.pair.n_halo <= g.n_halo
 
 
-def test_network_in_the_pair_form_equals_the_network_in_the_fine_form(monkeypatch):
-    """The whole training step with the two up-convolutions in the pair form against the same step with FGC_NO_PAIRS=1 (the
+def test_network_in_the_pair_form_equals_the_network_in_the_fine_form(fgc_option):
+    """The whole training step with the two up-convolutions in the pair form against the same step with the library option NO_PAIRS = 1 (the
     round-3 kernels): same sums in another order - normals within 1e-6, loss 1e-6 relative, every gradient within 2e-5 of its
     tensor's largest entry - on a natively preprocessed torus (Morton order, fake rows in most blocks)."""
     from facet_graph_convolution_amd.net import FacetDenoiser
@@ -188,7 +186,7 @@ def test_network_in_the_pair_form_equals_the_network_in_the_fine_form(monkeypatc
     Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("FGC_NO_PAIRS", mode)
+        fgc_option("NO_PAIRS", int(mode))
         net = FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt)
         assert bool(net.pair_dims()) == (mode == "0")
         net.set_samples(samp)

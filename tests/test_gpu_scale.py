@@ -77,16 +77,16 @@ def test_39k_facet_train_step_matches_oracle():
     _train_step_vs_oracle(x, adjs, gt)
 
 
-def test_39k_facet_train_step_with_the_data_kernel_on_half_tiles_matches_oracle(monkeypatch):
+def test_39k_facet_train_step_with_the_data_kernel_on_half_tiles_matches_oracle(fgc_option):
     """The data-gradient kernel takes 16-node tiles from 81 920 nodes per level up (the benchmark's level 0); here it is
     forced onto them at 47 904 / 11 976 / 2 994 nodes so that the form is held against the oracle too (its da | dg rows
     live in spare floats of the edge table: conv_w8_kernel<DATA, ..., NT = 16>)."""
-    monkeypatch.setenv("FGC_W8_DATA16_MIN_N", "0")
+    fgc_option("W8_DATA16_MIN_N", 0)
     _train_step_vs_oracle(*_mesh(140, 140))
 
 
-@pytest.mark.parametrize("dtype,env", [("f32", "FGC_NO_FUSED_DS"), ("bf16", "FGC_NO_FUSED_DS_BF16")])
-def test_160k_facet_fused_ds_prologue_agrees_with_the_separate_launch(dtype, env, monkeypatch):
+@pytest.mark.parametrize("dtype,env", [("f32", "NO_FUSED_DS"), ("bf16", "NO_FUSED_DS_BF16")])
+def test_160k_facet_fused_ds_prologue_agrees_with_the_separate_launch(dtype, env, fgc_option):
     """Levels beyond 131 072 nodes (here 195k at level 0): the d-logits kernel's prologue computes s = dy * lrelu'(y) / deg
     there too since the bias-gradient partials are one per tile at every size.  Size-independent property: the two ways of
     computing s agree - every gradient that does not pass through the bias partial sums bit for bit, the biases to fp32
@@ -97,7 +97,7 @@ def test_160k_facet_fused_ds_prologue_agrees_with_the_separate_launch(dtype, env
     samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
     grads = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv(env, mode)
+        fgc_option(env, int(mode))
         net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
         net.set_samples(samp)
         net.set_rotation(np.eye(3))

@@ -227,3 +227,44 @@ def test_sim_run_serves_waits_per_rank_and_delivers_at_the_wait():
 
     with pytest.raises(AssertionError):
         shard.sim_run([FakeNet("a")], never_waits)
+
+
+def test_pair_form_is_a_job_wide_decision():
+    """A mesh on which exactly ONE shard has a coarse row with more in-pairs than the data-gradient kernel has edge slots
+    (24): a rank-local test would put that rank's up-convolution in the fine form and its peer's in the pair form, and the
+    two forms exchange different tensors in the backward pass.  shard.pair_form_allowed looks at the GLOBAL pair graph, which
+    every rank has: the same answer on every rank, and 'no' as soon as any shard would have to refuse."""
+    from facet_graph_convolution_amd.dataClasses import InferenceMesh
+    from facet_graph_convolution_amd.meshgen import torus, flip_edges, add_noise
+    from facet_graph_convolution_amd.shard import pair_form_allowed, PAIR_KMAX
+    V, F = torus(60, 50)
+    F = flip_edges(F, 9000, seed=1)
+    ds = InferenceMesh()
+    ds.addMesh(add_noise(V, F, 0.2, seed=1), F, seed=0)
+    gh = [csr_from_klist(a) for a in ds.adj_list[0]]
+    plans = [ShardPlan(gh, r, 2) for r in range(2)]
+    found = False
+    for l in (0, 1):
+        local = [p.levels[l].pair.max_in_deg for p in plans]
+        glob = [p.levels[l].pair.global_max_in_deg for p in plans]
+        assert glob[0] == glob[1] == max(local)
+        answers = [pair_form_allowed(p.levels[l].pair, 32) for p in plans]
+        assert answers[0] == answers[1] == (glob[0] <= PAIR_KMAX)
+        if min(local) <= PAIR_KMAX < max(local):
+            found = True                  # the case a per-rank decision gets wrong
+            assert answers == [False, False]
+    assert found, "the mesh no longer has a level on which the shards disagree: pick another seed"
+    # a regular mesh: allowed on every rank
+    gh, _ = _graphs_of_torus()
+    for r in range(2):
+        P = ShardPlan(gh, r, 2)
+        assert all(pair_form_allowed(P.levels[l].pair, 64) for l in (0, 1))
+
+
+def _graphs_of_torus():
+    from facet_graph_convolution_amd.dataClasses import InferenceMesh
+    from facet_graph_convolution_amd.meshgen import torus, add_noise
+    V, F = torus(40, 32)
+    ds = InferenceMesh()
+    ds.addMesh(add_noise(V, F, 0.2, seed=1), F, seed=0)
+    return [csr_from_klist(a) for a in ds.adj_list[0]], ds
