@@ -277,7 +277,7 @@ def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
     """The oracle timed on this host as BASELINE.md section 3 prescribes, on a BOUNDED sample (about 30 s of CPU work in
     all, so that the default bench run stays within minutes): the reference-shaped torch-CPU restatement
     (oracle/model_ref.py: zero-row pad -> K-padded gather -> per-edge softmax -> multiply -> reduce) on a 7 200-facet
-    torus of the same family as the headline mesh, same seeds and weights as the GPU run -
+    torus of the same family as the headline mesh (mesh seed 0 and weight seed 0 as in the GPU run) -
       * forward + backward and forward only, 2 warm-ups then the median of 5 runs, torch threads = all cores in the
         affinity mask (`value`, `forward`);
       * the same with 32 threads (1 warm-up, median of 3): on the 128-core boxes the K-padded ops stop scaling there;
@@ -293,7 +293,7 @@ def cpu_baseline(sample_faces=(60, 60), full=(250, 200)):
         print("bench: cpu_baseline: " + msg, file=sys.stderr, flush=True)
 
     def tensors(nu, nv):
-        ds, F = build_mesh(nu, nv, seed=7)
+        ds, F = build_mesh(nu, nv, seed=0)       # (the GPU run's seed: the full mesh below IS the headline mesh)
         x = torch.tensor(ds.in_list[0].astype(np.float32))
         gt = torch.tensor(ds.gt_list[0].astype(np.float32))
         adjs = [torch.tensor(a.astype(np.int32)) for a in ds.adj_list[0]]
@@ -636,26 +636,13 @@ def main(argv=None):
         exchange = net.measure_exchanges(lambda: step(), steps=max(2, min(5, args.steps)))
         dist.barrier()
 
-    roofline = None
-    families = None
-    pair_form = None
-    kernels = {}
-    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-    traffic_note = None
-    if not args.no_roofline and train and (shard or world == 1):
-        # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
-        # `steps` eager steps of the same work as the timed region.  Facet-sharded: every rank runs the steps (they hold
-        # collectives), rank 0's table is the one reported; a layer that runs as interior | exchange | boundary launches
-        # counts with the SUM of its launches
-        net.profile_start()
-        for k in range(args.steps):
-            kk = k % nsteps_total
-            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None, in_place=True)
-            net.forward_backward(rotate=True, capture=False)
-            net.adam_step()
-        prof = net.profile_stop()
-        dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net.layer_dims()}
-        pdims = net.pair_dims()
+    def analyse(net_, prof, steps_, dtype_, nu_, nv_, dump_=""):
+        """(roofline, families, pair_form, kernels) from a table of hipEvent durations (net.profile_stop) taken over steps_
+        eager training steps of net_: the dominant kernel FAMILY through its launch with the most algorithmic work."""
+        roofline, families, kernels = None, None, {}
+        peak = PEAK_BF16_MFMA_TFLOPS if dtype_ == "bf16" else PEAK_F32_MFMA_TFLOPS
+        dims = {name: (n, nnz, cin, cout) for name, n, nnz, cin, cout in net_.layer_dims()}
+        pdims = net_.pair_dims()
         pair_form = {name: {"coarse_rows": nc, "pairs": npairs, "executed_gflop": 0.0, "us_per_step": 0.0,
                             # what the SURVEY convention counts for the layer (forward + d-logits + data + weight gradient)
                             "survey_gflop": round(sum(kernel_flops(k, *dims[name]) for k in
@@ -675,40 +662,40 @@ def main(argv=None):
                     kind = "bwd_logits"
                 elif "conv_bwd_data_kernel" in kern or "conv_w8_kernel<data>" in kern:
                     kind = "bwd_data"
-                elif "gemm_tn" in kern and cnt == args.steps:
+                elif "gemm_tn" in kern and cnt == steps_:
                     kind = "bwd_weight"
             avg_us = ms / cnt * 1e3
-            if kind in ("fwd", "bwd_data") and cnt > args.steps and cnt % args.steps == 0:
-                avg_us = ms / args.steps * 1e3        # interior + boundary launches of one layer: their sum
+            if kind in ("fwd", "bwd_data") and cnt > steps_ and cnt % steps_ == 0:
+                avg_us = ms / steps_ * 1e3        # interior + boundary launches of one layer: their sum
             fl = kernel_flops(kind, *dims[layer]) if kind else None
-            by = kernel_bytes(kind, layer, *dims[layer], 2 if args.dtype == "bf16" else 4) if kind else None
+            by = kernel_bytes(kind, layer, *dims[layer], 2 if dtype_ == "bf16" else 4) if kind else None
             if layer == "reduce" and "gemm_tn" in kern:
                 # the weight-gradient GEMMs of all layers, grouped into one launch per kernel form at the end of the backward
                 # pass (FGC_CONV_DEFER_DW): the work of all of them over these launches; pair layers with what they execute
                 dw = {name: (pair_kernel_flops("gemm_tn", pdims[name][0], pdims[name][1], dims[name][2], dims[name][3])
                              if name in pdims else kernel_flops("bwd_weight", *dims[name])) for name in dims}
-                fl = sum(dw.values()) / max(cnt / args.steps, 1.0)
+                fl = sum(dw.values()) / max(cnt / steps_, 1.0)
                 for name in pdims:
                     pair_form[name]["executed_gflop"] += dw[name] / 1e9
             if layer in pdims:      # pair form: the FLOPs the launch executes, not the fine-form convention
                 fl = pair_kernel_flops(kern, pdims[layer][0], pdims[layer][1], dims[layer][2], dims[layer][3])
                 by = None
-                pair_form[layer]["executed_gflop"] += (fl or 0.0) * cnt / args.steps / 1e9
-                pair_form[layer]["us_per_step"] += ms / args.steps * 1e3
+                pair_form[layer]["executed_gflop"] += (fl or 0.0) * cnt / steps_ / 1e9
+                pair_form[layer]["us_per_step"] += ms / steps_ * 1e3
             if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern):
                 # 32 -> 1024 -> 3 per padded node; the backward recomputes the hidden layer and adds dW and dx
                 fl = 2.0 * dims["conv1"][0] * 1024 * (32 + 3) * (3 if "mlp_bwd_kernel" in kern else 1)
                 if "<" in kern:      # the bf16 backward is two launches (dx: 2 of the 3 products, w: 2 of the 3)
                     fl = fl * 2.0 / 3.0
-                by = dims["conv1"][0] * (32 * (2 if args.dtype == "bf16" else 4) + 12.0) * (2 if "bwd" in kern else 1)
+                by = dims["conv1"][0] * (32 * (2 if dtype_ == "bf16" else 4) + 12.0) * (2 if "bwd" in kern else 1)
             rows.append((ms, key, cnt, avg_us, fl))
             abytes[key] = by
         rows.sort(reverse=True)
-        if args.dump_kernels and rank == 0:
-            with open(args.dump_kernels, "w") as fh:
+        if dump_ and rank == 0:
+            with open(dump_, "w") as fh:
                 for ms, key, cnt, avg_us, fl in rows:
                     fh.write("%-60s launches/step %4.1f  avg %9.2f us  per-step %9.2f us  share %5.2f%%  %s\n" % (
-                        key, cnt / args.steps, avg_us, ms / args.steps * 1e3, 100 * ms / total_ms,
+                        key, cnt / steps_, avg_us, ms / steps_ * 1e3, 100 * ms / total_ms,
                         ("%.1f TFLOP/s" % (fl / (avg_us * 1e-6) / 1e12)) if fl else ""))
         for ms, key, cnt, avg_us, fl in rows[:12]:
             kernels[key] = {"launches": cnt, "avg_us": round(avg_us, 2), "share": round(ms / total_ms, 4),
@@ -717,7 +704,7 @@ def main(argv=None):
         # transpose); HBM bytes per launch of each family's reported launch from the PMC passes kept under profiles/
         # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md); null when no pass is recorded
         traffic_db, traffic_note = ({}, "PMC passes are taken on the single-GPU run") if shard else \
-            load_traffic_db(args.dtype, args.nu, args.nv)
+            load_traffic_db(dtype_, nu_, nv_)
         fam = {}
         for ms, key, cnt, avg_us, fl in rows:
             f = fam.setdefault(family_of(key.split("/", 1)[1]), {"ms": 0.0, "flop": 0.0, "rows": []})
@@ -737,13 +724,13 @@ def main(argv=None):
                              "algorithmic_bytes": ab,
                              "hbm_gbs": round(ab / (top[3] * 1e-6) / 1e9, 1) if ab else None,
                              "hbm_frac": round(ab / (top[3] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if ab else None,
-                             "us_per_step": round(f["ms"] / args.steps * 1e3, 1),
+                             "us_per_step": round(f["ms"] / steps_ * 1e3, 1),
                              "family_tflops": round(f["flop"] / (f["ms"] * 1e-3) / 1e12, 2),
                              "family_frac": round(f["flop"] / (f["ms"] * 1e-3) / 1e12 / peak, 4),
                              "kernel": top[1], "avg_kernel_us": round(top[3], 2), "launch_flops": top[4],
                              "achieved": round(ach, 2), "frac": round(ach / peak, 4),
                              "traffic": tr["hbm_bytes_per_launch"] if tr else None})
-        if families and args.dtype == "bf16":
+        if families and dtype_ == "bf16":
             # bf16 storage: the matrix products are 16x cheaper, the bound to quote is HBM - the
             # kernels are far from it too: they are bound by vector-ALU issue in the aggregation
             d = families[0]
@@ -754,10 +741,10 @@ def main(argv=None):
                         # what the counters say binds the bf16 kernels (the contract's `bound` is the roofline quoted)
                         "binds": load_binds("bf16"),
                         "family_share_of_step": d["share_of_step"],
-                        "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
+                        "eager_step_ms_sum_of_kernels": round(total_ms / steps_, 3),
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
                         "traffic_source": traffic_note,
-                        "launches_per_step": round(sum(c for c, _ in prof.values()) / args.steps, 1)}
+                        "launches_per_step": round(sum(c for c, _ in prof.values()) / steps_, 1)}
         elif families:
             d = families[0]
             roofline = {"bound": "mfma", "kernel": d["kernel"], "family": d["family"], "achieved": d["achieved"],
@@ -765,10 +752,127 @@ def main(argv=None):
                         "avg_kernel_us": d["avg_kernel_us"], "launch_flops": d["launch_flops"],
                         "family_share_of_step": d["share_of_step"], "family_frac": d["family_frac"],
                         "binds": load_binds("f32"),
-                        "eager_step_ms_sum_of_kernels": round(total_ms / args.steps, 3),
+                        "eager_step_ms_sum_of_kernels": round(total_ms / steps_, 3),
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
                         "traffic_source": traffic_note,
-                        "launches_per_step": round(sum(c for c, _ in prof.values()) / args.steps, 1)}
+                        "launches_per_step": round(sum(c for c, _ in prof.values()) / steps_, 1)}
+
+        return roofline, families, pair_form, kernels
+
+    roofline = None
+    families = None
+    pair_form = None
+    kernels = {}
+    if not args.no_roofline and train and (shard or world == 1):
+        # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
+        # `steps` eager steps of the same work as the timed region.  Facet-sharded: every rank runs the steps (they hold
+        # collectives), rank 0's table is the one reported; a layer that runs as interior | exchange | boundary launches
+        # counts with the SUM of its launches
+        net.profile_start()
+        for k in range(args.steps):
+            kk = k % nsteps_total
+            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None, in_place=True)
+            net.forward_backward(rotate=True, capture=False)
+            net.adam_step()
+        prof = net.profile_stop()
+        roofline, families, pair_form, kernels = analyse(net, prof, args.steps, args.dtype, args.nu, args.nv, args.dump_kernels)
+
+    fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net, elem=2 if args.dtype == "bf16" else 4)
+    n0_line = n0
+    # ---- beside the headline, after the timed region, never part of `value` --------------------------------------------
+    def side_step_bench(ds_, dtype_, nu_, nv_, label, warm=10, steps_=30):
+        """One more training-step measurement on one GPU: eager launches AND the step replayed from one hipGraph (a step
+        shorter on the GPU than its launches are on the host - config 3 - is trained from the graph), with the roofline of
+        its dominant launch.  Own network, own step inputs (seed 200)."""
+        n0_ = ds_.in_list[0].shape[1]
+        rs_ = np.random.RandomState(200)
+        tot = warm + steps_
+        SR = FacetDenoiser.pack_step_inputs([rs_.randint(n0_, size=4000) for _ in range(tot)],
+                                            [rand_rotation_matrix(randnums=rs_.uniform(size=3)) for _ in range(tot)], dev)
+        res = {"workload": label, "dtype": dtype_, "steps": steps_, "warmup": warm}
+        for mode in ("eager", "hipgraph"):
+            nn = FacetDenoiser(dev, seed=0, dtype=dtype_).bind_mesh(ds_.in_list[0], ds_.adj_list[0], gt=ds_.gt_list[0])
+            for k in range(warm):
+                nn.set_step_inputs_packed(SR[k], in_place=True)
+                nn.forward_backward(rotate=True, capture=(mode == "hipgraph"))
+                nn.adam_step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(warm, tot):
+                nn.set_step_inputs_packed(SR[k], in_place=True)
+                nn.forward_backward(rotate=True, capture=(mode == "hipgraph"))
+                nn.adam_step()
+            torch.cuda.synchronize()
+            res["ms_per_step_" + mode] = (time.perf_counter() - t) / steps_ * 1e3
+            res["loss_deg_" + mode] = nn.buffers["loss"][0].item()
+            if mode == "eager" and not args.no_roofline:
+                nn.profile_start()
+                for k in range(steps_):
+                    nn.set_step_inputs_packed(SR[k % tot], in_place=True)
+                    nn.forward_backward(rotate=True, capture=False)
+                    nn.adam_step()
+                rl, fams, _, _ = analyse(nn, nn.profile_stop(), steps_, dtype_, nu_, nv_)
+                res["roofline"] = rl
+                res["launches_per_step"] = rl["launches_per_step"] if rl else None
+                res["algorithmic_bytes_per_step"] = algorithmic_bytes_fwd_bwd(nn, elem=2 if dtype_ == "bf16" else 4)[1]
+            del nn
+        F_ = 2 * nu_ * nv_
+        best = min(res["ms_per_step_eager"], res["ms_per_step_hipgraph"])
+        res["facets"] = F_
+        res["facets_per_s"] = F_ / (best * 1e-3)
+        res["matches_eager"] = res["loss_deg_eager"] == res["loss_deg_hipgraph"]
+        if "algorithmic_bytes_per_step" in res:
+            res["hbm_roofline_frac_whole_step"] = res["algorithmic_bytes_per_step"] / (best * 1e-3) / (PEAK_HBM_GBS * 1e9)
+        return res
+
+    also = None
+    if world == 1 and train and args.config == "c2" and args.dtype == "f32" and (args.nu, args.nv) == (250, 200) \
+            and not args.multi_scale and not os.environ.get("FGC_BENCH_NO_ALSO"):
+        # BASELINE config 3 (train step, bf16 storage / fp32 accumulate) at its own 50k facets and at the headline's 100k: a
+        # few seconds, so that the driver's record carries them.  A build extension (the reference is fp32 only): accepted at
+        # the bf16 tolerances of tests/test_gpu_bf16.py / test_gpu_scale.py (normals 5e-3, loss 1e-2 relative, gradients
+        # 8e-2 of each tensor's largest entry), never the headline.
+        torch.cuda.synchronize()
+        t_also = time.perf_counter()
+        ds3, _ = build_mesh(250, 100, seed=0)
+        also = {"c3_bf16_50k": side_step_bench(ds3, "bf16", 250, 100, "c3: torus 250x100 = 50000 facets, train step, bf16 storage / "
+                                               "fp32 accumulate"),
+                "c2_bf16_100k": side_step_bench(ds, "bf16", 250, 200, "torus 250x200 = 100000 facets, train step, bf16 storage / fp32 "
+                                                "accumulate"),
+                "note": "untimed extras measured after the headline's timed region; bf16 storage is a build extension accepted at "
+                        "the tolerances of tests/test_gpu_bf16.py (normals 5e-3, loss 1e-2, gradients 8e-2 of each tensor's maximum)"}
+        del ds3
+        also["seconds"] = round(time.perf_counter() - t_also, 1)
+
+    # N > 1, facet-sharded, weak scaling (the driver's run): the OTHER reading of "facets/s on a 100k-facet mesh at N GPUs" -
+    # the one 100 000-facet mesh sharded over the N ranks (strong scaling) - measured by the same ranks behind the weak
+    # region, with the same barriers and the max over ranks
+    strong = None
+    if shard and train and args.scaling == "weak" and args.config == "c2" and not os.environ.get("FGC_BENCH_NO_STRONG"):
+        del net
+        torch.cuda.empty_cache()
+        t1 = time.perf_counter()
+        ds_s, F_s = build_mesh(args.nu, args.nv, seed=0)
+        plan_s = ShardPlan(graphs_to_host_csr(ds_s.adj_list[0]), rank, world)
+        net = FacetDenoiser(dev, **mk).bind_mesh(ds_s.in_list[0], ds_s.adj_list[0], gt=ds_s.gt_list[0], plan=plan_s, comm=DistComm())
+        n0 = ds_s.in_list[0].shape[1]
+        rs_s = np.random.RandomState(300)      # (same stream on every rank: samples are drawn over the whole mesh)
+        samp_host = [rs_s.randint(n0, size=4000) for _ in range(nsteps_total)]
+        rot_host = [rand_rotation_matrix(randnums=rs_s.uniform(size=3)) for _ in range(nsteps_total)]
+        SR_all = FacetDenoiser.pack_step_inputs(samp_host, rot_host, dev)
+        S_loc = [net.local_samples_device(sm) for sm in samp_host]
+        graph_mode[0] = False
+        args.graph = 0
+        counter[0] = 0
+        setup_s = time.perf_counter() - t1
+        for _ in range(args.warmup):
+            step()
+        dts = timed_block()
+        strong = {"scaling": "strong", "workload": "ONE torus %dx%d = %d facets facet-sharded over %d GPUs, train step, eager launches"
+                  % (args.nu, args.nv, F_s, world), "facets": F_s, "value": F_s * args.steps / dts, "unit": "facets/s",
+                  "ms_per_step": dts / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                  "loss_deg": net.buffers["loss"][0].item(), "setup_s": round(setup_s, 2),
+                  "halo_over_owned_rows_rank0": [round(net._mesh["nh"][l] / max(net._mesh["ns"][l], 1), 4) for l in range(3)]}
 
     # the world as the collective back end itself counts it: every rank contributes a one to an all-reduce
     world_check = None
@@ -777,7 +881,6 @@ def main(argv=None):
         dist.all_reduce(one)
         world_check = {"backend": "RCCL" if backend == "nccl" else backend, "ranks_in_all_reduce": int(one.item()),
                        "get_world_size": dist.get_world_size()}
-    fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net, elem=2 if args.dtype == "bf16" else 4)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -786,7 +889,7 @@ def main(argv=None):
         ms_step = dt / args.steps * 1e3
         step_bytes = fb_b if train else fwd_b
         mesh_txt = "torus %dx%d quads = %d facets%s (N0=%d padded nodes%s)" % (
-            nu, args.nv, int(F_total if shard else F), "" if shard else " per GPU", n0, " in the whole mesh" if shard else "")
+            nu, args.nv, int(F_total if shard else F), "" if shard else " per GPU", n0_line, " in the whole mesh" if shard else "")
         what_txt = ("rotate + forward + angular loss + backward + Adam" if train else
                     "multi-scale denoising forward (three heads, each normalised)")
         out = {
@@ -834,6 +937,10 @@ def main(argv=None):
             "pair_form": ({k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                            for k, v in pair_form.items()} if pair_form else None),
             "kernels": kernels,
+            # config 3 (bf16 train step, 50k facets) and the headline mesh in bf16: eager and replayed, with their rooflines
+            "also": also,
+            # N > 1, weak: the strong-scaling reading of the same metric (one 100k-facet mesh over the N ranks)
+            "strong": strong,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

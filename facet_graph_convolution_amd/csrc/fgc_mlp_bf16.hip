@@ -204,6 +204,21 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[3], const u32x4 (&b
     return acc;
 }
 
+// The same product into TWO accumulators: the five small terms into `lo`, a0 b0 into `hi`.  For a sum that runs over many
+// calls (dx over the 1024 hidden columns): added to one accumulator that already holds the large partial sum, every small
+// term is rounded to that sum's last place by the matrix pipe's adder - measured 6e-7 of max |dx| against 1.4e-7 for the
+// fp32 MFMA kernel; kept among themselves they keep their bits until the one addition at the end.
+__device__ __forceinline__ void mfma_split2(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4& hi, f32x4& lo) {
+#define FGC_M16(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), ACC_, 0, 0, 0)
+    FGC_M16(a[0], b[2], lo);
+    FGC_M16(a[2], b[0], lo);
+    FGC_M16(a[1], b[1], lo);
+    FGC_M16(a[0], b[1], lo);
+    FGC_M16(a[1], b[0], lo);
+    FGC_M16(a[0], b[0], hi);
+#undef FGC_M16
+}
+
 // forward: the bf16 kernel's structure (a workgroup = 64 rows, wave w walks the hidden column tiles w, w + 4, ...); x is
 // fp32 and is split once per workgroup, the weights come split from mlp_pack_split_kernel.
 template <int KS, int CO>
@@ -753,11 +768,11 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
         for (int o = 0; o < 3; ++o) d[o] = keep_if(dy[rc * cout + min(o, cout - 1)], row < n && o < cout);
         gA[r] = split_k3_frag(d, lq, 0);      // rows past n: zero, so their dh is zero
     }
-    f32x4 dxacc[MB_RT][MT];
+    f32x4 dxacc[MB_RT][MT], dxlo[MB_RT][MT];      // (large and small terms apart: mfma_split2)
 #pragma unroll
     for (int r = 0; r < MB_RT; ++r)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) dxacc[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MT; ++m) dxacc[r][m] = dxlo[r][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int npairs = nct >> 1;
     u32x4 stage[NI];
@@ -813,7 +828,7 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
         for (int m = 0; m < MT; ++m) {
             const u32x4 bt[3] = {w[(6 * KS + 2 + m * 3 + 0) * 64], w[(6 * KS + 2 + m * 3 + 1) * 64], w[(6 * KS + 2 + m * 3 + 2) * 64]};
 #pragma unroll
-            for (int r = 0; r < MB_RT; ++r) dxacc[r][m] = mfma_split(ad[r], bt, dxacc[r][m]);
+            for (int r = 0; r < MB_RT; ++r) mfma_split2(ad[r], bt, dxacc[r][m], dxlo[r][m]);
         }
         __builtin_amdgcn_sched_barrier(0);
         park((pp + 1) & 1);                   // (buffer (pp + 1) & 1 was last read in iteration pp - 1, before its barrier)
@@ -827,7 +842,7 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
             const int row = row0 + r * 16 + lq * 4 + t;
             if (row < n) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) dx[(size_t)row * CIN + m * 16 + lr] = dxacc[r][m][t];
+                for (int m = 0; m < MT; ++m) dx[(size_t)row * CIN + m * 16 + lr] = dxacc[r][m][t] + dxlo[r][m][t];
             }
         }
 }

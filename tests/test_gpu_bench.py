@@ -69,6 +69,12 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert e["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in e["config"]["parallelism"]
     # weak scaling: the mesh has twice the facets of the single-GPU run
     assert "%d facets" % (2 * 48 * 40 * 2) in j["config"]["workload"]
+    # ... and the same ranks report the OTHER reading of the metric beside it: the ONE single-GPU-sized mesh sharded over
+    # them (strong scaling), timed with the same barriers after the weak region
+    st = j["strong"]
+    assert st["scaling"] == "strong" and st["facets"] == 48 * 40 * 2 and st["steps"] == 2 and 0 < st["loss_deg"] < 180
+    assert abs(st["value"] - st["facets"] / (st["ms_per_step"] * 1e-3)) < 1e-6 * st["value"]
+    assert j["also"] is None
 
 
 def test_multi_scale_denoising_mode_sharded_and_single():
