@@ -74,6 +74,7 @@ CONV_DEFER_REDUCE = 2
 CONV_DEFER_DW = 16
 CONV_SAVE_Z = 4
 CONV_BF16 = 8
+CONV_R_PAD = 32
 
 
 _SIGS = {
@@ -123,6 +124,7 @@ _SIGS = {
                                C.c_void_p]),
     "fgc_conv_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "fgc_conv_bwd_needs_exchange": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO)]),
+    "fgc_conv_r_ld": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "fgc_conv_uses_pairs": (C.c_int, [C.POINTER(ConvDesc)]),
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_conv_pack": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)), C.POINTER(C.c_void_p),

@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_data_kernel(CoreParams p, D
                 *reinterpret_cast<f32x4*>(o + 4) = f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]};
                 *reinterpret_cast<f32x4*>(o + 8) = f32x4{dgsum[8], 0.f, 0.f, 0.f};
                 // da | dg behind the node's r row (scalar stores: rld need not be a multiple of 4 on this path)
-                float* rt = ep.r + (size_t)j * ep.rld + (ep.rld - 24);
+                float* rt = ep.r + (size_t)j * ep.rld + (FGC_M * p.cg);
 #pragma unroll
                 for (int m = 0; m < 12; ++m) {
                     rt[m] = m < FGC_M ? da[m] : 0.f;
@@ -1887,10 +1887,10 @@ struct TnPlan {
 static bool tn_groupable(int v) { return v <= TN_BF16_2; }
 // rows x [PL columns of A] against [c0 + c1 columns of x0 | x1]
 static TnPlan tn_plan_of(bool bf16, bool vec4, bool stream_ok, const void* A, int PL, const void* x0, const void* x1, int c0, int c1,
-                         int shift, int rows, int rps, float* slab) {
+                         int shift, int rows, int rps, float* slab, int lda = 0) {
     TnPlan pl;
     const int cin = c0 + c1, ns = cdiv(rows, rps);
-    pl.a = TnArgs{A, x0, x1, slab, PL, PL, c0, c1, shift, rows, rps, 0};
+    pl.a = TnArgs{A, x0, x1, slab, lda ? lda : PL, PL, c0, c1, shift, rows, rps, 0};   // (lda: row stride of A, >= its PL columns)
     pl.nsplits = ns;
     if (bf16 && tn_bf16_ok(PL, c0, c1)) {
         pl.variant = cin % 64 == 0 ? TN_BF16_4 : TN_BF16_2;
@@ -2010,13 +2010,14 @@ static TnPlan layer_tn_plan(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, c
     const bool bf16 = (d->flags & FGC_CONV_BF16) != 0;
     if (pairs_ok(d)) {      // K = the n / 4 coarse rows, one source
         const int nc = d->n >> 2;
-        return tn_plan_of(bf16, true, true, io->r, PL, d->x0, nullptr, d->c0, 0, 0, nc, tn_rows_per_slab(nc, w.splitW), w.slab);
+        return tn_plan_of(bf16, true, true, io->r, PL, d->x0, nullptr, d->c0, 0, 0, nc, tn_rows_per_slab(nc, w.splitW), w.slab,
+                          conv_r_ld(cout, io->flags, bf16));
     }
     const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0);
     const bool stream_ok = v4 && !(opt(OPT_NO_TNSTREAM) == 1);
     (void)cin;
     return tn_plan_of(bf16, v4, stream_ok, io->r, PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, tn_rows_per_slab(d->n, w.splitW),
-                      w.slab);
+                      w.slab, conv_r_ld(cout, io->flags, bf16));
 }
 
 // the five fixed-order sums behind a layer's parameter gradients (slabs of the weight-gradient GEMM, db and dc partials)
@@ -2041,6 +2042,10 @@ using namespace fgc;
 extern "C" size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d) {
     if (!d) return 0;
     return plan_bwd(d, nullptr).bytes;
+}
+
+extern "C" int32_t fgc_conv_r_ld(int32_t cout, int32_t padded, int32_t bf16) {
+    return conv_r_ld(cout, padded ? FGC_CONV_R_PAD : 0, bf16 != 0);
 }
 
 extern "C" int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* io) {
@@ -2135,7 +2140,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             CoreParams p;
             fill_core_params(p, g2, nc, io->tpair_rowptr, io->tpair_col, io->tpair_edge, io->dt, nullptr, cout, 0, 0, cin, io->ag,
                              0, 12, 0, w.Wpt);
-            DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout + 24, d->u, d->v, cin, d->c0, 0, 0,
+            DataEpilogue ep{io->dl, io->dag, io->r, conv_r_ld(cout, io->flags, bf16), d->u, d->v, cin, d->c0, 0, 0,
                             io->dx0, nullptr, io->accumulate0, 0};
             const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
             FGC_CHECK_ARG(w8_erow_supported(p, d->max_pair_in_deg) && (!bf16 || w8_bf16_supported(p, d->max_pair_in_deg)),
@@ -2354,7 +2359,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                          d->shift, 12, 0, w.Wpt);
         p.tile_list = io->data_tile_list;
         p.n_tiles = io->n_data_tiles;
-        DataEpilogue ep{io->dl, io->dag, io->r, FGC_M * cout + 24, d->u, d->v, cin, d->c0, d->c1, d->shift,
+        DataEpilogue ep{io->dl, io->dag, io->r, conv_r_ld(cout, io->flags, bf16), d->u, d->v, cin, d->c0, d->c1, d->shift,
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);

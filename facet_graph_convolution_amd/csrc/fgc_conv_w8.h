@@ -16,8 +16,8 @@ struct FwdEpilogue {
 struct DataEpilogue {
     const float* dl;      // [nnz, 12]
     float* dag;           // reads 0..8 (da), writes 12..20 (dg)
-    float* r;             // [n, rld]: 9*cout aggregate columns, then da (0..8) | dg (12..20) of the node
-    int rld;              // 9*cout + 24
+    float* r;             // [n, rld]: 9*cout aggregate columns, then da (0..8) | dg (12..20) of the node at column 9*cout
+    int rld;              // 9*cout + 24, or that rounded up to whole 128-byte lines (FGC_CONV_R_PAD: conv_r_ld)
     const float* u;       // [9, cin]
     const float* v;       // [9, cin]
     int cin, c0f, c1f;    // forward input split
@@ -26,6 +26,14 @@ struct DataEpilogue {
     float* dx1;
     int acc0, acc1;
 };
+
+// row stride of r in elements (fp32 floats / bf16 halves): 9*cout + 24, padded to a whole number of 128-byte lines with
+// FGC_CONV_R_PAD in fgc_conv_bwd_io.flags (rows of 1 248 bytes start at 0 / 96 / 64 / 32 bytes into a line, so three of four
+// 128-byte pieces a node's 16 lanes store straddle two lines)
+static inline int conv_r_ld(int cout, int io_flags, bool bf16) {
+    const int pl = FGC_M * cout + 24, q = bf16 ? 64 : 32;
+    return (io_flags & FGC_CONV_R_PAD) ? (pl + q - 1) / q * q : pl;
+}
 
 bool w8_supported(const CoreParams& p, int max_deg);
 // max_deg: the largest degree of the gathered graph (<= KMAX); <= 16 selects the 16-slot form of the fast kernel

@@ -16,7 +16,7 @@ namespace fgc {
 // developer knock-outs for phase timing (results are wrong with any bit set; never set in the shipped build):
 // 1 = no MFMA instructions (operand loads kept), 2 = no aggregation FMAs (gathers kept), 4 = no soft-assignment math,
 // 8 = no matrix phase at all (barriers kept), 16 = no row gathers, 32 = no output epilogue, 64 = no logit-row gathers,
-// 128 = data kernel: no r stores, 256 = data kernel: no dl gathers
+// 128 = data kernel: no r stores, 256 = data kernel: no dl gathers, 512 = no packed-weight loads (MFMAs on constants)
 #ifndef FGC_KO
 #define FGC_KO 0
 #endif
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
     const unsigned w_unit = BF ? (unsigned)(nct * 1024) : (unsigned)(p.npad * 64);
     auto loadw = [&](int pass, int u) {
         const int uu = min(u, u1 - 1);
+        if (FGC_KO & 512) return u32x4{(unsigned)uu, (unsigned)pass, 0x3f800000u, 0x3f000000u};   // (no packed-weight loads)
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, (unsigned)(pass * UPP + uu) * w_unit, 0));
     };
     f32x2 xa[16];                                      // PIPE: the rows in flight
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                     // da | dg behind the node's r row: [du; dv] = (da | dg)^T x rides in the dW0 GEMM
                     if constexpr (BF) {
                         u32x2* rt = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(de.r) + (size_t)i * de.rld +
-                                                             (de.rld - 24));
+                                                             (FGC_M * p.cg));
                         rt[0] = f4_to_bf4(f32x4{da[0], da[1], da[2], da[3]});
                         rt[1] = f4_to_bf4(f32x4{da[4], da[5], da[6], da[7]});
                         rt[2] = f4_to_bf4(f32x4{da[8], 0.f, 0.f, 0.f});
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
                         rt[4] = f4_to_bf4(f32x4{dgsum[4], dgsum[5], dgsum[6], dgsum[7]});
                         rt[5] = f4_to_bf4(f32x4{dgsum[8], 0.f, 0.f, 0.f});
                     } else {
-                    float* rt = de.r + (size_t)i * de.rld + (de.rld - 24);
+                    float* rt = de.r + (size_t)i * de.rld + (FGC_M * p.cg);
                     *reinterpret_cast<f32x4*>(rt) = f32x4{da[0], da[1], da[2], da[3]};
                     *reinterpret_cast<f32x4*>(rt + 4) = f32x4{da[4], da[5], da[6], da[7]};
                     *reinterpret_cast<f32x4*>(rt + 8) = f32x4{da[8], 0.f, 0.f, 0.f};

@@ -190,6 +190,9 @@ class FacetDenoiser:
         # Infinity Cache (1.761 -> 1.773 ms): a launch per layer.  FGC_GROUPED_DW=0 / 1 forces either.
         self.grouped_dw = self.batched and os.environ.get("FGC_GROUPED_DW", "1" if dtype == "bf16" else "0") == "1"
         self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
+        # rows of the backward aggregate r padded to whole 128-byte lines (include/fgc.h: FGC_CONV_R_PAD); FGC_NO_R_PAD=1: the
+        # packed rows of M*cout + 24 elements
+        self.r_pad = 0 if os.environ.get("FGC_NO_R_PAD", "0") == "1" else _lib.CONV_R_PAD
         # the gradient of the 4:1 max pooling behind conv1 / conv2 is a term of those layers' backward stage 1
         self.fused_pool = os.environ.get("FGC_NO_FUSED_POOL", "0") != "1"
         # the loss end of an unsharded training step (normalise, rotate the ground truth, sampled loss, both gradients) in
@@ -307,7 +310,10 @@ class FacetDenoiser:
                     B["loss" + k] = torch.zeros(2, **f)
         # shared backward scratch, sized for the largest user
         max_ds = max((ns[l.level] + nh[l.level]) * self._cout(l) for l in self.layers)
-        max_r = max(ns[l.level] * (FGC_M * self._cout(l) + 24) for l in self.layers)
+        rld = lambda l: self.L.fgc_conv_r_ld(self._cout(l), 1 if self.r_pad else 0, 1 if bf16 else 0)   # elements per row of r
+        max_r = max(ns[l.level] * rld(l) for l in self.layers)
+        if bf16:
+            max_r = (max_r + 1) // 2           # (B["r"] is allocated in fp32 words)
         max_dl = max(max(g.nnz + getattr(g, "n_cross_in", 0) for g in graphs),
                      max((g.pair.n_pairs + g.pair.n_cross_in for g in graphs[:2] if getattr(g, "pair", None) is not None), default=0))
         B["ds"] = torch.zeros(max_ds, **f)
@@ -316,7 +322,7 @@ class FacetDenoiser:
         B["r"] = torch.empty(max_r, **f)
         if self.grouped_dw and gt is not None:
             for lay in self.layers[1:]:        # (the first layer has no r: its GEMM reads the saved aggregates and ds)
-                cnt = ns[lay.level] * (FGC_M * self._cout(lay) + 24)
+                cnt = ns[lay.level] * rld(lay)
                 B["r_" + lay.name] = torch.empty((cnt + 1) // 2 if bf16 else cnt, **f)
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
         B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
@@ -815,6 +821,7 @@ class FacetDenoiser:
                                  _p(vals[s + 2]), LRELU_ALPHA, _p(B["g_d1"]), _p(grads[s]), _p(grads[s + 1]),
                                  _p(grads[s + 2]), _p(grads[s + 3]), M.get("mlp_packed", 0), _p(ws), ws.numel(), st),
                    "head0 bwd")
+        rp = self.r_pad      # (FGC_CONV_R_PAD: rows of r padded to whole 128-byte lines)
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
             self._tag("bwd:" + name)
             # (g_h2 += d pool2 and g_h1 += d pool1 are folded into stage 1 of conv2 / conv1: fgc_conv_bwd_io.pool_y / pool_dy;
@@ -827,7 +834,7 @@ class FacetDenoiser:
                            "pool1 bwd")
             d, io = M["descs"][name], M["ios"][name]
             lws = B["wsb_" + name]
-            base = (_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0
+            base = ((_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0) | rp
             if self.batched and self.grouped_dw:
                 base |= _lib.CONV_DEFER_DW
             if not self.sharded:
@@ -859,7 +866,7 @@ class FacetDenoiser:
                 yield ("xchg", [("pedges", lay.level, dtb), ("pedges", lay.level, dlb)], None)
                 io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("pair data")
-                io.flags = 0
+                io.flags = rp
                 continue
             # s = dy * lrelu'(y) / deg on owned rows and the d-logits of owned edges, in one call (the deep d-logits kernel
             # computes s in its prologue; packs the operands of stages 2 and 4 when the network did not)
@@ -880,17 +887,17 @@ class FacetDenoiser:
                 io.stages = 4 | 8
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_bnd"][0].data_ptr(), g.tiles["ttiles_bnd"][1]
                 call("data/boundary")
-                io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
+                io.data_tile_list, io.n_data_tiles, io.flags = None, 0, rp
             else:
                 yield ("xchg", items, None)
                 io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("data")
-                io.flags = 0
+                io.flags = rp
         if self.batched:
             A = M["arrays"]
             if self.grouped_dw:      # (the staged calls of a sharded step leave other flags behind)
                 for io in M["ios"].values():
-                    io.flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW
+                    io.flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW | rp
             self._tag("bwd:reduce")
             _lib.check(L.fgc_conv_bwd_reduce(A["descs"], A["ios"], A["wsb"], A["count"], st), "reduce")
         if self.sharded:

@@ -236,6 +236,9 @@ typedef struct fgc_conv_desc {
                                    * launch per kernel form (same slabs, bit-identical gradients).  The layer's r (a first layer
                                    * over a narrow input: ds and its saved aggregates), its inputs x0 / x1 and its workspace must
                                    * then stay untouched until that call: a caller that shares r between layers cannot use it */
+#define FGC_CONV_R_PAD 32         /* fgc_conv_bwd_io.flags: the rows of r are padded to whole 128-byte lines - row stride
+                                     fgc_conv_r_ld(cout, 1, bf16) elements instead of M*cout + 24 (columns unchanged: M*cout
+                                     aggregate columns, then da | dg; the pad columns are never read) */
 #define FGC_CONV_SAVE_Z 4         /* fgc_conv_desc.flags, first layer over a narrow input (cin <= 8): the forward pass
                                   * leaves the aggregates z [n, roundup4(9*cin)] in its workspace (sized for it by
                                   * fgc_conv_workspace_bytes when the flag is set) so that the backward pass, given
@@ -318,6 +321,9 @@ typedef struct fgc_conv_bwd_io {
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
+/* row stride of fgc_conv_bwd_io.r in elements (fp32: floats, FGC_CONV_BF16: 2-byte halves): M*cout + 24, or with
+ * padded != 0 (FGC_CONV_R_PAD) that rounded up to a multiple of 128 bytes */
+int32_t fgc_conv_r_ld(int32_t cout, int32_t padded, int32_t bf16);
 /* 1 if a staged (facet-sharded) backward of this layer needs the halo rows of ds and the d-logits of incoming
  * cross-shard edges between its stages; 0 for a first layer over a narrow input (dx0 == NULL, cin <= 8), whose
  * parameter gradients are sums over the owned nodes only (stages 1, 2, 8; stage 4 is empty). */
