@@ -683,7 +683,9 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
 // tile, W1 at pack time, dh = g * lrelu'(h) in registers right where it is produced (4.5 vector instructions per hidden
 // activation against the 64 multiply-adds it then feeds).  g = dy W2^T (K = 3) is ONE MFMA whose 32 k slots hold the six
 // significant term pairs of its three products (split_k3_frag); dW2 = hact^T dy and db2 stay fp32 on the vector ALU (three
-// FMAs per hidden activation - cheaper than splitting hact).  Same results as the fp32-MFMA kernel up to summation order
+// FMAs per hidden activation - cheaper than splitting hact).  The bias starts in the accumulator of the recomputed hidden
+// layer (one vector add per activation less): the small terms of the split product are then added to a sum that already
+// holds b1 - they lose what lies below the last place of max(|b1|, |x W1|), which is below the last place of the result.  Same results as the fp32-MFMA kernel up to summation order
 // (tests/test_gpu_ops.py holds both against float64 at the same bound).  FGC_NO_MLP_BWD_SPLIT=1 keeps mlp_bwd_kernel.
 // ---------------------------------------------------------------------------------------------
 // split eight fp32 values (two f32x4: fragment elements 0-3 and 4-7) into the three planes of one A / B fragment
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
         for (int c2 = 0; c2 < 2; ++c2) {
             f32x4 h[MB_RT], g[MB_RT];
 #pragma unroll
-            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < MB_RT; ++r) h[r] = bb[c2];     // (the bias rides in the accumulator: below)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 bw[3] = {w[((c2 * KS + ks) * 3 + 0) * 64], w[((c2 * KS + ks) * 3 + 1) * 64], w[((c2 * KS + ks) * 3 + 2) * 64]};
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) d[c2][r][t] = g[r][t] * lrelu01_slope(h[r][t] + bb[c2][t], alpha);
+                for (int t = 0; t < 4; ++t) d[c2][r][t] = g[r][t] * lrelu01_slope(h[r][t], alpha);
         }
         u32x4 ad[MB_RT][3];
 #pragma unroll
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
                                                   //  addresses are the same - they would be 60 registers held across the loop)
             f32x4 h[MB_RT], g[MB_RT];
 #pragma unroll
-            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{bb[c], bb[c], bb[c], bb[c]};   // (the bias rides in the accumulator)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 u32x4 bw[3];
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
                 for (int t4 = 0; t4 < 4; ++t4) {
                     // (the row's dy: re-read per column tile, four addresses per wave - cheaper than 24 registers held)
                     const f32x4 dyv = *reinterpret_cast<const f32x4*>(dyw + (r * 16 + 4 * lq + t4) * 4);
-                    const float pre = h[r][t4] + bb[c];
+                    const float pre = h[r][t4];
                     const float slope = lrelu01_slope(pre, alpha);
                     const float ha = pre * slope;            // lrelu(pre) = pre * lrelu'(pre)
                     g[r][t4] *= slope;
