@@ -681,6 +681,9 @@ def main(argv=None):
         total_ms = sum(ms for _, ms in prof.values())
         rows = []
         abytes = {}
+        row_peak = {}
+        from facet_graph_convolution_amd import _lib as _l
+        mlp_on_bf16_pipe = _l.get_option("NO_MLP_SPLIT") != 1
         for key, (cnt, ms) in prof.items():
             tag, kern = key.split("/", 1)
             phase, layer = (tag.split(":") + [""])[:2]
@@ -712,6 +715,10 @@ def main(argv=None):
                 by = None
                 pair_form[layer]["executed_gflop"] += (fl or 0.0) * cnt / steps_ / 1e9
                 pair_form[layer]["us_per_step"] += ms / steps_ * 1e3
+            if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern) and dtype_ == "f32" and mlp_on_bf16_pipe:
+                # the fp32 network's MLP on the bf16 matrix pipe (three-term operand splits: six bf16 products per fp32
+                # product): its roofline is that pipe's peak over six, in fp32-equivalent FLOPs
+                row_peak[key] = PEAK_BF16_MFMA_TFLOPS / 6.0
             if layer == "mlp" and ("mlp_fwd_kernel" in kern or "mlp_bwd_kernel" in kern):
                 # 32 -> 1024 -> 3 per padded node; the backward recomputes the hidden layer and adds dW and dx
                 fl = 2.0 * dims["conv1"][0] * 1024 * (32 + 3) * (3 if "mlp_bwd_kernel" in kern else 1)
@@ -729,7 +736,8 @@ def main(argv=None):
                         ("%.1f TFLOP/s" % (fl / (avg_us * 1e-6) / 1e12)) if fl else ""))
         for ms, key, cnt, avg_us, fl in rows[:12]:
             kernels[key] = {"launches": cnt, "avg_us": round(avg_us, 2), "share": round(ms / total_ms, 4),
-                            "tflops": round(fl / (avg_us * 1e-6) / 1e12, 2) if fl else None}
+                            "tflops": round(fl / (avg_us * 1e-6) / 1e12, 2) if fl else None,
+                            "frac_of_its_pipe": round(fl / (avg_us * 1e-6) / 1e12 / row_peak.get(key, peak), 4) if fl else None}
         # families = kernel FUNCTIONS (conv_w8 forward and data-gradient are the same kernel over the graph and its
         # transpose); HBM bytes per launch of each family's reported launch from the PMC passes kept under profiles/
         # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md); null when no pass is recorded
@@ -750,15 +758,19 @@ def main(argv=None):
             ach = top[4] / (top[3] * 1e-6) / 1e12
             tr = traffic_db.get(top[1])
             ab = abytes.get(top[1])
+            fpeak = row_peak.get(top[1], peak)
             families.append({"family": name, "share_of_step": round(f["ms"] / total_ms, 4),
                              "algorithmic_bytes": ab,
                              "hbm_gbs": round(ab / (top[3] * 1e-6) / 1e9, 1) if ab else None,
                              "hbm_frac": round(ab / (top[3] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if ab else None,
                              "us_per_step": round(f["ms"] / steps_ * 1e3, 1),
                              "family_tflops": round(f["flop"] / (f["ms"] * 1e-3) / 1e12, 2),
-                             "family_frac": round(f["flop"] / (f["ms"] * 1e-3) / 1e12 / peak, 4),
+                             "family_frac": round(f["flop"] / (f["ms"] * 1e-3) / 1e12 / fpeak, 4),
                              "kernel": top[1], "avg_kernel_us": round(top[3], 2), "launch_flops": top[4],
-                             "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+                             "achieved": round(ach, 2), "frac": round(ach / fpeak, 4), "peak": round(fpeak, 1),
+                             "pipe": ("bf16 MFMA, fp32 operands as three-term splits (6 bf16 products per fp32 product): peak = "
+                                      "%.0f / 6 fp32-equivalent TFLOP/s" % PEAK_BF16_MFMA_TFLOPS) if fpeak != peak else
+                                     ("bf16 MFMA" if dtype_ == "bf16" else "fp32 MFMA"),
                              "traffic": tr["hbm_bytes_per_launch"] if tr else None})
         if families and dtype_ == "bf16":
             # bf16 storage: the matrix products are 16x cheaper, the bound to quote is HBM - the

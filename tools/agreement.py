@@ -34,18 +34,23 @@ def main():
     lines.append("command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps %d --warmup %d --repeats 5   "
                  "(profiles/%s_rocprofv3_kernel_stats.csv, profiles/%s_bench_under_rocprofv3.json)"
                  % (prof["steps"], prof["warmup"], tag, tag))
-    # the forward conv launches of level 0: the forward instantiation (<false, ...>) on its largest grid; dconv1 and upconv1 alternate
-    fwd = [r for r in named("conv_w8_kernel<false")]
+    # the forward conv launches of level 0: the fp32 forward instantiation (<DATA = false, FAST, QS = 16, BF = false, ...>; the
+    # bf16 networks of the line's `also` object launch the BF = true one on the same grid) on its largest grid = dconv1 (upconv1
+    # runs in the pair form since round 4)
+    fwd = [r for r in rows if "conv_w8_kernel<false, true, 16, false" in r["Kernel_Name"].replace("(bool)0", "false").replace("(bool)1", "true")]
+    if not fwd:
+        fwd = [r for r in named("conv_w8_kernel<false")]
     if fwd:
         gmax = max(int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]) for r in fwd)
         big = [r for r in fwd if (int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"])) == gmax]
-        d1 = [r["_d"] for r in big[0::2]]
-        u1 = [r["_d"] for r in big[1::2]]
+        d1 = [r["_d"] for r in big]
+        u1 = []
         lines.append("  hipEvents inside bench.py (fgc_profile_*, %d steps), rocprofv3 attached      avg %.2f us"
                      % (prof["steps"], roof["avg_kernel_us"]))
         lines.append("  rocprofv3 --kernel-trace, same command, the %d dconv1 forward launches     avg %.2f us (min %.2f, max %.2f)"
                      % (len(d1), avg(d1), min(d1), max(d1)))
-        lines.append("  (upconv1 forward, same grid: avg %.2f us over %d)" % (avg(u1), len(u1)))
+        if u1:
+            lines.append("  (upconv1 forward, same grid: avg %.2f us over %d)" % (avg(u1), len(u1)))
         lines.append("  hipEvents, no profiler, default arguments (profiles/%s_bench.json)        avg %.2f us"
                      % (tag, dflt["roofline"]["avg_kernel_us"]))
     kern = prof.get("kernels", {})
