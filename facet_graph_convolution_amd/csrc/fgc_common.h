@@ -74,6 +74,7 @@ struct ProfScope {
     X(NO_TNSTREAM, 0)         /* 1: the LDS-staged weight-gradient GEMM */                                                       \
     X(TN_SLOTS, 64)           /* workgroup slots per XCD of the streaming weight-gradient GEMM */                                \
     X(TNB_WGS, 256)           /* workgroups of the bf16 weight-gradient GEMM */                                                  \
+    X(NO_PROJ_STREAM, 0)      /* 1: the assignment-logit tables by the first (blocking) form of the kernel */                    \
     X(NO_MLP_SPLIT, 0)        /* 1: the MLP's 1024-wide products on the fp32 MFMA (forward and backward) */                      \
     X(NO_MLP_BWD_SPLIT, 0)    /* 1: ... the backward only */
 enum Opt {

@@ -90,6 +90,82 @@ __global__ __launch_bounds__(256) void proj_mfma_kernel(const float* __restrict_
     }
 }
 
+// Streaming form of proj_mfma_kernel for the network's fp32 shapes (cin = 16 KB with KB = 2, 4 or 8; both sources 16-byte
+// aligned, the concat boundary on a multiple of 16 channels - the source of a 16-channel block is then wave-uniform: no
+// exec-masked load).  Same products in the same order (bit-identical table).  What differs is how memory is asked for and
+// answered: all KB fragments of a wave's NEXT 16-row tile are in flight while it multiplies the current one (the old loop
+// waited for every 16-channel block before its eight MFMAs: four to sixteen dependent round trips per tile), the [u | v]
+// fragments stay in registers, and the 16 x 24 result tile leaves through a 1.5 KB LDS tile as 96 coalesced 16-byte stores
+// (1 536 contiguous bytes) instead of eight scalar stores per lane with a 96-byte stride.
+template <int KB>
+__global__ __launch_bounds__(256) void proj_stream_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int c0, int c1,
+                                                          int rows, const float* __restrict__ u, const float* __restrict__ c,
+                                                          const float* __restrict__ v, float* __restrict__ ag) {
+    __shared__ __attribute__((aligned(16))) float otile[4][16 * FGC_AG_LD];
+    const int cin = c0 + c1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    // B fragments: element (kb, t) of lane (lr, lq) = [u | v][column lr][channel kb*16 + 4*lq + t] (columns >= 9: zero)
+    f32x4 bu[KB], bv[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int ch = kb * 16 + 4 * lq;
+        const int col = min(lr, FGC_M - 1);
+        const f32x4 uu = *reinterpret_cast<const f32x4*>(u + (size_t)col * cin + ch);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (size_t)col * cin + ch);
+        const float keep = lr < FGC_M ? 1.f : 0.f;
+        bu[kb] = uu * keep;
+        bv[kb] = vv * keep;
+    }
+    const float cbias = lr < FGC_M ? c[lr] : 0.f;
+    const int ntile = (rows + 15) >> 4;
+    const int stride = gridDim.x * 4;
+    f32x4 an[KB], ac[KB];
+    auto request = [&](int tile, f32x4 (&a)[KB]) {         // (clamped: always valid loads)
+        const int row = min(min(tile, ntile - 1) * 16 + lr, rows - 1);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int cb = kb * 16;                         // wave-uniform source
+            const float* src = cb < c0 ? x0 + (size_t)row * c0 + cb : x1 + (size_t)row * c1 + (cb - c0);
+            a[kb] = *reinterpret_cast<const f32x4*>(src + 4 * lq);
+        }
+    };
+    int tile = blockIdx.x * 4 + wave;
+    request(tile, an);
+    float* ot = otile[wave];
+    for (; tile < ntile; tile += stride) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) ac[kb] = an[kb];
+        request(tile + stride, an);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[kb][t], bu[kb][t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[kb][t], bv[kb][t], acc1, 0, 0, 0);
+            }
+        // C layout: column = lr (logit index), row = lq*4 + reg  ->  the tile's 16 table rows in LDS
+        if (lr < 12) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ot[(lq * 4 + t) * FGC_AG_LD + lr] = lr < FGC_M ? acc0[t] + cbias : 0.f;
+                ot[(lq * 4 + t) * FGC_AG_LD + 12 + lr] = lr < FGC_M ? acc1[t] : 0.f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 16 rows x 96 bytes = 96 pieces of 16 bytes, contiguous in the table
+        const int nvalid = (min(rows - tile * 16, 16) * FGC_AG_LD) >> 2;
+        f32x4* out = reinterpret_cast<f32x4*>(ag + (size_t)tile * 16 * FGC_AG_LD);
+        const f32x4* in = reinterpret_cast<const f32x4*>(ot);
+        if (lane < nvalid) out[lane] = in[lane];
+        if (lane + 64 < nvalid) out[lane + 64] = in[lane + 64];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // the table of a narrow first layer (cin <= 8): a row per thread on the vector ALU, the arithmetic of narrow_logits_row
 __global__ __launch_bounds__(256) void proj_narrow_kernel(const float* __restrict__ x, int rows, int cin, const float* __restrict__ u,
                                                           const float* __restrict__ c, const float* __restrict__ v,
@@ -322,7 +398,18 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
         else if (xbf)
             FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true, true>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
                        prows, d->u, d->c, d->v, pag);
-        else if (conv_vec4_ok(d))
+        else if (conv_vec4_ok(d) && (cin == 32 || cin == 64 || cin == 128) && d->c0 % 16 == 0 && (uintptr_t)pag % 16 == 0 &&
+                 ((uintptr_t)d->u | (uintptr_t)d->v) % 16 == 0 && opt(OPT_NO_PROJ_STREAM) != 1) {
+            if (cin == 32)
+                FGC_LAUNCH("proj_mfma_kernel", st, (proj_stream_kernel<2>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1, prows, d->u,
+                           d->c, d->v, pag);
+            else if (cin == 64)
+                FGC_LAUNCH("proj_mfma_kernel", st, (proj_stream_kernel<4>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1, prows, d->u,
+                           d->c, d->v, pag);
+            else
+                FGC_LAUNCH("proj_mfma_kernel", st, (proj_stream_kernel<8>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1, prows, d->u,
+                           d->c, d->v, pag);
+        } else if (conv_vec4_ok(d))
             FGC_LAUNCH("proj_mfma_kernel", st, (proj_mfma_kernel<true>), dim3(pg), dim3(256), 0, px0, px1, d->c0, d->c1,
                        prows, d->u, d->c, d->v, pag);
         else

@@ -250,20 +250,34 @@ __device__ __forceinline__ void rot3(const float (&r)[9], float a, float b, floa
 // housekeeping launch): the same bits.
 __device__ __forceinline__ void narrow_logits_row(const float* xr, int cin, const float* __restrict__ u, const float* __restrict__ c,
                                                   const float* __restrict__ v, float* __restrict__ agr) {
-#pragma unroll 1
+    // the 24 floats of the row in registers (fully unrolled: k < cin <= 8 by predicate, the same FMA chain per logit as
+    // ever), then six 16-byte stores: a row per thread with 24 scalar stores made every store instruction of a wave touch
+    // 64 different rows, four bytes each
+    float o[FGC_AG_LD];
+#pragma unroll
     for (int m = 0; m < FGC_M; ++m) {
         float a = c[m], g = 0.f;
-        for (int k = 0; k < cin; ++k) {
-            a = fmaf(u[m * cin + k], xr[k], a);
-            g = fmaf(v[m * cin + k], xr[k], g);
-        }
-        agr[m] = a;
-        agr[12 + m] = g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < cin) {
+                a = fmaf(u[m * cin + k], xr[k], a);
+                g = fmaf(v[m * cin + k], xr[k], g);
+            }
+        o[m] = a;
+        o[12 + m] = g;
     }
 #pragma unroll
     for (int m = FGC_M; m < 12; ++m) {
-        agr[m] = 0.f;
-        agr[12 + m] = 0.f;
+        o[m] = 0.f;
+        o[12 + m] = 0.f;
+    }
+    if ((reinterpret_cast<uintptr_t>(agr) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < FGC_AG_LD / 4; ++q)
+            reinterpret_cast<f32x4*>(agr)[q] = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+    } else {
+#pragma unroll
+        for (int q = 0; q < FGC_AG_LD; ++q) agr[q] = o[q];
     }
 }
 __device__ __forceinline__ void narrow_logits_body(const float* __restrict__ x, int rows, int cin, const float* __restrict__ u,
@@ -271,7 +285,8 @@ __device__ __forceinline__ void narrow_logits_body(const float* __restrict__ x, 
                                                    int bid, int nb) {
     for (int r = bid * blockDim.x + threadIdx.x; r < rows; r += nb * blockDim.x) {
         float xr[8];
-        for (int k = 0; k < cin; ++k) xr[k] = x[(size_t)r * cin + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xr[k] = k < cin ? x[(size_t)r * cin + k] : 0.f;
         narrow_logits_row(xr, cin, u, c, v, ag + (size_t)r * FGC_AG_LD);
     }
 }
@@ -285,14 +300,17 @@ __device__ __forceinline__ void rotate_logits_body(const float* __restrict__ x, 
     for (int i = 0; i < 9; ++i) r9[i] = Rd[i];
     const int cin = 3 * vecs;
     for (int r = bid * blockDim.x + threadIdx.x; r < rows; r += nb * blockDim.x) {
-        float xr[8];
-        for (int q = 0; q < vecs; ++q) {
-            const size_t i = (size_t)r * vecs + q;
-            const float a = x[3 * i], b = x[3 * i + 1], cc = x[3 * i + 2];
-            rot3(r9, a, b, cc, xr[3 * q], xr[3 * q + 1], xr[3 * q + 2]);
-            y[3 * i] = xr[3 * q];
-            y[3 * i + 1] = xr[3 * q + 1];
-            y[3 * i + 2] = xr[3 * q + 2];
+        float xr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {          // (vecs <= 2: checked by the host; static indices keep xr in registers)
+            if (q < vecs) {
+                const size_t i = (size_t)r * vecs + q;
+                const float a = x[3 * i], b = x[3 * i + 1], cc = x[3 * i + 2];
+                rot3(r9, a, b, cc, xr[3 * q], xr[3 * q + 1], xr[3 * q + 2]);
+                y[3 * i] = xr[3 * q];
+                y[3 * i + 1] = xr[3 * q + 1];
+                y[3 * i + 2] = xr[3 * q + 2];
+            }
         }
         narrow_logits_row(xr, cin, u, c, v, ag + (size_t)r * FGC_AG_LD);
     }
