@@ -858,7 +858,7 @@ __global__ __launch_bounds__(MBB_THREADS, 3) void mlp_bwd_dx_split_kernel(
 //   LDS: 2 x { x [32 rows][plane 0 | plane 1 | plane 2 | pad] bf16, dy [32][4] fp32, dy operand [32][3 lane groups] } +
 //   per wave its W1 fragments [c][ks][plane][lane] (they do not change over the walk; as registers they were 48 of 256).
 #define MBS_TILE_LDS(CIN_) (MB_T * MBS_XTS(CIN_) + MB_T * 16 + MB_T * 48)
-#define MBS_WG_LDS(CIN_) (2 * MBS_TILE_LDS(CIN_) + MBB_WAVES * MBW_CT * ((CIN_) / 32) * 3 * 1024)
+#define MBS_WG_LDS(CIN_) (2 * MBS_TILE_LDS(CIN_))
 // all nine dwords of the dy operand of one row (split_k3_frag, side 0): lane group lq takes dwords 4 lq .. 4 lq + 3
 __device__ __forceinline__ void split_k3_row(const float (&v)[3], unsigned (&w)[9]) {
     unsigned short p[3][3];
@@ -886,14 +886,16 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
     constexpr int XPL = CIN * 2;              // byte offset of a plane within a row
     constexpr int TILE = MBS_TILE_LDS(CIN);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    u32x4* bwl = reinterpret_cast<u32x4*>(smem_raw + 2 * TILE) + wave * (MBW_CT * KS * 3 * 64);
     const int hc0 = blockIdx.y * (MBB_WAVES * MBW_HCW) + wave * MBW_HCW;
     const int nct = hidden >> 4;
     const int ntiles = (n + MB_T - 1) / MB_T;
     const int walker = blockIdx.x, nwalkers = gridDim.x;
     const size_t wplane = (size_t)KS * nct * 64;
 
-    u32x4 bg[MBW_CT];
+    // the wave's weights do not change over its walk: W1 fragments (three planes: 48 registers - affordable since the file is
+    // compiled without the SLP vectoriser, which had the kernel at 226 registers; in LDS they were 12 reads per tile), b1 and
+    // the W2 operand
+    u32x4 bw[MBW_CT][KS][3], bg[MBW_CT];
     float bb[MBW_CT];
 #pragma unroll
     for (int c = 0; c < MBW_CT; ++c) {
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bwl[((c * KS + ks) * 3 + p) * 64 + lane] = Wp16[p * wplane + ((size_t)ks * nct + ct) * 64 + lane];
+            for (int p = 0; p < 3; ++p) bw[c][ks][p] = Wp16[p * wplane + ((size_t)ks * nct + ct) * 64 + lane];
         bb[c] = b1[ct * 16 + lr];
         bg[c] = W2s[ct * 64 + lane];
     }
@@ -965,6 +967,14 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
             const unsigned keep = lq < 3 ? ~0u : 0u;
             gA[r] = u32x4{f[0] & keep, f[1] & keep, f[2] & keep, f[3] & keep};
         }
+        u32x4 ax[MB_RT][KS][3];       // x fragments: row r*16 + lr, channels ks*32 + 8*lq .. + 7, plane by plane (once per tile)
+#pragma unroll
+        for (int r = 0; r < MB_RT; ++r)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    ax[r][ks][p] = *reinterpret_cast<const u32x4*>(t + (r * 16 + lr) * XTS + p * XPL + (ks * 32 + 8 * lq) * 2);
         if (blockIdx.y == 0 && wave == 0 && lr == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -982,19 +992,9 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r) h[r] = f32x4{bb[c], bb[c], bb[c], bb[c]};   // (the bias rides in the accumulator)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                u32x4 bw[3];
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bw[p] = bwl[((c * KS + ks) * 3 + p) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < MB_RT; ++r) {
-                    u32x4 ax[3];                  // x fragments: row r*16 + lr, channels ks*32 + 8*lq .. + 7, plane by plane
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        ax[p] = *reinterpret_cast<const u32x4*>(t + (r * 16 + lr) * XTS + p * XPL + (ks * 32 + 8 * lq) * 2);
-                    h[r] = mfma_split(ax, bw, h[r]);
-                }
-            }
+                for (int r = 0; r < MB_RT; ++r) h[r] = mfma_split(ax[r][ks], bw[c][ks], h[r]);
 #pragma unroll
             for (int r = 0; r < MB_RT; ++r)
                 g[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gA[r]), __builtin_bit_cast(bf16x8, bg[c]),
