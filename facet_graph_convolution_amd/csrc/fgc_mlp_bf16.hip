@@ -975,6 +975,11 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     ax[r][ks][p] = *reinterpret_cast<const u32x4*>(t + (r * 16 + lr) * XTS + p * XPL + (ks * 32 + 8 * lq) * 2);
+        u32x4 af[MT][3];              // x^T fragments of the channel tiles (transposed reads, once per tile)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[m][p] = mbs_xT_frag(t + p * XPL, XTS, m * 16, lq, lr);
         if (blockIdx.y == 0 && wave == 0 && lr == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1020,10 +1025,7 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_split_kernel(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                u32x4 af[3];                      // x^T fragments of channel tile m (re-read per column tile: registers)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) af[p] = mbs_xT_frag(t + p * XPL, XTS, m * 16, lq, lr);
-                dW1acc[c][m] = mfma_split(af, bf, dW1acc[c][m]);
+                dW1acc[c][m] = mfma_split(af[m], bf, dW1acc[c][m]);
                 // (volatile statements keep their order: this column tile's last product comes before the next one's first
                 //  LDS read; left free, the compiler runs two column tiles' phases side by side and spills the accumulators)
                 asm volatile("" : "+v"(dW1acc[c][m])::"memory");
