@@ -283,7 +283,9 @@ __global__ __launch_bounds__(MB_THREADS, 2) void mlp_fwd_split_kernel(const floa
         fetch_weights(ct + 4);
         f32x4 h[MB_FWD_RT];
 #pragma unroll
-        for (int r = 0; r < MB_FWD_RT; ++r) h[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the bias rides in the accumulator: the small terms of the split product then lose what lies below the last place of
+        //  max(|b1|, |x W1|) - below the last place of the result; one vector add per hidden activation less)
+        for (int r = 0; r < MB_FWD_RT; ++r) h[r] = f32x4{bb, bb, bb, bb};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(MB_THREADS, 2) void mlp_fwd_split_kernel(const floa
         for (int r = 0; r < MB_FWD_RT; ++r)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float v = h[r][t] + bb;      // (the bias is added last: riding in the accumulator it would swallow the small terms)
+                float v = h[r][t];
                 v = lrelu01(v, alpha);
 #pragma unroll
                 for (int o = 0; o < CO; ++o) yp[r][t][o] = fmaf(v, w2[o], yp[r][t][o]);
