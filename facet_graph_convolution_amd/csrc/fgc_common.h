@@ -76,7 +76,8 @@ struct ProfScope {
     X(TNB_WGS, 256)           /* workgroups of the bf16 weight-gradient GEMM */                                                  \
     X(NO_PROJ_STREAM, 0)      /* 1: the assignment-logit tables by the first (blocking) form of the kernel */                    \
     X(NO_MLP_SPLIT, 0)        /* 1: the MLP's 1024-wide products on the fp32 MFMA (forward and backward) */                      \
-    X(NO_MLP_BWD_SPLIT, 0)    /* 1: ... the backward only */
+    X(NO_MLP_BWD_SPLIT, 0)    /* 1: ... the backward only */                                                                     \
+    X(NO_K1_SPLIT, 0)         /* 1: the dz GEMM of the fp32 d-logits kernel (half tiles, 32 outputs) on the fp32 MFMA */
 enum Opt {
 #define FGC_OPT_ENUM(name, def) OPT_##name,
     FGC_OPTION_LIST(FGC_OPT_ENUM)

@@ -22,6 +22,7 @@
 #include "fgc_conv_pair.h"
 #include "fgc_reduce.h"
 #include "fgc_pack.h"
+#include "fgc_split.h"
 
 namespace fgc {
 
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void pack_many_kernel(PackJobs J) {
         else if (j.kind == 12) mlp_pack_w1dx_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
         else if (j.kind == 15) mlp_pack_w1dx_split_body(j.W0, (unsigned short*)j.dst, j.cin, j.ncols, bid, nb);
         else if (j.kind == 16) mlp_pack_w2_split_body(j.W0, (u32x4*)j.dst, j.ncols, j.cout, bid);
+        else if (j.kind == 17) pack_logit_weight_split_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);
         else mlp_pack_w2_bf16_body(j.W0, (u32x4*)j.dst, j.ncols, j.cout, bid);
     } else if (j.kind == 7) pack_plain_bf16_body(j.W0, (unsigned short*)j.dst, j.kdim, bid, nb);
     else if (j.kind == 6) pack_logit_weight_bf16_body(j.W0, (unsigned short*)j.dst, j.cin, j.cout, j.passes, bid, nb);
@@ -615,9 +617,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 // NT_ nodes per workgroup, NPW_ nodes per wave.  (32, 8): the form described above, four waves, 68 KB of LDS, 188 registers:
 // two workgroups = two waves per SIMD per CU.  (16, 4), regular graphs only: four waves on HALF a tile - half the per-wave
 // state (gathers of 4 nodes instead of 8), 34 KB of LDS: four workgroups per CU if the registers stay under 128.
-template <bool LONG, int OKG, int NT_ = 32, int NPW_ = 8>
+// SPLIT (half tiles, OKG = 2): the dz GEMM on the bf16 matrix pipe with three-term operand splits (fgc_split.h) - the s
+// tile is the A operand of 18 column tiles per pass, so splitting it costs 44 vector instructions per wave and k-step and
+// replaces 8 v_mfma_f32_16x16x4_f32 (32 cycles each) per column tile by 6 v_mfma_f32_16x16x32_bf16 (16 cycles each); the
+// weights come as three planes of B fragments (pack_logit_weight_split_body).  Same sums as the fp32 form up to the order
+// of the additions.  The per-edge products stay on the fp32 MFMA: both of their operands are used once.  Measured (round 5,
+// same-box alternating runs): dconv1 at 100k facets 122.9 -> 116.6 us.  The 64-wide layers were tried and gained nothing
+// (77.5 -> 76.0 / 77.6 us): a half tile re-reads the whole packed operand from L2 - 446 MB per level-0 launch as fp32, half
+// as much again as three bf16 planes - and that stream, not the matrix pipe, is what those launches wait for.
+template <bool LONG, int OKG, int NT_ = 32, int NPW_ = 8, bool SPLIT = false>
 __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
     static_assert((NT_ == 32 && NPW_ == 8) || (NT_ == 16 && NPW_ == 4 && !LONG), "tile shapes");
+    static_assert(!SPLIT || (NT_ == 16 && OKG == 2), "split dz GEMM: half tiles of the 32-wide layers");
     // (shadow the 32-node constants of the file)
     constexpr int TILE = NT_, NPW = NPW_, NWV = NT_ / NPW_, NTHREADS = NWV * 64, RT = NT_ / 16, LPN = NTHREADS / NT_;
     static_assert(NWV == 4, "four waves either way: the column-tile split and the dc sums below assume it");
@@ -797,6 +808,29 @@ __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
                     for (int c = 0; c < K1_CTW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT) {
+                    // one chunk per column tile (K = cout = 32 is one k-step); the three planes of chunk c + 2 are requested
+                    // before the six MFMAs of chunk c (a ring of three 12-register slots)
+                    u32x4 wring[3][3], a3[3];
+                    auto loadq = [&](int c, u32x4 (&b)[3]) {
+                        const int ct = min(wave + c * 4, nct - 1);
+                        const unsigned soff = (unsigned)(((pass * 18 + ct) * 3) * 1024);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            b[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wq_rs, (unsigned)(lane * 16 + pl * 1024), soff, 0));
+                    };
+                    loadq(0, wring[0]);
+                    loadq(1, wring[1]);
+                    {
+                        const float* ar = dst + lr * ostride + 8 * lq;
+                        split3_frag(*reinterpret_cast<const f32x4*>(ar), *reinterpret_cast<const f32x4*>(ar + 4), a3);
+                    }
+#pragma unroll
+                    for (int c = 0; c < K1_CTW; ++c) {
+                        if (c + 2 < K1_CTW) loadq(c + 2, wring[(c + 2) % 3]);
+                        acc[0][c] = mfma_split(a3, wring[c % 3], acc[0][c]);
+                    }
+                } else {
                 // (buffer loads: the lane's part of the offset is a loop invariant, the k-group's part scalar - the indexed form
                 // spent a 64-bit multiply-add chain per fragment on the vector ALU, which the fp32 MFMA shares)
                 auto loadw = [&](int g, f32x4 (&b)[K1_CTW]) {
@@ -852,6 +886,7 @@ __global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd
                         loadw(g, w0);
                         mmw(g, w0);
                     }
+                }
                 }
                 if (!LONG) gather(H, bxb);
                 if (pass > 0 || sweep > 0) __syncthreads();  // the previous readers of ztile are done
@@ -1876,6 +1911,20 @@ static int k1_nodes(const fgc_conv_desc* d) {
     return deep ? 16 : TILE;
 }
 
+// The dz GEMM of the half-tile d-logits kernel on split bf16 operands (conv_bwd_logits_deep_kernel<.., SPLIT>): the fp32
+// network's 32-wide layers on regular graphs.  A function of the descriptor and the options alone: it decides the
+// layout (and size) of the packed operand Wq, which fgc_conv_pack may write long before the launch.  NO_K1_SPLIT=1: fp32 MFMA.
+static bool k1_split(const fgc_conv_desc* d) {
+    if (opt(OPT_NO_K1_SPLIT) == 1 || (d->flags & FGC_CONV_BF16)) return false;
+    return k1_nodes(d) == 16 && d->cout == 32 && !pairs_ok(d);
+}
+static size_t k1_wq_floats(const fgc_conv_desc* d) {
+    const ConvGeom g1 = conv_geom(d->c0 + d->c1, d->cout);
+    const int opad = (d->cout + 15) / 16 * 16;
+    const size_t f32 = (size_t)g1.passes * opad * g1.kpass;
+    return k1_split(d) ? std::max(f32, (size_t)g1.passes * (d->cout >> 5) * 18 * 3 * 256) : f32;
+}
+
 // ---- which kernel computes a layer's weight gradient, and with what arguments: shared by the per-layer launch (stage 8) and
 // ---- the grouped launch of fgc_conv_bwd_reduce (FGC_CONV_DEFER_DW)
 enum TnVariant { TN_STREAM2 = 0, TN_STREAM4, TN_STREAM2_BF, TN_STREAM4_BF, TN_BF16_4, TN_BF16_2, TN_PLAIN_V4, TN_PLAIN, TN_NVARIANTS };
@@ -1972,7 +2021,7 @@ static BwdWorkspace plan_bwd(const fgc_conv_desc* d, char* base) {
         off += align_up(nfloats * 4, 256);
         return ptr;
     };
-    w.Wq = take((size_t)g1.passes * opad * g1.kpass);
+    w.Wq = take(k1_wq_floats(d));
     w.Wpt = take((size_t)g2.passes * g2.kpass * g2.npad);
     // pair form (fgc_conv_pair.hip): one db / dc partial per workgroup of its d-logits kernel (k1n fine nodes each), and the
     // weight-gradient GEMM reduces over the n / 4 coarse rows
@@ -2237,6 +2286,13 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         FGC_CHECK_LAUNCH("fgc_conv_bwd/pack");
     } else if ((stages & 6) && !(io->flags & FGC_CONV_PACKED)) {
         const size_t tot = (size_t)g1.passes * opad * g1.kpass;
+        if (k1_split(d)) {
+            PackJobs J;
+            J.njobs = 1;
+            J.job[0] = PackJob{d->W0, w.Wq, 17, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0};
+            J.nblocks = cdiv((int)((size_t)g1.passes * (cout >> 5) * 18 * 3 * 512), 1024);
+            FGC_LAUNCH("pack_many_kernel", st, pack_many_kernel, dim3(J.nblocks), dim3(256), 0, J);
+        } else
         FGC_LAUNCH("pack_logit_weight_kernel", st, pack_logit_weight_kernel, dim3(cdiv((int)tot, 1024)), dim3(256), 0, d->W0, w.Wq, cin, cout,
                            opad, g1.kc, g1.kpass, g1.passes);
         const size_t tot2 = (size_t)g2.passes * g2.kpass * g2.npad;
@@ -2323,11 +2379,24 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                    dim3(cdiv(d->n, NT)), dim3(256), smem16, p, lp);                                                  \
     } while (0)
                     const bool al = ((uintptr_t)io->ds % 16) == 0;
+#define FGC_DEEP_HALF_SPLIT(OKG_)                                                                                    \
+    do {                                                                                                             \
+        hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<false, OKG_, NT, 4, true>,                      \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);                                \
+        FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, (conv_bwd_logits_deep_kernel<false, OKG_, NT, 4, true>),       \
+                   dim3(cdiv(d->n, NT)), dim3(256), smem16, p, lp);                                                  \
+    } while (0)
+                    if (k1_split(d)) {
+                        // (the packed operand is in the split layout whatever the pointers: no other kernel can take it)
+                        FGC_CHECK_ARG(al, "fgc_conv_bwd: ds must be 16-byte aligned (cout=%d)", cout);
+                        FGC_DEEP_HALF_SPLIT(2);
+                    } else
                     if (cout == 32 && al) FGC_DEEP_HALF(2);
                     else if (cout == 64 && al) FGC_DEEP_HALF(4);
                     else if (cout == 128 && al && fuse_ds) FGC_DEEP_HALF(8);   // (only for its prologue: s and db in this launch)
                     else FGC_DEEP_HALF(0);
 #undef FGC_DEEP_HALF
+#undef FGC_DEEP_HALF_SPLIT
                 } else {
                 // 24 edge slots + the ds tile of a 64- or 128-wide layer do not fit twice into a CU's LDS
                 if (lng && cout > 32 && cout % 16 == 0 && ((uintptr_t)io->ds % 16) == 0) {
@@ -2450,7 +2519,10 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
                 add(PackJob{d->W0, w.Wpt, 5, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},
                     (size_t)g2.passes * 9 * (g2.npad >> 4) * 512);
             } else {
-            if (!pairs)
+            if (!pairs && k1_split(d))
+            add(PackJob{d->W0, w.Wq, 17, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
+                (size_t)g1.passes * (cout >> 5) * 18 * 3 * 512);
+            else if (!pairs)
             add(PackJob{d->W0, w.Wq, 2, cin, cout, 0, 0, 0, g1.kc, g1.kpass, g1.passes, opad, 0},
                 (size_t)g1.passes * opad * g1.kpass);
             add(PackJob{d->W0, w.Wpt, 1, cin, cout, cout, cin, g2.npad, g2.kc, g2.kpass, g2.passes, 0, 0},

@@ -16,6 +16,7 @@
 #include "fgc_reduce.h"
 #include "fgc_mlp_split.h"
 #include "fgc_pack.h"
+#include "fgc_split.h"
 
 namespace fgc {
 
@@ -178,45 +179,9 @@ __global__ __launch_bounds__(MB_THREADS, 4) void mlp_fwd_bf16_kernel(const unsig
 // terms left out (a1 b2, a2 b1, a2 b2) are below 2^-25 of the product: the result differs from the fp32-MFMA kernel's by
 // summation order only (tests/test_gpu_ops.py compares the two).  FGC_NO_MLP_SPLIT=1 keeps the fp32 MFMA kernels.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split3(const f32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
-    p0 = f4_to_bf4(v);
-    const f32x4 r1 = v - bf4_to_f4(p0);
-    p1 = f4_to_bf4(r1);
-    const f32x4 r2 = r1 - bf4_to_f4(p1);
-    p2 = f4_to_bf4(r2);
-}
-
 // W1 [cin, hidden] fp32 -> three planes of B fragments [plane][k-step][column tile][lane][8] bf16
 __global__ void mlp_pack_split_kernel(const float* __restrict__ W1, unsigned short* __restrict__ Wp, int cin, int hidden) {
     mlp_pack_split_body(W1, Wp, cin, hidden, blockIdx.x, gridDim.x);
-}
-
-// six MFMAs of one split product, smallest terms first
-__device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 acc) {
-#define FGC_M16(A_, B_) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), acc, 0, 0, 0)
-    FGC_M16(a[0], b[2]);
-    FGC_M16(a[2], b[0]);
-    FGC_M16(a[1], b[1]);
-    FGC_M16(a[0], b[1]);
-    FGC_M16(a[1], b[0]);
-    FGC_M16(a[0], b[0]);
-#undef FGC_M16
-    return acc;
-}
-
-// The same product into TWO accumulators: the five small terms into `lo`, a0 b0 into `hi`.  For a sum that runs over many
-// calls (dx over the 1024 hidden columns): added to one accumulator that already holds the large partial sum, every small
-// term is rounded to that sum's last place by the matrix pipe's adder - measured 6e-7 of max |dx| against 1.4e-7 for the
-// fp32 MFMA kernel; kept among themselves they keep their bits until the one addition at the end.
-__device__ __forceinline__ void mfma_split2(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4& hi, f32x4& lo) {
-#define FGC_M16(A_, B_, ACC_) ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), ACC_, 0, 0, 0)
-    FGC_M16(a[0], b[2], lo);
-    FGC_M16(a[2], b[0], lo);
-    FGC_M16(a[1], b[1], lo);
-    FGC_M16(a[0], b[1], lo);
-    FGC_M16(a[1], b[0], lo);
-    FGC_M16(a[0], b[0], hi);
-#undef FGC_M16
 }
 
 // forward: the bf16 kernel's structure (a workgroup = 64 rows, wave w walks the hidden column tiles w, w + 4, ...); x is
@@ -690,15 +655,6 @@ __global__ __launch_bounds__(MBB_THREADS, 2) void mlp_bwd_w_bf16_kernel(
 // holds b1 - they lose what lies below the last place of max(|b1|, |x W1|), which is below the last place of the result.  Same results as the fp32-MFMA kernel up to summation order
 // (tests/test_gpu_ops.py holds both against float64 at the same bound).  FGC_NO_MLP_BWD_SPLIT=1 keeps mlp_bwd_kernel.
 // ---------------------------------------------------------------------------------------------
-// split eight fp32 values (two f32x4: fragment elements 0-3 and 4-7) into the three planes of one A / B fragment
-__device__ __forceinline__ void split3_frag(const f32x4& lo, const f32x4& hi, u32x4 (&p)[3]) {
-    u32x2 l[3], h[3];
-    split3(lo, l[0], l[1], l[2]);
-    split3(hi, h[0], h[1], h[2]);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) p[q] = u32x4{l[q][0], l[q][1], h[q][0], h[q][1]};
-}
-
 // (x tile: row = [plane 0 | plane 1 | plane 2 | 32 pad bytes], so that two workgroups of four waves fit a CU's 160 KB)
 #define MBS_XTS(CIN_) (3 * (CIN_) * 2 + 32)
 typedef short mbs_s16x4 __attribute__((ext_vector_type(4)));

@@ -188,6 +188,26 @@ __device__ __forceinline__ void split3_scalar(float v, unsigned short (&p)[3]) {
     p[1] = f_to_bf(r1);
     p[2] = f_to_bf(r1 - bf_to_f(p[1]));
 }
+// d-logits operand for the dz GEMM on split operands (conv_bwd_logits_deep_kernel<.., SPLIT>): the B fragments of
+// pack_logit_weight_bf16_body in three planes, [pass][k-step][column tile][plane][lane][8]:
+//   lane l: o = k-step*32 + 8*(l>>4) + j (j = 0..7), column kk = column tile*16 + (l&15) = m*32 + cl, channel pass*32 + cl
+__device__ __forceinline__ void pack_logit_weight_split_body(const float* __restrict__ W0, unsigned short* __restrict__ Wq, int cin,
+                                                             int cout, int passes, int bid, int nb) {
+    const int kso = (cout + 31) >> 5;
+    const size_t total = (size_t)passes * kso * 18 * 3 * 512;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < total; idx += (size_t)nb * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63;
+        const size_t rest = idx >> 9;
+        const int plane = rest % 3, ct = (rest / 3) % 18, ks = (rest / 54) % kso, pass = (int)(rest / ((size_t)54 * kso));
+        const int o = ks * 32 + 8 * (lane >> 4) + j;
+        const int kk = ct * 16 + (lane & 15);
+        const int m = kk >> 5, cl = kk & 31;
+        const int c = pass * 32 + cl;
+        unsigned short p[3];
+        split3_scalar((o < cout && c < cin) ? W0[((size_t)m * cout + o) * cin + c] : 0.f, p);
+        Wq[idx] = p[plane];
+    }
+}
 // The K = 3 product g[row][col] = sum_o dy[row][o] W2[col][o] with fp32-equivalent accuracy in ONE bf16 MFMA: both operands
 // split into three terms, the six products dy_p W2_q that matter (p + q <= 2) times three outputs fill 18 of the 32 k slots.
 //   slot s = pair * 3 + o,  pair -> (dy plane, W2 plane) = (0,0) (0,1) (1,0) (1,1) (0,2) (2,0);  lane (lr, lq) holds slots
@@ -339,6 +359,7 @@ struct PackJob {
                 // MLP operands, W0 = W1 [cin, ncols]: 9 mlp_pack_body (kdim = kpad), 10 mlp_pack_split_body,
                 // 11 mlp_pack_bf16_body, 12 mlp_pack_w1dx_bf16_body; 13 mlp_pack_w2_bf16_body (W0 = W2 [ncols, cout]);
                 // 15 mlp_pack_w1dx_split_body, 16 mlp_pack_w2_split_body (W0 = W2 [ncols, cout])
+                // 17 pack_logit_weight_split_body
     int cin, cout, kdim, ncols, npad, kc, kpass, passes, opad;
     int block0;
     const float* aux;

@@ -147,6 +147,44 @@ def test_conv_backward_fused_addressing_matches_oracle(mode):
                                    err_msg=name)
 
 
+def test_logit_gradients_on_split_operands_match_the_fp32_form(fgc_option):
+    """The dz GEMM of the half-tile d-logits kernel on the bf16 matrix pipe with three-term operand splits (option
+    NO_K1_SPLIT = 0, the default for 32 outputs on regular graphs): every gradient against the oracle at the fp32 tolerance
+    of the other conv tests, and against the fp32-MFMA form of the same kernel at the size of a summation-order difference."""
+    from facet_graph_convolution_amd import _lib, ops
+    from facet_graph_convolution_amd.graph import FacetGraph
+    from oracle import model_ref as R
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(31)
+    n, cin, cout = 400, 64, 32
+    adj = np.zeros((n, 23), dtype=np.int32)
+    for i in range(n):
+        d = rs.randint(3, 13)                      # degree <= 16: the half-tile kernel
+        adj[i, 0] = i + 1
+        adj[i, 1:1 + d] = rs.randint(1, n + 1, size=d)
+    g = FacetGraph(adj, dev)
+    x = torch.tensor(rs.normal(size=(n, cin)).astype(np.float32))
+    p = R.conv_params(cin, cout, 5)
+    dy = torch.tensor(rs.normal(size=(n, cout)).astype(np.float32))
+    gx_ref, gp_ref = _oracle_conv_grads([x], 0, adj, p, dy, act=True)
+    pd = [t.to(dev) for t in p]
+    out = {}
+    for no_split in (0, 1):
+        fgc_option("NO_K1_SPLIT", no_split)
+        y, _, ag = ops.conv_fwd(g, x.to(dev), None, 0, pd, act=1, alpha=0.1)
+        dx0, _, grads = ops.conv_bwd(g, x.to(dev), None, 0, pd, ag, y, dy.to(dev), act=1, alpha=0.1)
+        torch.cuda.synchronize()
+        out[no_split] = [dx0.cpu().numpy()] + [t.cpu().numpy() for t in grads]
+    assert _lib.get_option("NO_K1_SPLIT") == 1
+    refs = [gx_ref[0].numpy()] + [t.numpy() for t in gp_ref]
+    for a, b, r, name in zip(out[0], out[1], refs, ["dx", "dW0", "db", "du", "dc", "dv"]):
+        scale = max(1.0, np.abs(r).max())
+        np.testing.assert_allclose(a, r, atol=5e-6 * scale, err_msg=name)
+        np.testing.assert_allclose(a, b, atol=2e-6 * scale, err_msg=name + " (split vs fp32 MFMA)")
+    # the two forms are different kernels: the logit gradients are not bit-identical (or the option did nothing)
+    assert any(not np.array_equal(a, b) for a, b in zip(out[0][3:], out[1][3:]))
+
+
 def test_partial_calls_compose_to_the_whole_layer(golden_dir):
     """fgc_conv_desc.tile_list / proj_rows / FGC_CONV_PACKED and fgc_conv_bwd_io.data_tile_list / stages: a layer
     computed as two partial calls (what a facet-sharded run does around its halo exchange) is bit-identical to the
