@@ -1918,11 +1918,14 @@ static bool k1_split(const fgc_conv_desc* d) {
     if (opt(OPT_NO_K1_SPLIT) == 1 || (d->flags & FGC_CONV_BF16)) return false;
     return k1_nodes(d) == 16 && d->cout == 32 && !pairs_ok(d);
 }
+// (room for either layout wherever the shape allows the split one: the workspace a caller sized before changing NO_K1_SPLIT
+//  stays large enough; the operand itself must be packed again after such a change, like every packed operand)
 static size_t k1_wq_floats(const fgc_conv_desc* d) {
     const ConvGeom g1 = conv_geom(d->c0 + d->c1, d->cout);
     const int opad = (d->cout + 15) / 16 * 16;
     const size_t f32 = (size_t)g1.passes * opad * g1.kpass;
-    return k1_split(d) ? std::max(f32, (size_t)g1.passes * (d->cout >> 5) * 18 * 3 * 256) : f32;
+    const bool maybe = !(d->flags & FGC_CONV_BF16) && d->cout == 32;
+    return maybe ? std::max(f32, (size_t)g1.passes * (d->cout >> 5) * 18 * 3 * 256) : f32;
 }
 
 // ---- which kernel computes a layer's weight gradient, and with what arguments: shared by the per-layer launch (stage 8) and
