@@ -72,9 +72,10 @@ def parse_args(argv=None):
                     help="storage of the activations: f32 (default, the headline) or bf16 (default of --config c3)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the step from hipGraphs (one GPU: the whole step as one graph; facet-sharded: one graph "
-                         "per stretch of launches between two exchanges, falling back to eager if capture raises), 0 / -1 "
-                         "(default): eager launches - the step is GPU-bound, replay is 1 %% faster on one GPU and 3 - 5 %% on "
-                         "two gloo ranks.  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
+                         "per stretch of launches between two exchanges, falling back to eager if capture raises), 0: eager "
+                         "launches, -1 (default): one GPU training = 1 (replay is 1 %% faster at 100k facets, and the only "
+                         "stable timing at 50k), everything else = 0 (3 - 5 %% less host time per step on two gloo ranks, but "
+                         "collectives next to replays have not run on a real node).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which the package sets at import: with "
                          "the runtime's pre-built graph packets a replay after a stream synchronise computes garbage on "
                          "this ROCm stack (DESIGN.md section 6)")
     ap.add_argument("--repeats", type=int, default=5, help="untimed-extra repeats of the K-step block (min / median)")
@@ -542,12 +543,14 @@ def main(argv=None):
     counter = [0]
     auto_graph = args.graph < 0
     args.graph = 0 if auto_graph else args.graph
-    if auto_graph and world == 1 and train and F <= 60000:
-        # A small mesh (config 3: 50k facets, 0.75 ms of GPU time per step) is shorter on the GPU than its ~55 launches
-        # are on the host (0.8 ms of Python + ctypes per step): timed with eager launches it measures the host's jitter
-        # (blocks of 0.76 and 1.03 ms side by side in one run).  The step replayed from ONE hipGraph is what such a mesh is
-        # trained with (bit-identical: tests/test_gpu_net.py); the 100k-facet headline stays on eager launches (GPU-bound,
-        # replay within 0.1 %).
+    if auto_graph and world == 1 and train:
+        # A single-GPU training step is timed as ONE replayed hipGraph (the whole forward + backward enqueue captured in the
+        # first warm-up step; bit-identical to eager launches: tests/test_gpu_net.py, and `hipgraph_replay.matches_eager` of
+        # this line, which also carries the eager time of the same steps).  Config 3 (50k facets, 0.7 ms of GPU time) is
+        # shorter on the GPU than its ~45 launches are on the host (0.8 ms of Python + ctypes per step): timed with eager
+        # launches it measures the host's jitter.  The 100k-facet headline was GPU-bound with eager launches at 1.78 ms; at
+        # 1.61 ms the gaps between its 48 launches show: replay 1.594 - 1.600 against 1.616 - 1.618 eager on two of three
+        # boxes (profiles/r5_c_bench_three_boxes.txt).  `--graph 0` times eager launches.
         args.graph = 1
     # A facet-sharded training run times EAGER launches unless --graph 1 asks for hipGraph segments between the exchanges
     # (3 - 5 % less host time per step on two gloo ranks; the GPU time of a step exceeds the host's either way).  Round 3
@@ -605,6 +608,11 @@ def main(argv=None):
             graph_mode[0] = False
             net._graph_fb = None
     launch_mode = "hipGraph segments between the exchanges" if graph_mode[0] else "eager launches"
+    # (the collector off for the measurement: a full collection of this process's heap - meshes, plans, job tables - is a host
+    #  pause of 10 - 40 ms, which eager launches turn into an idle GPU: one K-step block in five read 3.5 instead of 1.65 ms)
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     dt = timed_block()                       # THE timed region: exactly K steps, max over ranks
