@@ -30,8 +30,32 @@ if preheat:      # unrelated work (fp32 matrix products on other memory) right i
         for _ in range(4):
             b = a @ a
         torch.cuda.synchronize()
+# the card's shader clock and power (sysfs, read-only) sampled by a thread while the steps run
+import glob, os, threading
+samples, stop = [], [False]
+def _card():
+    pr = torch.cuda.get_device_properties(0)
+    want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    for c in glob.glob("/sys/class/drm/card*/device"):
+        if os.path.basename(os.path.realpath(c)) == want:
+            h = glob.glob(c + "/hwmon/hwmon*")
+            return h[0] if h else None
+    return None
+hw = _card()
+def _sample():
+    f1, pw = hw + "/freq1_input", hw + "/power1_input"
+    while not stop[0]:
+        try:
+            samples.append((time.perf_counter(), int(open(f1).read()) / 1e6, int(open(pw).read()) / 1e6))
+        except Exception:
+            pass
+        time.sleep(0.0005)
+th = threading.Thread(target=_sample) if hw else None
+if th:
+    th.start()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
 wall = []
+t_start = time.perf_counter()
 for k in range(nsteps):
     t0 = time.perf_counter()
     ev[k][0].record()
@@ -41,7 +65,22 @@ for k in range(nsteps):
     ev[k][1].record()
     wall.append((time.perf_counter() - t0) * 1e3)
 torch.cuda.synchronize()
+t_end = time.perf_counter()
+stop[0] = True
+if th:
+    th.join()
 gpu = [a.elapsed_time(b) for a, b in ev]
+if samples:
+    # (the steps run back to back on the GPU from the end of step 0's capture: sample times are mapped onto steps by the
+    #  cumulative GPU time counted back from the end of the run)
+    ends = np.cumsum(gpu[::-1])[::-1]
+    print("hwmon:", hw, "samples", len(samples))
+    out = []
+    for k in range(nsteps):
+        lo, hi = t_end - ends[k] * 1e-3, t_end - (ends[k] - gpu[k]) * 1e-3
+        v = [(f, p) for t, f, p in samples if lo <= t < hi]
+        out.append("%d:%s" % (k, ("%.0fMHz/%.0fW" % (np.mean([a for a, _ in v]), np.mean([b for _, b in v]))) if v else "-"))
+    print("clock / power per step:", " ".join(out))
 if len(sys.argv) > 5:      # a second batch of steps after an idle pause (same network, training continues)
     time.sleep(float(sys.argv[5]))
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
