@@ -587,12 +587,19 @@ def main(argv=None):
             torch.cuda.synchronize()
 
     def timed_block():
-        sync_barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_barrier()
-        dt = time.perf_counter() - t0
+        import gc as _gc
+        was = _gc.isenabled()
+        _gc.disable()
+        try:
+            sync_barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync_barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            if was:
+                _gc.enable()
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -608,14 +615,17 @@ def main(argv=None):
             graph_mode[0] = False
             net._graph_fb = None
     launch_mode = "hipGraph segments between the exchanges" if graph_mode[0] else "eager launches"
-    # (the collector off for the measurement: a full collection of this process's heap - meshes, plans, job tables - is a host
-    #  pause of 10 - 40 ms, which eager launches turn into an idle GPU: one K-step block in five read 3.5 instead of 1.65 ms)
+    # (the collector OFF for the measurement - gc.disable() around every timed block, not only gc.freeze(), which keeps
+    #  collecting what is allocated afterwards: a full collection of this process's heap - meshes, plans, job tables - is a
+    #  host pause of 10 - 40 ms, which eager launches turn into an idle GPU: one K-step block in five read 3.5 instead of
+    #  1.65 ms in round 5's eager rows)
     import gc
     gc.collect()
     gc.freeze()
     w_done = 0
     graph_note = None
-    if args.graph and world == 1 and train and args.warmup > 0:
+    if args.graph and world == 1 and train:
+        # (also with --warmup 0: the capture is never part of the timed block)
         # the first warm-up step captures the step's hipGraph: if this runtime refuses (it never has), the same arithmetic is
         # timed with eager launches and the line says so, instead of there being no line
         try:
@@ -799,14 +809,41 @@ def main(argv=None):
                                       "%.0f / 6 fp32-equivalent TFLOP/s" % PEAK_BF16_MFMA_TFLOPS) if fpeak != peak else
                                      ("bf16 MFMA" if dtype_ == "bf16" else "fp32 MFMA"),
                              "traffic": tr["hbm_bytes_per_launch"] if tr else None})
-        if families and dtype_ == "bf16":
+        # The launch `roofline` names is the one that takes the most TIME per step among the launches with a work model
+        # (round-5 review: the family's best launch is not the launch that dominates time); the best launch of its family
+        # rides along as `family_best`.
+        def launch_row(r):
+            ms_, key_, cnt_, avg_, fl_ = r
+            ab_ = abytes.get(key_)
+            pk_ = row_peak.get(key_, peak)
+            tr_ = traffic_db.get(key_)
+            ach_ = fl_ / (avg_ * 1e-6) / 1e12
+            return {"kernel": key_, "family": family_of(key_.split("/", 1)[1]), "avg_kernel_us": round(avg_, 2),
+                    "us_per_step": round(ms_ / steps_ * 1e3, 2), "launch_flops": fl_, "achieved": round(ach_, 2),
+                    "frac": round(ach_ / pk_, 4), "peak": round(pk_, 1), "algorithmic_bytes": ab_,
+                    "hbm_gbs": round(ab_ / (avg_ * 1e-6) / 1e9, 1) if ab_ else None,
+                    "hbm_frac": round(ab_ / (avg_ * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if ab_ else None,
+                    "traffic": tr_["hbm_bytes_per_launch"] if tr_ else None}
+        modelled = [r for r in rows if r[4] and (dtype_ != "bf16" or abytes.get(r[1]))]
+        dom = launch_row(max(modelled, key=lambda r: (r[0], r[1]))) if modelled else None
+        fam_best = None
+        if dom:
+            same = [launch_row(r) for r in modelled if family_of(r[1].split("/", 1)[1]) == dom["family"]]
+            bkey = "hbm_frac" if dtype_ == "bf16" else "frac"
+            b = max(same, key=lambda d_: (d_[bkey] or 0.0, d_["kernel"]))
+            fam_best = {k_: b[k_] for k_ in ("kernel", "avg_kernel_us", "achieved", "frac", "hbm_gbs", "hbm_frac")}
+            fshare = {f_["family"]: f_ for f_ in families}.get(dom["family"], {})
+            dom["share_of_step"] = fshare.get("share_of_step", round(fam[dom["family"]]["ms"] / total_ms, 4))
+            dom["family_frac"] = fshare.get("family_frac")
+        if dom and dtype_ == "bf16":
             # bf16 storage: the matrix products are 16x cheaper, the bound to quote is HBM - the
             # kernels are far from it too: they are bound by vector-ALU issue in the aggregation
-            d = families[0]
+            d = dom
             roofline = {"bound": "hbm", "kernel": d["kernel"], "family": d["family"], "achieved": d["hbm_gbs"],
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["hbm_frac"], "traffic": d["traffic"],
                         "avg_kernel_us": d["avg_kernel_us"], "launch_bytes": d["algorithmic_bytes"],
                         "mfma_tflops": d["achieved"], "mfma_frac": d["frac"],
+                        "selected_by": "largest time per step among the launches with a work model", "family_best": fam_best,
                         # what the counters say binds the bf16 kernels (the contract's `bound` is the roofline quoted)
                         "binds": load_binds("bf16"),
                         "family_share_of_step": d["share_of_step"],
@@ -814,11 +851,12 @@ def main(argv=None):
                         "traffic_whole_step": traffic_db.get("whole_step", {}).get("hbm_bytes_per_step"),
                         "traffic_source": traffic_note,
                         "launches_per_step": round(sum(c for c, _ in prof.values()) / steps_, 1)}
-        elif families:
-            d = families[0]
+        elif dom:
+            d = dom
             roofline = {"bound": "mfma", "kernel": d["kernel"], "family": d["family"], "achieved": d["achieved"],
-                        "peak": peak, "unit": "TFLOP/s", "frac": d["frac"], "traffic": d["traffic"],
+                        "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"], "traffic": d["traffic"],
                         "avg_kernel_us": d["avg_kernel_us"], "launch_flops": d["launch_flops"],
+                        "selected_by": "largest time per step among the launches with a work model", "family_best": fam_best,
                         "family_share_of_step": d["share_of_step"], "family_frac": d["family_frac"],
                         "binds": load_binds("f32"),
                         "eager_step_ms_sum_of_kernels": round(total_ms / steps_, 3),
@@ -894,79 +932,7 @@ def main(argv=None):
             res["hbm_roofline_frac_whole_step"] = res["algorithmic_bytes_per_step"] / (best * 1e-3) / (PEAK_HBM_GBS * 1e9)
         return res
 
-    also = None
-    if world == 1 and train and args.config == "c2" and args.dtype == "f32" and (args.nu, args.nv) == (250, 200) \
-            and not args.multi_scale and not os.environ.get("FGC_BENCH_NO_ALSO"):
-        # BASELINE config 3 (train step, bf16 storage / fp32 accumulate) at its own 50k facets and at the headline's 100k: a
-        # few seconds, so that the driver's record carries them.  A build extension (the reference is fp32 only): accepted at
-        # the bf16 tolerances of tests/test_gpu_bf16.py / test_gpu_scale.py (normals 5e-3, loss 1e-2 relative, gradients
-        # 8e-2 of each tensor's largest entry), never the headline.
-        torch.cuda.synchronize()
-        t_also = time.perf_counter()
-        try:                                    # (an extra: a failure here is recorded, it does not cost the headline's line)
-            ds3, _ = build_mesh(250, 100, seed=0)
-            also = {"c3_bf16_50k": side_step_bench(ds3, "bf16", 250, 100, "c3: torus 250x100 = 50000 facets, train step, bf16 storage / "
-                                                   "fp32 accumulate"),
-                    "c2_bf16_100k": side_step_bench(ds, "bf16", 250, 200, "torus 250x200 = 100000 facets, train step, bf16 storage / "
-                                                    "fp32 accumulate"),
-                    "note": "untimed extras measured after the headline's timed region; bf16 storage is a build extension accepted "
-                            "at the tolerances of tests/test_gpu_bf16.py (normals 5e-3, loss 1e-2, gradients 8e-2 of each tensor's "
-                            "maximum)"}
-            del ds3
-            also["seconds"] = round(time.perf_counter() - t_also, 1)
-        except Exception as e:                  # noqa: BLE001
-            print("bench: the bf16 extras failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
-            also = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # the world as the collective back end itself counts it: every rank contributes a one to an all-reduce
-    world_check = None
-    if world > 1:
-        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(one)
-        world_check = {"backend": "RCCL" if backend == "nccl" else backend, "ranks_in_all_reduce": int(one.item()),
-                       "get_world_size": dist.get_world_size()}
-
-    # N > 1, facet-sharded, weak scaling (the driver's run): the OTHER reading of "facets/s on a 100k-facet mesh at N GPUs" -
-    # the one 100 000-facet mesh sharded over the N ranks (strong scaling) - measured by the same ranks behind the weak
-    # region, with the same barriers and the max over ranks
-    strong = None
-    if shard and train and args.scaling == "weak" and args.config == "c2" and not os.environ.get("FGC_BENCH_NO_STRONG"):
-        # (an extra behind the headline: whatever goes wrong here - the same thing on every rank, these are the calls the weak
-        #  region has just made - must not cost the line; it is recorded instead)
-        try:
-            del net
-            torch.cuda.empty_cache()
-            t1 = time.perf_counter()
-            ds_s, F_s = build_mesh_shared(args.nu, args.nv, 0, rank, world, backend, dev)
-            plan_s = ShardPlan(graphs_to_host_csr(ds_s.adj_list[0]), rank, world)
-            net = FacetDenoiser(dev, **mk).bind_mesh(ds_s.in_list[0], ds_s.adj_list[0], gt=ds_s.gt_list[0], plan=plan_s, comm=DistComm())
-            n0 = ds_s.in_list[0].shape[1]
-            rs_s = np.random.RandomState(300)      # (same stream on every rank: samples are drawn over the whole mesh)
-            samp_host = [rs_s.randint(n0, size=4000) for _ in range(nsteps_total)]
-            rot_host = [rand_rotation_matrix(randnums=rs_s.uniform(size=3)) for _ in range(nsteps_total)]
-            SR_all = FacetDenoiser.pack_step_inputs(samp_host, rot_host, dev)
-            S_loc = [net.local_samples_device(sm) for sm in samp_host]
-            graph_mode[0] = False
-            args.graph = 0
-            counter[0] = 0
-            setup_s = time.perf_counter() - t1
-            for _ in range(args.warmup):
-                step()
-            dts = timed_block()
-            strong = {"scaling": "strong", "workload": "ONE torus %dx%d = %d facets facet-sharded over %d GPUs, train step, eager launches"
-                      % (args.nu, args.nv, F_s, world), "facets": F_s, "value": F_s * args.steps / dts, "unit": "facets/s",
-                      "ms_per_step": dts / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
-                      "loss_deg": net.buffers["loss"][0].item(), "setup_s": round(setup_s, 2),
-                      "halo_over_owned_rows_rank0": [round(net._mesh["nh"][l] / max(net._mesh["ns"][l], 1), 4) for l in range(3)]}
-        except Exception as e:      # noqa: BLE001
-            print("bench: strong-scaling extra failed on rank %d: %s: %s" % (rank, type(e).__name__, e), file=sys.stderr)
-            strong = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-
-    if rank == 0:
+    def make_record(also, strong, cpu):
         ms_step = dt / args.steps * 1e3
         step_bytes = fb_b if train else fwd_b
         mesh_txt = "torus %dx%d quads = %d facets%s (N0=%d padded nodes%s)" % (
@@ -1024,7 +990,130 @@ def main(argv=None):
             "strong": strong,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        return out
+
+    # the world as the collective back end itself counts it: every rank contributes a one to an all-reduce
+    world_check = None
+    if world > 1:
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        world_check = {"backend": "RCCL" if backend == "nccl" else backend, "ranks_in_all_reduce": int(one.item()),
+                       "get_world_size": dist.get_world_size()}
+
+    def emit_early(rec, why):
+        """The headline record BEFORE any extra runs (stderr and, where gpurun_out/ exists, a file): an extra that dies by a
+        signal or never returns must not cost the measurement that was already taken (round-5 advisor finding)."""
+        if rank != 0:
+            return
+        txt = json.dumps(rec)
+        print("bench: headline record %s: %s" % (why, txt), file=sys.stderr, flush=True)
+        d = os.path.join(REPO, "gpurun_out")
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_headline_early.json"), "w") as fh:
+                    fh.write(txt + "\n")
+            except OSError:
+                pass
+
+    also = None
+    if world == 1:
+        emit_early(make_record(None, None, None), "before the bf16 extras and the CPU baseline")
+    if world == 1 and train and args.config == "c2" and args.dtype == "f32" and (args.nu, args.nv) == (250, 200) \
+            and not args.multi_scale and not os.environ.get("FGC_BENCH_NO_ALSO"):
+        # BASELINE config 3 (train step, bf16 storage / fp32 accumulate) at its own 50k facets and at the headline's 100k: a
+        # few seconds, so that the driver's record carries them.  A build extension (the reference is fp32 only): accepted at
+        # the bf16 tolerances of tests/test_gpu_bf16.py / test_gpu_scale.py (normals 5e-3, loss 1e-2 relative, gradients
+        # 8e-2 of each tensor's largest entry), never the headline.
+        torch.cuda.synchronize()
+        t_also = time.perf_counter()
+        try:                                    # (an extra: a failure here is recorded, it does not cost the headline's line)
+            ds3, _ = build_mesh(250, 100, seed=0)
+            also = {"c3_bf16_50k": side_step_bench(ds3, "bf16", 250, 100, "c3: torus 250x100 = 50000 facets, train step, bf16 storage / "
+                                                   "fp32 accumulate"),
+                    "c2_bf16_100k": side_step_bench(ds, "bf16", 250, 200, "torus 250x200 = 100000 facets, train step, bf16 storage / "
+                                                    "fp32 accumulate"),
+                    "note": "untimed extras measured after the headline's timed region; bf16 storage is a build extension accepted "
+                            "at the tolerances of tests/test_gpu_bf16.py (normals 5e-3, loss 1e-2, gradients 8e-2 of each tensor's "
+                            "maximum)"}
+            del ds3
+            also["seconds"] = round(time.perf_counter() - t_also, 1)
+        except Exception as e:                  # noqa: BLE001
+            print("bench: the bf16 extras failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
+            also = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # N > 1, facet-sharded, weak scaling (the driver's run): the OTHER reading of "facets/s on a 100k-facet mesh at N GPUs" -
+    # the one 100 000-facet mesh sharded over the N ranks (strong scaling) - measured by the same ranks behind the weak
+    # region, with the same barriers and the max over ranks
+    strong = None
+    line_out = False
+    if world > 1:
+        # N > 1: the ONE JSON line is printed HERE, before the strong-scaling extra, which re-shards, binds a new network and
+        # issues collectives: a rank that raises or aborts in there would leave its peers waiting in a collective and the
+        # weak-scaling value unprinted.  The extra reports on stderr (`bench: strong-scaling extra: {...}`) and in
+        # gpurun_out/bench_strong.json; a watchdog ends the process (exit 0: the line is out) if it does not return.
+        if rank == 0:
+            print(json.dumps(make_record(None, {"note": "measured after this line was printed: see `bench: strong-scaling "
+                                                        "extra` on stderr"}, None)), flush=True)
+        line_out = True
+    if shard and train and args.scaling == "weak" and args.config == "c2" and not os.environ.get("FGC_BENCH_NO_STRONG"):
+        import threading
+        limit = float(os.environ.get("FGC_BENCH_STRONG_LIMIT_S", "180"))
+
+        def _give_up():
+            print("bench: strong-scaling extra did not return within %.0f s on rank %d; leaving (the headline line is out)"
+                  % (limit, rank), file=sys.stderr, flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        # (an extra behind the headline: whatever goes wrong here - the same thing on every rank, these are the calls the weak
+        #  region has just made - must not cost the line; it is recorded instead)
+        try:
+            del net
+            torch.cuda.empty_cache()
+            t1 = time.perf_counter()
+            ds_s, F_s = build_mesh_shared(args.nu, args.nv, 0, rank, world, backend, dev)
+            plan_s = ShardPlan(graphs_to_host_csr(ds_s.adj_list[0]), rank, world)
+            net = FacetDenoiser(dev, **mk).bind_mesh(ds_s.in_list[0], ds_s.adj_list[0], gt=ds_s.gt_list[0], plan=plan_s, comm=DistComm())
+            n0 = ds_s.in_list[0].shape[1]
+            rs_s = np.random.RandomState(300)      # (same stream on every rank: samples are drawn over the whole mesh)
+            samp_host = [rs_s.randint(n0, size=4000) for _ in range(nsteps_total)]
+            rot_host = [rand_rotation_matrix(randnums=rs_s.uniform(size=3)) for _ in range(nsteps_total)]
+            SR_all = FacetDenoiser.pack_step_inputs(samp_host, rot_host, dev)
+            S_loc = [net.local_samples_device(sm) for sm in samp_host]
+            graph_mode[0] = False
+            args.graph = 0
+            counter[0] = 0
+            setup_s = time.perf_counter() - t1
+            for _ in range(args.warmup):
+                step()
+            dts = timed_block()
+            strong = {"scaling": "strong", "workload": "ONE torus %dx%d = %d facets facet-sharded over %d GPUs, train step, eager launches"
+                      % (args.nu, args.nv, F_s, world), "facets": F_s, "value": F_s * args.steps / dts, "unit": "facets/s",
+                      "ms_per_step": dts / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                      "loss_deg": net.buffers["loss"][0].item(), "setup_s": round(setup_s, 2),
+                      "halo_over_owned_rows_rank0": [round(net._mesh["nh"][l] / max(net._mesh["ns"][l], 1), 4) for l in range(3)]}
+        except Exception as e:      # noqa: BLE001
+            print("bench: strong-scaling extra failed on rank %d: %s: %s" % (rank, type(e).__name__, e), file=sys.stderr)
+            strong = {"error": "%s: %s" % (type(e).__name__, e)}
+            # (the peers may be waiting in a collective this rank will never join: leave together through the watchdog)
+        if rank == 0:
+            print("bench: strong-scaling extra: %s" % json.dumps(strong), file=sys.stderr, flush=True)
+            d_ = os.path.join(REPO, "gpurun_out")
+            if os.path.isdir(d_):
+                with open(os.path.join(d_, "bench_strong.json"), "w") as fh:
+                    fh.write(json.dumps(strong) + "\n")
+        if "error" in strong:
+            sys.stderr.flush()
+            os._exit(0)
+        watchdog.cancel()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0 and not line_out:
+        print(json.dumps(make_record(also, strong, cpu)))
     if world > 1:
         dist.destroy_process_group()
 

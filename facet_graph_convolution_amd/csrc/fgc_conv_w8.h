@@ -45,4 +45,9 @@ int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int
 bool w8_erow_supported(const CoreParams& p, int max_deg);
 int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16 = false);
 
+// bf16 storage, degrees <= 16: the aggregation on the bf16 matrix pipe (fgc_conv_bfm.hip).  half = 16-node workgroups.
+bool bfm_supported(const CoreParams& p, int max_deg, bool data, int cin_fwd);
+int launch_fwd_bfm(const CoreParams& p, const FwdEpilogue& ep, bool half, hipStream_t st);
+int launch_data_bfm(const CoreParams& p, const DataEpilogue& ep, bool half, bool erow, hipStream_t st);
+
 }  // namespace fgc

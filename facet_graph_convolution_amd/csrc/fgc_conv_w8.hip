@@ -666,12 +666,19 @@ bool w8_bf16_supported(const CoreParams& p, int max_deg) {
     return w8_supported(p, max_deg) && w8_fast(p) && (nct == 2 || nct == 4 || nct == 8) && p.nout == p.npad;
 }
 
+// (the matrix-pipe form stores r in 16-byte pieces)
+static bool bfm_r_ok(const DataEpilogue& de) { return ((uintptr_t)de.r & 15) == 0 && de.rld % 8 == 0; }
+
 template <bool DATA>
 static int launch_w8(const CoreParams& p, const FwdEpilogue& fe, const DataEpilogue& de, size_t smem, int max_deg,
                      bool bf16, hipStream_t st) {
-    if (bf16)
+    if (bf16) {
+        // degrees <= 16: the aggregation on the bf16 matrix pipe (fgc_conv_bfm.hip; option NO_BFM = 1: the vector form)
+        if (bfm_supported(p, max_deg, DATA, de.cin) && (!DATA || bfm_r_ok(de)))
+            return DATA ? launch_data_bfm(p, de, w8_half_tiles<DATA>(p), false, st) : launch_fwd_bfm(p, fe, w8_half_tiles<DATA>(p), st);
         return max_deg <= 16 ? launch_w8f<DATA, true, 16, true>(p, fe, de, smem, st)
                              : launch_w8f<DATA, true, KMAX, true>(p, fe, de, smem, st);
+    }
     if (!w8_fast(p)) return launch_w8f<DATA, false, KMAX>(p, fe, de, smem, st);
     return max_deg <= 16 ? launch_w8f<DATA, true, 16>(p, fe, de, smem, st)
                          : launch_w8f<DATA, true, KMAX>(p, fe, de, smem, st);
@@ -689,6 +696,7 @@ int launch_data_w8(const CoreParams& p, const DataEpilogue& ep, size_t smem, int
 bool w8_erow_supported(const CoreParams& p, int max_deg) { return w8_supported(p, max_deg) && w8_fast(p) && p.eid != nullptr; }
 int launch_data_w8_erow(const CoreParams& p, const DataEpilogue& ep, size_t smem, int max_deg, hipStream_t st, bool bf16) {
     FwdEpilogue fe{};
+    if (bf16 && bfm_supported(p, max_deg, true, ep.cin) && bfm_r_ok(ep)) return launch_data_bfm(p, ep, w8_half_tiles<true>(p), true, st);
     if (bf16)
         return max_deg <= 16 ? launch_w8f<true, true, 16, true, true>(p, fe, ep, smem, st)
                              : launch_w8f<true, true, KMAX, true, true>(p, fe, ep, smem, st);

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity_report import FP32_GRAD_TOL, FP32_NORMAL_TOL, check_gradients, check_normals
+
 pytestmark = pytest.mark.gpu
 
 
@@ -24,15 +26,13 @@ def test_reference_style_graph_build_matches_fixture(golden_dir):
     assert len(store.vars) == 44 and sum(v.numel() for v in store.vars) == 474199
     ref = z["y0"]
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
-    np.testing.assert_allclose(n_conv.detach().cpu().numpy(), z["n_conv"], rtol=0, atol=2e-5)
+    check_normals(n_conv, z["n_conv"], FP32_NORMAL_TOL, "model.py mirror, ico3")
     idx = torch.tensor(z["sample_ind"], device=dev)
     loss = faceNormalsLoss(n_conv[:, idx], gt[:, idx])
     assert abs(loss.item() - float(z["loss"])) < 1e-4 * float(z["loss"])
     loss.backward()
-    for i, v in enumerate(store.vars):
-        r = z["g%02d" % i]
-        scale = max(np.abs(r).max(), 1e-3)
-        assert np.abs(v.grad.cpu().numpy() - r).max() / scale < 2e-3, "grad %d" % i
+    check_gradients(["var%02d" % i for i in range(len(store.vars))], [v.grad for v in store.vars],
+                    [z["g%02d" % i] for i in range(len(store.vars))], FP32_GRAD_TOL, "model.py mirror, ico3")
     # second call after rewind reuses the same 44 variables (graph built once, run many times)
     with M.variable_store(store):
         y2 = M.get_model_reg_multi_scale(x, adjs, 1.0)

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity_report import FP32_GRAD_TOL, FP32_NORMAL_TOL, check_gradients, check_normals
+
 pytestmark = pytest.mark.gpu
 
 
@@ -32,17 +34,11 @@ def test_train_forward_backward_matches_reference(golden_dir, name, tag, seed):
     ref = z["y0"][0]
     print("y0 max abs err %.3e (scale %.3f)" % (np.abs(y0 - ref).max(), np.abs(ref).max()))
     np.testing.assert_allclose(y0, ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
-    # denoised normals: max abs 2e-5 on unit vectors (SURVEY §8c tolerance), i.e. ~1e-3 degree
-    np.testing.assert_allclose(B["nconv"].cpu().numpy(), z["n_conv"][0], rtol=0, atol=2e-5)
+    # denoised normals: SURVEY section 8c allows 2e-5 abs on unit vectors (~1e-3 degree); held to what the kernels achieve
+    check_normals(B["nconv"], z["n_conv"][0], FP32_NORMAL_TOL, name)
     assert abs(loss[0].item() - float(z["loss"])) < 1e-4 * float(z["loss"])
-    worst = 0.0
-    for i, g in enumerate(net.params.grads):
-        ref = z["g%02d" % i]
-        scale = max(np.abs(ref).max(), 1e-3)
-        err = np.abs(g.cpu().numpy() - ref).max() / scale
-        worst = max(worst, err)
-        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
-    print("worst relative gradient error over 44 variables: %.3e" % worst)
+    check_gradients(net.params.spec, net.params.grads, [z["g%02d" % i] for i in range(len(net.params.grads))],
+                    FP32_GRAD_TOL, name)
 
 
 def test_train_step_matches_the_reference_at_its_patch_size(golden_dir):
@@ -63,16 +59,10 @@ def test_train_step_matches_the_reference_at_its_patch_size(golden_dir):
     B = net.buffers
     ref = z["y0"][0]
     np.testing.assert_allclose(B["y0"].cpu().numpy(), ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()))
-    np.testing.assert_allclose(B["nconv"].cpu().numpy(), z["n_conv"][0], rtol=0, atol=2e-5)
+    check_normals(B["nconv"], z["n_conv"][0], FP32_NORMAL_TOL, "net_ico5_20k")
     assert abs(loss[0].item() - float(z["loss"])) < 1e-4 * float(z["loss"])
-    worst = 0.0
-    for i, g in enumerate(net.params.grads):
-        ref = z["g%02d" % i]
-        scale = max(np.abs(ref).max(), 1e-3)
-        err = np.abs(g.cpu().numpy() - ref).max() / scale
-        worst = max(worst, err)
-        assert err < 2e-3, "grad %d (%s): rel err %.3e" % (i, net.params.spec[i], err)
-    print("20 480 faces: worst relative gradient error over 44 variables %.3e" % worst)
+    check_gradients(net.params.spec, net.params.grads, [z["g%02d" % i] for i in range(len(net.params.grads))],
+                    FP32_GRAD_TOL, "net_ico5_20k (reference fixture, 20 480 faces)")
 
 
 def test_gradients_vs_float64_truth(golden_dir):
@@ -115,13 +105,13 @@ def test_inference_epilogue_matches_reference(golden_dir):
     net, prep = _bind(golden_dir, "ico3", 0)
     out = net.infer_normals(prep["permutations"], int(prep["num_faces"]))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(net.buffers["nconv"].cpu().numpy(), z["n_conv"][0], atol=2e-5)
+    check_normals(net.buffers["nconv"], z["n_conv"][0], FP32_NORMAL_TOL, "infer_ico3")
     got = out.cpu().numpy()
     ref = z["predicted_normals"]
     assert got.shape == (1280, 3)
     ang = np.degrees(np.arccos(np.clip((got * ref).sum(1), -1, 1)))
     print("max angular deviation vs reference: %.2e deg" % ang.max())
-    assert ang.max() < 0.05 and np.abs(got - ref).max() < 2e-5
+    assert ang.max() < 0.05 and np.abs(got - ref).max() < FP32_NORMAL_TOL
 
 
 def test_multiscale_heads_forward(golden_dir):
@@ -263,11 +253,9 @@ def test_irregular_mesh_train_step_matches_oracle():
                                     torch.tensor(gt.astype(np.float32)), params, samp,
                                     torch.tensor(Rm.astype(np.float32)))
     ref_loss.backward()
-    assert (net.buffers["nconv"].cpu() - n_conv[0].detach()).abs().max().item() < 2e-5
+    check_normals(net.buffers["nconv"], n_conv[0], FP32_NORMAL_TOL, "irregular mesh")
     assert abs(loss[0].item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
-    for i, (g, p) in enumerate(zip(net.params.grads, params)):
-        scale = max(p.grad.abs().max().item(), 1e-3)
-        assert (g.cpu() - p.grad).abs().max().item() / scale < 2e-3, "grad %d" % i
+    check_gradients(net.params.spec, net.params.grads, [p.grad for p in params], FP32_GRAD_TOL, "irregular mesh vs model_ref")
 
 
 def test_irregular_mesh_sharded_matches_single():
@@ -316,11 +304,9 @@ def test_tiny_mesh_one_coarsest_node():
     ref_loss, n_conv = R.train_loss(torch.tensor(x.astype(np.float32)), [torch.tensor(a.astype(np.int32)) for a in adjs],
                                     torch.tensor(gt.astype(np.float32)), params, samp, torch.eye(3))
     ref_loss.backward()
-    assert (net.buffers["nconv"].cpu() - n_conv[0].detach()).abs().max().item() < 2e-5
+    check_normals(net.buffers["nconv"], n_conv[0], FP32_NORMAL_TOL, "octahedron")
     assert abs(loss[0].item() - ref_loss.item()) < 1e-4 * max(abs(ref_loss.item()), 1.0)
-    for i, (g, p) in enumerate(zip(net.params.grads, params)):
-        scale = max(p.grad.abs().max().item(), 1e-3)
-        assert (g.cpu() - p.grad).abs().max().item() / scale < 2e-3, "grad %d" % i
+    check_gradients(net.params.spec, net.params.grads, [p.grad for p in params], FP32_GRAD_TOL, "octahedron vs model_ref")
 
 
 @pytest.mark.parametrize("switches", [
@@ -550,9 +536,8 @@ def test_multiscale_training_step_matches_oracle(golden_dir):
     for a, b in zip(got, losses):
         assert abs(a - b.item()) < 1e-4 * abs(b.item()), (got, [l.item() for l in losses])
     assert len(net.params.grads) == 52
-    for i, (g, p) in enumerate(zip(net.params.grads, params)):
-        scale = max(p.grad.abs().max().item(), 1e-3)
-        assert (g.cpu() - p.grad).abs().max().item() / scale < 2e-3, "grad %d (%s)" % (i, net.params.spec[i])
+    check_gradients(net.params.spec, net.params.grads, [p.grad for p in params], FP32_GRAD_TOL,
+                    "three heads, ico3 vs model_ref")
     # and it trains
     rs = np.random.RandomState(0)
     first = None
