@@ -638,6 +638,23 @@ def main(argv=None):
             torch.cuda.synchronize()
             step()
         w_done = 1
+    # Per-kernel durations (hipEvents recorded by the library around every launch, same stream) over `steps` eager steps of the
+    # same work as the timed region, taken BEFORE the timed region since round 6 (behind the capture step, in
+    # front of the other warm-up steps, so that no host-only stretch separates it from the timed block): the pass doubles as the
+    # clock warm-up the contract's W steps are too short for (a GPU that idled through the mesh preprocessing runs its first
+    # ~15 steps 3 - 15 % slow: profiles/r5_first_steps_probe.txt; the driver's --warmup 5 --steps 20 sat inside that ramp).
+    # The timed region itself is unchanged: W untimed steps, then exactly K steps between barriers.  Facet-sharded: every
+    # rank runs the steps (they hold collectives), rank 0's table is the one reported; a layer that runs as interior |
+    # exchange | boundary launches counts with the SUM of its launches.
+    prof = None
+    if not args.no_roofline and train and (shard or world == 1):
+        net.profile_start()
+        for k in range(args.steps):
+            kk = k % nsteps_total
+            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None, in_place=True)
+            net.forward_backward(rotate=True, capture=False)
+            net.adam_step()
+        prof = net.profile_stop()
     for _ in range(args.warmup - w_done):
         step()
     dt = timed_block()                       # THE timed region: exactly K steps, max over ranks
@@ -870,18 +887,11 @@ def main(argv=None):
     families = None
     pair_form = None
     kernels = {}
-    if not args.no_roofline and train and (shard or world == 1):
+    if prof is not None:
         # per-kernel durations from hipEvents recorded by the library around every launch (same stream), over
         # `steps` eager steps of the same work as the timed region.  Facet-sharded: every rank runs the steps (they hold
         # collectives), rank 0's table is the one reported; a layer that runs as interior | exchange | boundary launches
         # counts with the SUM of its launches
-        net.profile_start()
-        for k in range(args.steps):
-            kk = k % nsteps_total
-            net.set_step_inputs_packed(SR_all[kk], S_loc[kk] if S_loc else None, in_place=True)
-            net.forward_backward(rotate=True, capture=False)
-            net.adam_step()
-        prof = net.profile_stop()
         roofline, families, pair_form, kernels = analyse(net, prof, args.steps, args.dtype, args.nu, args.nv, args.dump_kernels)
 
     fwd_b, fb_b = algorithmic_bytes_fwd_bwd(net, elem=2 if args.dtype == "bf16" else 4)
@@ -966,6 +976,10 @@ def main(argv=None):
                                        "1 mesh per GPU, flat-gradient all-reduce (%s world size %d)" % (
                                            "RCCL" if backend == "nccl" else backend, dist.get_world_size()))},
             "loss_deg": loss,
+            # what the process ran, in order (round 6: the hipEvent pass moved in front; the timed region is W + K steps as ever)
+            "timeline": ("%sW = %d untimed warm-up steps -> K = %d timed steps between barriers -> untimed extras" % (
+                "per-kernel hipEvent pass (%d eager steps; also warms the clocks) -> " % args.steps if prof is not None else "",
+                args.warmup, args.steps)),
             "startup_s": {k: round(v, 2) for k, v in startup.items()},
             "world_check": world_check,
             "repeats_ms_per_step": [round(v, 4) for v in rep_ms],

@@ -30,6 +30,9 @@
 #ifndef BFM_KO
 #define BFM_KO 0
 #endif
+#ifndef BFM_RING
+#define BFM_RING 4
+#endif
 #ifndef BFM_SEPARATE_QT
 #define BFM_SEPARATE_QT 0
 #endif
@@ -382,15 +385,23 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_bfm_kernel(CoreParams p, FwdE
                                                                 acc[r], 0, 0, 0);
             }
         };
+        // the packed-weight fragments run through a ring of BFM_RING registers sets with fixed roles (loads unconditional on
+        // clamped indices, loop bounds scalar: counted s_waitcnt vmcnt): on the coarse levels a launch is ONE wave of tiles
+        // and its time is a tile's chain of L2 round trips - two fragments in flight left every other k-step waiting
+        u32x4 bw[BFM_RING];
         int ks = u0;
-        u32x4 b0 = loadw(pass, ks), b1 = loadw(pass, ks + 1);
-        for (; ks + 2 <= u1; ks += 2) {
-            mmb(ks, b0);
-            b0 = loadw(pass, ks + 2);
-            mmb(ks + 1, b1);
-            b1 = loadw(pass, ks + 3);
+#pragma unroll
+        for (int t = 0; t < BFM_RING; ++t) bw[t] = loadw(pass, ks + t);
+        for (; ks + BFM_RING <= u1; ks += BFM_RING) {
+#pragma unroll
+            for (int t = 0; t < BFM_RING; ++t) {
+                mmb(ks + t, bw[t]);
+                bw[t] = loadw(pass, ks + BFM_RING + t);
+            }
         }
-        if (ks < u1) mmb(ks, b0);
+#pragma unroll
+        for (int t = 0; t < BFM_RING - 1; ++t)
+            if (ks + t < u1) mmb(ks + t, bw[t]);
     };
     for (int pass = 0; pass < p.passes; ++pass) do_pass(pass);
     if (!want_gemm) return;

@@ -184,11 +184,17 @@ class FacetDenoiser:
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
         self.step_prologue = os.environ.get("FGC_NO_STEP_PROLOGUE", "0") != "1"
-        # bf16 storage: the weight-gradient GEMMs of all layers in one launch per kernel form at the end of the backward pass
-        # (every layer keeps an `r` of its own until then): there a layer's GEMM is mostly ramp and tail (100k facets: 1.095 ->
-        # 1.070 ms per step, 50k: 0.726 -> 0.705).  The fp32 GEMMs are matrix-bound and lose the shared `r` that stays in the
-        # Infinity Cache (1.761 -> 1.773 ms): a launch per layer.  FGC_GROUPED_DW=0 / 1 forces either.
-        self.grouped_dw = self.batched and os.environ.get("FGC_GROUPED_DW", "1" if dtype == "bf16" else "0") == "1"
+        # The weight-gradient GEMMs of several layers in ONE launch per kernel form at the end of the backward pass
+        # (FGC_CONV_DEFER_DW; a deferring layer keeps an `r` of its own until then).  bf16 storage: all layers - a layer's GEMM is
+        # mostly ramp and tail there (100k facets: 1.095 -> 1.070 ms per step, 50k: 0.726 -> 0.705).  fp32: the GEMMs are
+        # matrix-bound and grouping ALL of them loses the shared `r` whose lines stay in the Infinity Cache (1.761 -> 1.773 ms
+        # at 100k facets), so a layer defers only if its `r` is small (grouped_dw_max_r_bytes, bind_mesh decides per layer):
+        # on a 100k-facet mesh the level-2 layers and the up-convolutions' coarse rows, on a mesh of 25k facets or a shard of
+        # a strong-scaling run every layer - where a step is its launches, not its FLOPs.  FGC_GROUPED_DW=0 / 1: none / all.
+        self.grouped_dw_mode = os.environ.get("FGC_GROUPED_DW", "1" if dtype == "bf16" else "auto") if self.batched else "0"
+        self.grouped_dw_max_r_bytes = int(os.environ.get("FGC_GROUPED_DW_MAX_R_MB", "40")) << 20
+        self.grouped_dw = self.grouped_dw_mode == "1"       # (all layers; bind_mesh fills grouped_dw_layers)
+        self.grouped_dw_layers = frozenset()
         self.save_z = os.environ.get("FGC_NO_SAVE_Z", "0") != "1"
         # rows of the backward aggregate r padded to whole 128-byte lines (include/fgc.h: FGC_CONV_R_PAD); FGC_NO_R_PAD=1: the
         # packed rows of M*cout + 24 elements
@@ -320,10 +326,17 @@ class FacetDenoiser:
         B["dl"] = torch.zeros(max(max_dl, 1) * DL_LD, **f)
         B["dag"] = torch.empty(max(ns) * AG_LD, **f)
         B["r"] = torch.empty(max_r, **f)
-        if self.grouped_dw and gt is not None:
+        grouped = []
+        if self.grouped_dw_mode != "0" and gt is not None:
+            grouped.append(self.layers[0].name)   # (no r to keep apart: its GEMM can always wait for the grouped launch)
             for lay in self.layers[1:]:        # (the first layer has no r: its GEMM reads the saved aggregates and ds)
                 cnt = ns[lay.level] * rld(lay)
-                B["r_" + lay.name] = torch.empty((cnt + 1) // 2 if bf16 else cnt, **f)
+                # (a layer over a 4x-upsampled tensor runs on its n / 4 coarse rows - the pair form - unless refused)
+                used = cnt // 4 if (lay.shift == 2 and self.pairs) else cnt
+                if self.grouped_dw_mode == "1" or used * (2 if bf16 else 4) <= self.grouped_dw_max_r_bytes:
+                    B["r_" + lay.name] = torch.empty((cnt + 1) // 2 if bf16 else cnt, **f)
+                    grouped.append(lay.name)
+        self.grouped_dw_layers = frozenset(grouped)
         B["abs_part"] = torch.empty(self.L.fgc_mlp_num_partials(n0), **f)
         B["norm_scratch"] = torch.zeros(2 + self.L.fgc_norm_num_partials(n0), **f)
         B["loss"] = torch.zeros(2, **f)
@@ -835,7 +848,7 @@ class FacetDenoiser:
             d, io = M["descs"][name], M["ios"][name]
             lws = B["wsb_" + name]
             base = ((_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0) | rp
-            if self.batched and self.grouped_dw:
+            if self.batched and name in self.grouped_dw_layers:
                 base |= _lib.CONV_DEFER_DW
             if not self.sharded:
                 io.stages, io.flags = 0, base
@@ -895,9 +908,8 @@ class FacetDenoiser:
                 io.flags = rp
         if self.batched:
             A = M["arrays"]
-            if self.grouped_dw:      # (the staged calls of a sharded step leave other flags behind)
-                for io in M["ios"].values():
-                    io.flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW | rp
+            for lname in self.grouped_dw_layers:      # (the staged calls of a sharded step leave other flags behind)
+                M["ios"][lname].flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW | rp
             self._tag("bwd:reduce")
             _lib.check(L.fgc_conv_bwd_reduce(A["descs"], A["ios"], A["wsb"], A["count"], st), "reduce")
         if self.sharded:

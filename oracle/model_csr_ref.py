@@ -51,7 +51,7 @@ def custom_conv2d(x, graph, params, biasMask=True):
     g = x @ v.t()                                                   # model.py:80
     xp = torch.cat([x, torch.zeros(1, cin, dtype=x.dtype)], 0)      # the zero row of get_patches, model.py:383-384
     gp = torch.cat([g, torch.zeros(1, M, dtype=x.dtype)], 0)
-    q = torch.softmax(a[:, None, :] + gp[idx], dim=-1) * mask[:, :, None]      # [n, D, M]
+    q = torch.softmax(a[:, None, :] + gp[idx], dim=-1) * mask[:, :, None].to(x.dtype)      # [n, D, M]
     z = torch.bmm(q.transpose(1, 2), xp[idx])                       # [n, M, cin]
     Wr = W0.permute(0, 2, 1).reshape(M * cin, cout)                 # [(m, c), o]
     degf = deg.to(x.dtype)

@@ -443,7 +443,7 @@ def test_grouped_weight_gradient_launches_equal_the_per_layer_launches(dtype, mo
     for grouped in ("1", "0"):
         monkeypatch.setenv("FGC_GROUPED_DW", grouped)
         net = FacetDenoiser("cuda:0", seed=0, dtype=dtype).bind_mesh(x, adjs, gt=gt)
-        assert net.grouped_dw == (grouped == "1")
+        assert net.grouped_dw == (grouped == "1") and len(net.grouped_dw_layers) == (8 if grouped == "1" else 0)
         losses = [net.train_step(sample_ind=samp, R=Rm)[0].item() for _ in range(3)]
         out.append((losses, net.params.grad.clone(), net.params.theta.clone()))
     assert out[0][0] == out[1][0]
