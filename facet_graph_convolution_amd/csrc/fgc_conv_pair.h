@@ -6,6 +6,7 @@ namespace fgc {
 
 // does this descriptor run in the pair form (a function of the descriptor alone: workspace plans depend on it)
 bool pairs_ok(const fgc_conv_desc* d);
+bool pairs_graph_allowed(int64_t rows, int64_t n_pairs, int max_in_deg, int cout);   // fgc_conv_pairs_allowed
 // blocks (of four fine nodes) per workgroup of pair_fwd_kernel / pair_bwd_logits_kernel: one db / dc partial each
 int pair_blocks_per_wg(int cout);
 static inline int pair_num_wgs(const fgc_conv_desc* d) {

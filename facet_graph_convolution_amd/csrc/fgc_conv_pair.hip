@@ -26,6 +26,16 @@ constexpr int PQ_LD = 12;                 // floats per pair slot: q[0..8], [9] 
 constexpr int PQ_SLOTS = 16;              // pairs per chunk
 constexpr int PQ_STRIDE = PQ_SLOTS * PQ_LD + 4;   // (+4: consecutive blocks start on different banks)
 
+// the graph-dependent limits (fgc_conv_pairs_allowed): in-pairs against the edge slots of the data-gradient kernel, hc and dt
+// offsets against 32 bits, row ids of hc and dt against the 24-bit multiplies (dt also holds a facet-sharded rank's incoming
+// cross pairs: a margin)
+bool pairs_graph_allowed(int64_t rows, int64_t n_pairs, int max_in_deg, int cout) {
+    if (rows < 0 || n_pairs < 0 || cout <= 0 || max_in_deg < 0 || max_in_deg > KMAX) return false;
+    if ((uint64_t)rows * FGC_M * cout * 4 >= 0xFFFFFFFFull || (uint64_t)n_pairs * cout * 4 >= 0xFFFFFFFFull) return false;
+    if (rows >= (1 << 24) || n_pairs >= (1 << 24) - (1 << 20)) return false;
+    return true;
+}
+
 bool pairs_ok(const fgc_conv_desc* d) {
     if (opt(OPT_NO_PAIRS) == 1) return false;
     // (developer switches that take the eight-wave fast kernels away take the pair form's data-gradient kernel with them)
@@ -40,9 +50,7 @@ bool pairs_ok(const fgc_conv_desc* d) {
     // tiles) and "the rest of the rows, then every block" (no tile list); there is no interior / boundary split of blocks
     if (d->tile_list && d->n_tiles != 0) return false;
     const size_t rows = d->src_rows > 0 ? (size_t)d->src_rows : (size_t)(d->n >> 2);
-    if (rows * FGC_M * d->cout * 4 >= 0xFFFFFFFFull || (size_t)d->n_pairs * d->cout * 4 >= 0xFFFFFFFFull) return false;
-    // (row ids of hc and dt go through 24-bit multiplies; dt also holds a facet-sharded rank's incoming cross pairs: a margin)
-    if (rows >= (1u << 24) || d->n_pairs >= (1 << 24) - (1 << 20)) return false;
+    if (!pairs_graph_allowed((int64_t)rows, d->n_pairs, d->max_pair_in_deg, d->cout)) return false;
     if (((uintptr_t)d->x0 | (uintptr_t)d->hc) % 16) return false;
     return true;
 }
@@ -700,3 +708,6 @@ int launch_pair_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, fl
 }  // namespace fgc
 
 extern "C" int fgc_conv_uses_pairs(const fgc_conv_desc* d) { return fgc::pairs_ok(d) ? 1 : 0; }
+extern "C" int fgc_conv_pairs_allowed(int64_t rows, int64_t n_pairs, int32_t max_pair_in_deg, int32_t cout) {
+    return fgc::pairs_graph_allowed(rows, n_pairs, max_pair_in_deg, cout) ? 1 : 0;
+}

@@ -611,12 +611,13 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
                   fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));
     hipStream_t st = (hipStream_t)stream;
     // every 1024-wide product on the bf16 matrix pipe with three-term operand splits (fgc_mlp_bf16.hip) where the shape allows
-    if (mlp_bwd_split_ok(x, dx, cin, hidden, cout) && (uintptr_t)workspace % 16 == 0)
+    // (the dx kernel reads b1 in 16-byte pieces as well)
+    if (mlp_bwd_split_ok(x, dx, cin, hidden, cout) && (uintptr_t)workspace % 16 == 0 && (uintptr_t)b1 % 16 == 0)
         return launch_mlp_bwd_split(x, dy, n, cin, hidden, cout, W1, b1, W2, alpha, dx, dW1, db1, dW2, db2, workspace,
                                     (flags & FGC_MLP_PACKED) != 0, st);
     // (the operands fgc_conv_pack leaves are the split planes whenever the SHAPE takes the split path)
     FGC_CHECK_ARG(!(flags & FGC_MLP_PACKED) || !mlp_bwd_split_ok(nullptr, nullptr, cin, hidden, cout),
-                  "fgc_mlp_bwd: FGC_MLP_PACKED needs 16-byte aligned x, dx and workspace for this shape");
+                  "fgc_mlp_bwd: FGC_MLP_PACKED needs 16-byte aligned x, dx, b1 and workspace for this shape");
     const int kpad = mlp_bwd_kpad(cin);
     const int ctw = mlp_bwd_ctw(cin);
     const int gx = mlp_bwd_gx(n), gy = hidden / (64 * ctw);

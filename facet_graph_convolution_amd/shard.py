@@ -197,15 +197,13 @@ class ShardPlan:
         return np.concatenate([np.arange(P.lo, P.hi, dtype=np.int64), P.halo_ids])
 
 
-PAIR_KMAX = 24                          # edge slots of the data-gradient kernel (csrc: KMAX)
-PAIR_ID_LIMIT = (1 << 24) - (1 << 20)   # pair ids / coarse row ids go through 24-bit multiplies (fgc_conv_pair.hip: pairs_ok)
-
-
 def pair_form_allowed(PP, cout):
     """The job-wide half of fgc_conv_uses_pairs for a facet-sharded layer: the limits that depend on the graph, evaluated on
-    the GLOBAL pair graph (ShardPlan) so that every rank decides alike.  `cout`: the layer's output width."""
-    return (PP.global_max_in_deg <= PAIR_KMAX and PP.global_n_pairs < PAIR_ID_LIMIT and PP.global_rows < (1 << 24)
-            and PP.global_rows * 9 * cout * 4 < 0xFFFFFFFF and PP.global_n_pairs * cout * 4 < 0xFFFFFFFF)
+    the GLOBAL pair graph (ShardPlan) so that every rank decides alike - by the library's own function
+    (fgc_conv_pairs_allowed, which fgc_conv_uses_pairs applies to a descriptor's counts), not a copy of its constants.
+    `cout`: the layer's output width."""
+    from . import _lib
+    return bool(_lib.lib().fgc_conv_pairs_allowed(int(PP.global_rows), int(PP.global_n_pairs), int(PP.global_max_in_deg), int(cout)))
 
 
 class LocalPairGraph:

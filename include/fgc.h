@@ -42,8 +42,9 @@ extern "C" {
 
 /* ABI version of this header.  fgc_version() returns the value the LIBRARY was built with: a binding compares the two
  * (and the struct sizes below) before its first call.  102: fgc_set_option / fgc_get_option; fgc_conv_pack(extra),
- * flags of fgc_mlp_fwd / fgc_mlp_bwd and their _bf16 forms, larger fgc_conv_desc / fgc_conv_bwd_io (all since 101). */
-#define FGC_ABI_VERSION 102
+ * flags of fgc_mlp_fwd / fgc_mlp_bwd and their _bf16 forms, larger fgc_conv_desc / fgc_conv_bwd_io (all since 101).
+ * 103: fgc_conv_pairs_allowed; option NO_BFM. */
+#define FGC_ABI_VERSION 103
 
 const char* fgc_last_error(void);
 int fgc_version(void);
@@ -346,6 +347,11 @@ int fgc_conv_bwd_needs_exchange(const fgc_conv_desc* d, const fgc_conv_bwd_io* i
  * transposed pair graph and dt in its io.  Ranks of a facet-sharded job must agree on the answer per layer (they exchange
  * different tensors in the two forms): decide it on the GLOBAL pair graph (largest in-degree, pair counts), not per rank. */
 int fgc_conv_uses_pairs(const fgc_conv_desc* d);
+/* The GRAPH-dependent limits of the list above alone (in-pairs per coarse row, row and pair counts against the 24-bit row ids
+ * and 32-bit buffer offsets of the pair kernels), for counts that need not be a descriptor's: a facet-sharded job evaluates
+ * them on the GLOBAL pair graph so that every rank decides alike (fgc_conv_uses_pairs applies the same function to the
+ * descriptor's own counts).  rows: coarse source rows; 1 = allowed. */
+int fgc_conv_pairs_allowed(int64_t rows, int64_t n_pairs, int32_t max_pair_in_deg, int32_t cout);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);
 

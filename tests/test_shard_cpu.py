@@ -236,7 +236,8 @@ def test_pair_form_is_a_job_wide_decision():
     every rank has: the same answer on every rank, and 'no' as soon as any shard would have to refuse."""
     from facet_graph_convolution_amd.dataClasses import InferenceMesh
     from facet_graph_convolution_amd.meshgen import torus, flip_edges, add_noise
-    from facet_graph_convolution_amd.shard import pair_form_allowed, PAIR_KMAX
+    from facet_graph_convolution_amd.shard import pair_form_allowed
+    PAIR_KMAX = 24          # edge slots of the data-gradient kernel (csrc: KMAX); the library's own test is what decides
     V, F = torus(60, 50)
     F = flip_edges(F, 9000, seed=1)
     ds = InferenceMesh()
@@ -254,6 +255,15 @@ def test_pair_form_is_a_job_wide_decision():
             found = True                  # the case a per-rank decision gets wrong
             assert answers == [False, False]
     assert found, "the mesh no longer has a level on which the shards disagree: pick another seed"
+    # the decision IS the library's (fgc_conv_pairs_allowed, the function fgc_conv_uses_pairs applies to a descriptor's own
+    # counts): its limits, swept
+    from facet_graph_convolution_amd import _lib
+    allowed = _lib.lib().fgc_conv_pairs_allowed
+    for rows, pairs, indeg, cout, want in [(1000, 7000, 24, 64, 1), (1000, 7000, 25, 64, 0), (1 << 24, 7000, 8, 32, 0),
+                                           ((1 << 24) - 1, 7000, 8, 32, 0),        # rows * 9 * cout * 4 >= 2^32
+                                           (1000, (1 << 24) - (1 << 20), 8, 32, 0), (1000, (1 << 24) - (1 << 20) - 1, 8, 32, 1),
+                                           (3_000_000, 16_000_000, 8, 64, 0), (1_800_000, 14_000_000, 8, 64, 1), (-1, 5, 8, 32, 0)]:
+        assert allowed(rows, pairs, indeg, cout) == want, (rows, pairs, indeg, cout)
     # a regular mesh: allowed on every rank
     gh, _ = _graphs_of_torus()
     for r in range(2):
