@@ -495,6 +495,11 @@ struct RowJobs {
     int njobs;
 };
 constexpr int ROWJOB_ELEMS = 2048;      // dwords per workgroup
+// A facet-sharded step runs 23 of these per rank (14 packs, 9 unpacks: DESIGN.md section 7), each moving 0.1 - 1 MB: what they
+// cost is their dependent loads (job table -> row index -> row) and their instructions per element, not their bytes.  Rows
+// whose width is a multiple of four dwords (every activation and s row; the 12-dword d-logit rows too) between 16-byte
+// aligned buffers move as 16-byte pieces with 32-bit index arithmetic: one division per piece instead of a 64-bit division
+// per dword (round 6: 9.2 -> see DESIGN.md section 7 us per launch under the event timer).
 __global__ __launch_bounds__(EW_THREADS) void copy_rows_jobs_kernel(RowJobs J) {
     int j = 0;
 #pragma unroll 1
@@ -503,6 +508,28 @@ __global__ __launch_bounds__(EW_THREADS) void copy_rows_jobs_kernel(RowJobs J) {
     const fgc_row_job job = J.job[j];
     const int64_t total = (int64_t)job.rows * job.width;
     const int64_t e0 = (int64_t)(blockIdx.x - J.block0[j]) * ROWJOB_ELEMS;
+    const bool vec = (job.width & 3) == 0 && ((((uintptr_t)job.src) | ((uintptr_t)job.dst)) & 15) == 0 && total < (1ll << 31);
+    if (vec) {   // (uniform per workgroup)
+        const unsigned w4 = (unsigned)job.width >> 2;                     // 16-byte pieces per row
+        const unsigned p0 = (unsigned)(e0 >> 2), p1 = (unsigned)(min(e0 + ROWJOB_ELEMS, total) >> 2);
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(job.src);
+        f32x4* dst4 = reinterpret_cast<f32x4*>(job.dst);
+        // both pieces of a thread are requested before either is stored
+        unsigned pc[ROWJOB_ELEMS / 4 / EW_THREADS];
+        f32x4 v[ROWJOB_ELEMS / 4 / EW_THREADS];
+#pragma unroll
+        for (int t = 0; t < ROWJOB_ELEMS / 4 / EW_THREADS; ++t) {
+            pc[t] = p0 + threadIdx.x + t * EW_THREADS;
+            const unsigned pp = min(pc[t], p1 - 1);
+            const unsigned r = pp / w4, c = pp - r * w4;
+            const unsigned sr = job.idx ? (unsigned)job.idx[r] : r;
+            v[t] = src4[(size_t)sr * w4 + c];
+        }
+#pragma unroll
+        for (int t = 0; t < ROWJOB_ELEMS / 4 / EW_THREADS; ++t)
+            if (pc[t] < p1) dst4[pc[t]] = v[t];
+        return;
+    }
     for (int64_t e = e0 + threadIdx.x; e < min(e0 + ROWJOB_ELEMS, total); e += EW_THREADS) {
         const int64_t r = e / job.width;
         const int c = (int)(e - r * job.width);

@@ -231,6 +231,40 @@ def test_mlp_backward_at_a_coarse_head_size_is_exact_up_to_the_sign_of_zero_prea
         assert err < 5e-6, (name, err, "ambiguous units %d, moved %s" % (len(amb), moved))
 
 
+def test_copy_rows_jobs_moves_every_width_and_alignment():
+    """fgc_copy_rows_jobs (the pack / unpack launches of a facet-sharded step): several jobs in one launch - gathered by an
+    index list or consecutive, widths that are multiples of four dwords (16-byte pieces) and widths that are not, aligned and
+    misaligned buffers, a job of more than one workgroup with a ragged last piece, an empty job - bit for bit against torch."""
+    from facet_graph_convolution_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(0)
+    jobs, checks = [], []
+    keep = []
+    for rows, width, gather, mis_src, mis_dst in [(700, 64, True, 0, 0), (33, 12, True, 0, 0), (5, 3, True, 0, 0), (64, 32, False, 0, 0),
+                                                  (300, 16, True, 1, 0), (300, 16, True, 0, 1), (0, 32, True, 0, 0), (129, 128, False, 0, 0),
+                                                  (2049, 4, True, 0, 0)]:
+        n_src = max(rows * 2, 8)
+        src_all = torch.from_numpy(rs.normal(size=n_src * width + 4).astype(np.float32)).to(DEV)
+        dst_all = torch.full((max(rows, 1) * width + 4,), -7.0, device=DEV)
+        src = src_all[mis_src:mis_src + n_src * width].view(n_src, width)
+        dst = dst_all[mis_dst:mis_dst + max(rows, 1) * width].view(max(rows, 1), width)
+        idx = torch.from_numpy(rs.randint(0, n_src, size=max(rows, 1)).astype(np.int32)).to(DEV) if gather else None
+        keep += [src_all, dst_all, idx]
+        jobs.append((src, idx, dst, rows, width))
+        checks.append((src, idx, dst, rows, dst_all, mis_dst, width))
+    arr = (_lib.RowJob * len(jobs))()
+    for k, (src, idx, dst, rows, width) in enumerate(jobs):
+        arr[k].src, arr[k].idx, arr[k].dst = src.data_ptr(), (idx.data_ptr() if idx is not None else None), dst.data_ptr()
+        arr[k].rows, arr[k].width = rows, width
+    _lib.check(L.fgc_copy_rows_jobs(arr, len(jobs), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    for src, idx, dst, rows, dst_all, off, width in checks:
+        want = src[idx.long()[:rows]] if idx is not None else src[:rows]
+        assert torch.equal(dst[:rows], want), (rows, width)
+        # nothing outside the job's rows was written
+        assert (dst_all[:off] == -7.0).all() and (dst_all[off + rows * width:] == -7.0).all(), (rows, width)
+
+
 def test_elementwise_ops():
     from facet_graph_convolution_amd import ops
     from oracle import model_ref as R
