@@ -625,15 +625,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_logits_mfma_kernel(CorePara
 // same-box alternating runs): dconv1 at 100k facets 122.9 -> 116.6 us.  The 64-wide layers were tried and gained nothing
 // (77.5 -> 76.0 / 77.6 us): a half tile re-reads the whole packed operand from L2 - 446 MB per level-0 launch as fp32, half
 // as much again as three bf16 planes - and that stream, not the matrix pipe, is what those launches wait for.
-template <bool LONG, int OKG, int NT_ = 32, int NPW_ = 8, bool SPLIT = false>
-__global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : 4) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
+// QSR: edge slots per node of the soft-assignment table for the regular (!LONG) forms - 16, or 14 where the host knows that no
+// node has more edges (a closed triangle mesh's facet graph: 13): 1.5 KB less LDS per half tile, 32.6 KB - a FIFTH workgroup
+// per CU if the registers stay under 97 (the launch bound asks for five waves per SIMD then).  Round-5 review, candidate
+// "14-slot d-logits table"; measured in DESIGN.md section 10.
+template <bool LONG, int OKG, int NT_ = 32, int NPW_ = 8, bool SPLIT = false, int QSR = 16>
+__global__ __launch_bounds__((NT_ / NPW_) * 64, NT_ == 32 ? 2 : (QSR == 14 ? 5 : 4)) void conv_bwd_logits_deep_kernel(CoreParams p, LogitParams lp) {
+    static_assert(QSR == 16 || (QSR == 14 && NT_ == 16), "14 slots: the half-tile form");
     static_assert((NT_ == 32 && NPW_ == 8) || (NT_ == 16 && NPW_ == 4 && !LONG), "tile shapes");
     static_assert(!SPLIT || (NT_ == 16 && OKG == 2), "split dz GEMM: half tiles of the 32-wide layers");
     // (shadow the 32-node constants of the file)
     constexpr int TILE = NT_, NPW = NPW_, NWV = NT_ / NPW_, NTHREADS = NWV * 64, RT = NT_ / 16, LPN = NTHREADS / NT_;
     static_assert(NWV == 4, "four waves either way: the column-tile split and the dc sums below assume it");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int QS = LONG ? KMAX : 16;        // the host sends graphs with a degree above 16 to the LONG form
+    constexpr int QS = LONG ? KMAX : QSR;       // the host sends graphs with a degree above 16 to the LONG form
     const Smem s = carve(smem_raw, ZSTRIDE, QS, NT_);
     const int opad = OKG ? OKG * 16 : lp.opad;
     const int ostride = OKG ? OKG * 16 + 8 : lp.ostride;
@@ -2389,12 +2394,24 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, (conv_bwd_logits_deep_kernel<false, OKG_, NT, 4, true>),       \
                    dim3(cdiv(d->n, NT)), dim3(256), smem16, p, lp);                                                  \
     } while (0)
+                    // 14-slot table (option K1_QS14, degrees <= 14): a fifth workgroup per CU
+                    const bool qs14 = opt(OPT_K1_QS14) == 1 && d->max_deg > 0 && d->max_deg <= 14;
+                    const size_t smem14 = smem16 - (size_t)NT * (qnode_stride(16) - qnode_stride(14)) * 4;
+#define FGC_DEEP_HALF14(OKG_, SPLIT_)                                                                                \
+    do {                                                                                                             \
+        hipFuncSetAttribute((const void*)conv_bwd_logits_deep_kernel<false, OKG_, NT, 4, SPLIT_, 14>,                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem14);                                \
+        FGC_LAUNCH("conv_bwd_logits_deep_kernel", st, (conv_bwd_logits_deep_kernel<false, OKG_, NT, 4, SPLIT_, 14>), \
+                   dim3(cdiv(d->n, NT)), dim3(256), smem14, p, lp);                                                  \
+    } while (0)
                     if (k1_split(d)) {
                         // (the packed operand is in the split layout whatever the pointers: no other kernel can take it)
                         FGC_CHECK_ARG(al, "fgc_conv_bwd: ds must be 16-byte aligned (cout=%d)", cout);
-                        FGC_DEEP_HALF_SPLIT(2);
+                        if (qs14) FGC_DEEP_HALF14(2, true);
+                        else FGC_DEEP_HALF_SPLIT(2);
                     } else
                     if (cout == 32 && al) FGC_DEEP_HALF(2);
+                    else if (cout == 64 && al && qs14) FGC_DEEP_HALF14(4, false);
                     else if (cout == 64 && al) FGC_DEEP_HALF(4);
                     else if (cout == 128 && al && fuse_ds) FGC_DEEP_HALF(8);   // (only for its prologue: s and db in this launch)
                     else FGC_DEEP_HALF(0);
