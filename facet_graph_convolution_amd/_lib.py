@@ -35,7 +35,24 @@ class ConvDesc(C.Structure):
         ("pair_rowptr", C.c_void_p), ("pair_col", C.c_void_p), ("pair_mul", C.c_void_p),
         ("n_pairs", C.c_int32), ("max_pair_deg", C.c_int32), ("max_pair_in_deg", C.c_int32),
         ("hc", C.c_void_p),
+        # per-descriptor option overrides (include/fgc.h: fgc_option_override); HOST pointer
+        ("options", C.c_void_p), ("n_options", C.c_int32),
     ]
+
+
+class OptionOverride(C.Structure):
+    """struct fgc_option_override (include/fgc.h): one option value that holds for ONE descriptor."""
+    _fields_ = [("index", C.c_int32), ("reserved", C.c_int32), ("value", C.c_int64)]
+
+
+def option_overrides(**values):
+    """A ctypes array of fgc_option_override for ConvDesc.options (keep the array alive as long as the descriptor):
+    option_overrides(NO_PAIRS=1, W8_NT16=0).  Names as in fgc_option_name's enumeration."""
+    names = option_names()
+    arr = (OptionOverride * len(values))()
+    for k, (name, value) in enumerate(values.items()):
+        arr[k].index, arr[k].reserved, arr[k].value = names.index(name[4:] if name.startswith("FGC_") else name), 0, int(value)
+    return arr
 
 
 class RowJob(C.Structure):

@@ -87,6 +87,17 @@ enum Opt {
     OPT_COUNT
 };
 int64_t opt(Opt o);
+// per-descriptor overrides (fgc_conv_desc.options): every entry point that takes a descriptor opens a scope for the time it
+// works on that descriptor; opt() consults the calling thread's innermost scope first.  Nothing global is written.
+struct OptScope {
+    const void* prev_list;
+    int prev_n;
+    OptScope(const void* overrides /* fgc_option_override[] */, int n);
+    ~OptScope();
+    OptScope(const OptScope&) = delete;
+    OptScope& operator=(const OptScope&) = delete;
+};
+#define FGC_OPT_SCOPE(d) fgc::OptScope opt_scope__((d) ? (const void*)(d)->options : nullptr, (d) ? (d)->n_options : 0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -2097,6 +2097,7 @@ static void conv_param_jobs(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, c
 using namespace fgc;
 
 extern "C" size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d) {
+    FGC_OPT_SCOPE(d);
     if (!d) return 0;
     return plan_bwd(d, nullptr).bytes;
 }
@@ -2144,6 +2145,7 @@ static int launch_data(const CoreParams& p, const DataEpilogue& ep, bool vec4, s
 
 extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace,
                             size_t workspace_bytes, void* stream) {
+    FGC_OPT_SCOPE(d);
     int rc = validate_conv_desc(d, "fgc_conv_bwd");
     if (rc) return rc;
     FGC_CHECK_ARG(io != nullptr, "fgc_conv_bwd: null io");
@@ -2511,6 +2513,7 @@ extern "C" int fgc_conv_pack(const fgc_conv_desc* const* descs, const fgc_conv_b
     };
     for (int i = 0; i < count; ++i) {
         const fgc_conv_desc* d = descs[i];
+        FGC_OPT_SCOPE(d);      // (this layer's own option values, if its descriptor carries any)
         int rc = validate_conv_desc(d, "fgc_conv_pack");
         if (rc) return rc;
         const int cin = d->c0 + d->c1, cout = d->cout;
@@ -2598,6 +2601,7 @@ extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_
             const fgc_conv_desc* d = descs[i];
             const fgc_conv_bwd_io* io = ios[i];
             if (!io || !(io->flags & FGC_CONV_DEFER_DW)) continue;
+            FGC_OPT_SCOPE(d);
             rc = validate_conv_desc(d, "fgc_conv_bwd_reduce");
             if (rc) return rc;
             FGC_CHECK_ARG(bwd_ws[i], "fgc_conv_bwd_reduce: layer %d: null workspace", i);
@@ -2636,6 +2640,7 @@ extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_
     for (int i = 0; i < count; ++i) {
         const fgc_conv_desc* d = descs[i];
         const fgc_conv_bwd_io* io = ios[i];
+        FGC_OPT_SCOPE(d);
         rc = validate_conv_desc(d, "fgc_conv_bwd_reduce");
         if (rc) return rc;
         FGC_CHECK_ARG(io && bwd_ws[i] && io->dW0 && io->db && io->du && io->dc && io->dv,

@@ -254,6 +254,7 @@ static size_t packed_floats(const ConvGeom& g) { return (size_t)g.passes * g.kpa
 using namespace fgc;
 
 extern "C" size_t fgc_conv_workspace_bytes(const fgc_conv_desc* d) {
+    FGC_OPT_SCOPE(d);
     if (!d) return 0;
     const ConvGeom g = conv_geom(d->c0 + d->c1, d->cout);
     size_t b = align_up(packed_floats(g) * sizeof(float), 256);
@@ -342,6 +343,7 @@ static int launch_fwd(const CoreParams& p, const FwdEpilogue& ep, bool vec4, siz
 
 extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* y_pool, void* workspace,
                             size_t workspace_bytes, void* stream) {
+    FGC_OPT_SCOPE(d);
     int rc = validate_conv_desc(d, "fgc_conv_fwd");
     if (rc) return rc;
     FGC_CHECK_ARG(ag && y, "fgc_conv_fwd: null ag / y");

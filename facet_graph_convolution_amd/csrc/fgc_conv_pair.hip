@@ -707,7 +707,10 @@ int launch_pair_bwd_logits(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, fl
 
 }  // namespace fgc
 
-extern "C" int fgc_conv_uses_pairs(const fgc_conv_desc* d) { return fgc::pairs_ok(d) ? 1 : 0; }
+extern "C" int fgc_conv_uses_pairs(const fgc_conv_desc* d) {
+    FGC_OPT_SCOPE(d);
+    return fgc::pairs_ok(d) ? 1 : 0;
+}
 extern "C" int fgc_conv_pairs_allowed(int64_t rows, int64_t n_pairs, int32_t max_pair_in_deg, int32_t cout) {
     return fgc::pairs_graph_allowed(rows, n_pairs, max_pair_in_deg, cout) ? 1 : 0;
 }

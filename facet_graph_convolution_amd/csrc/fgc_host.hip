@@ -118,7 +118,21 @@ static void opt_init() {
         g_opt[i].store((e && *e) ? strtoll(e, nullptr, 10) : g_opt_table[i].def, std::memory_order_relaxed);
     }
 }
+static thread_local const fgc_option_override* tl_over = nullptr;
+static thread_local int tl_over_n = 0;
+OptScope::OptScope(const void* overrides, int n) : prev_list(tl_over), prev_n(tl_over_n) {
+    if (overrides && n > 0) {      // (a descriptor without a list leaves an enclosing scope in force)
+        tl_over = static_cast<const fgc_option_override*>(overrides);
+        tl_over_n = n;
+    }
+}
+OptScope::~OptScope() {
+    tl_over = static_cast<const fgc_option_override*>(prev_list);
+    tl_over_n = prev_n;
+}
 int64_t opt(Opt o) {
+    for (int i = 0; i < tl_over_n; ++i)
+        if (tl_over[i].index == (int)o) return tl_over[i].value;
     std::call_once(g_opt_once, opt_init);
     return g_opt[o].load(std::memory_order_relaxed);
 }

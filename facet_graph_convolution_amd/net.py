@@ -159,13 +159,18 @@ class _ConvLayer:
 
 
 class FacetDenoiser:
-    def __init__(self, device="cuda", multi_scale=False, in_channels=6, seed=0, dtype="f32"):
+    def __init__(self, device="cuda", multi_scale=False, in_channels=6, seed=0, dtype="f32", options=None):
         if not torch.cuda.is_available():
             raise RuntimeError("FacetDenoiser needs an MI355X (no CPU fallback)")
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16' (storage of the activations; weights stay fp32)")
         self.dtype = dtype
         self.L = _lib.lib()
+        # options: {name: value} of library options (fgc_option_name) that hold for THIS network's conv layers only - they
+        # travel in every layer's descriptor (fgc_conv_desc.options), the process-level table (fgc_set_option) is not touched:
+        # two networks in one process can run different kernel forms.  (The MLP entry points take no descriptor: their
+        # options stay process-level.)
+        self.option_overrides = _lib.option_overrides(**options) if options else None
         self.device = torch.device(device)
         self.multi_scale = multi_scale
         self.in_channels = in_channels
@@ -207,7 +212,7 @@ class FacetDenoiser:
         self.fused_loss = os.environ.get("FGC_NO_FUSED_LOSS", "0") != "1"
         # the two up-convolutions on their coarse source rows (pair form, include/fgc.h); library option NO_PAIRS = 1
         # (fgc_set_option; initial value from FGC_NO_PAIRS): the fine form
-        self.pairs = _lib.get_option("NO_PAIRS") != 1
+        self.pairs = self._option("NO_PAIRS") != 1
         # parameter slots
         k = 0
         self.slot = {}
@@ -386,6 +391,8 @@ class FacetDenoiser:
             if bf16:
                 d.flags |= _lib.CONV_BF16
             layer_flags[lay.name] = d.flags
+            if self.option_overrides is not None:
+                d.options, d.n_options = C.addressof(self.option_overrides), len(self.option_overrides)
             descs[lay.name] = d
             # a layer over a 4x-upsampled input (the two up-convolutions) runs on its COARSE source rows: the pair graph
             # of its level + the table of transformed coarse rows (include/fgc.h: fgc_conv_desc.pair_rowptr)
@@ -406,7 +413,7 @@ class FacetDenoiser:
                 d.hc = hc.data_ptr()
                 if self.L.fgc_conv_uses_pairs(C.byref(d)):
                     B["hc_" + lay.name] = hc
-                elif plan is not None and not any(_lib.get_option(k) == 1 for k in ("NO_PAIRS", "NO_W8", "NO_W8FAST")):
+                elif plan is not None and not any(self._option(k) == 1 for k in ("NO_PAIRS", "NO_W8", "NO_W8FAST")):
                     # the job-wide test passed and the switches are on: a rank that still refuses would leave the others
                     # waiting for messages of the pair form
                     raise RuntimeError("layer %s: the pair form is allowed job-wide but refused on this rank (n_pairs=%d, "
@@ -553,6 +560,15 @@ class FacetDenoiser:
     # behind it: conv1 -> {h1, p1}, conv2 -> {h2, p2}), 7 backward (a layer's s rows and cross-edge d-logits together),
     # two scalar all-reduces for normalizeTensor and its gradient, one all-reduce of gradient + loss sum: 17.
     # ------------------------------------------------------------------------------------------
+    def _option(self, name):
+        """The value a library option has for THIS network: its own override (options=...) or the process-level value."""
+        if self.option_overrides is not None:
+            names = _lib.option_names()
+            for o in self.option_overrides:
+                if names[o.index] == name:
+                    return int(o.value)
+        return _lib.get_option(name)
+
     def _st(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

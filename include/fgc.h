@@ -43,7 +43,7 @@ extern "C" {
 /* ABI version of this header.  fgc_version() returns the value the LIBRARY was built with: a binding compares the two
  * (and the struct sizes below) before its first call.  102: fgc_set_option / fgc_get_option; fgc_conv_pack(extra),
  * flags of fgc_mlp_fwd / fgc_mlp_bwd and their _bf16 forms, larger fgc_conv_desc / fgc_conv_bwd_io (all since 101).
- * 103: fgc_conv_pairs_allowed; option NO_BFM. */
+ * 103: fgc_conv_pairs_allowed; options NO_BFM, K1_QS14; fgc_conv_desc.options / n_options (per-descriptor option overrides). */
 #define FGC_ABI_VERSION 103
 
 const char* fgc_last_error(void);
@@ -179,6 +179,18 @@ int fgc_edge_map(const uint32_t* faces_h, int32_t nf, int32_t nv, int32_t max_ed
  * act: 0 = none, 1 = leaky ReLU with `alpha` (model.py:828-830) applied to y.
  * y_pool (optional, may be NULL): max over each 4 consecutive rows of y (model.py:779-788).
  * ---------------------------------------------------------------------------------- */
+/* One per-call override of a process-level option (fgc_set_option): `index` is the option's position in fgc_option_name's
+ * enumeration.  A descriptor that carries a list (fgc_conv_desc.options) runs EVERY entry point it is passed to - workspace
+ * queries, fgc_conv_uses_pairs, fgc_conv_pack, forward, backward, fgc_conv_bwd_reduce - with these values instead of the
+ * process-level ones, for that descriptor only and on the calling thread only: two networks in one process (or two layers of
+ * one network) can take different kernel forms without touching global state.  The same caveat as for fgc_set_option holds per
+ * descriptor: keep a descriptor's list the same from its plan / pack calls to the calls that consume their results. */
+typedef struct fgc_option_override {
+    int32_t index;
+    int32_t reserved;       /* 0 */
+    int64_t value;
+} fgc_option_override;
+
 typedef struct fgc_conv_desc {
     int32_t n;              /* nodes of this level */
     int32_t nnz;            /* edges */
@@ -227,6 +239,8 @@ typedef struct fgc_conv_desc {
                                     call transforms the source rows [proj_row0, proj_row0 + proj_rows) only; with a tile_list
                                     of no tiles it stops there, without a tile_list it then computes every block (a
                                     facet-sharded caller: owned rows while the halo parents travel, then the rest) */
+    const fgc_option_override* options;  /* HOST pointer, [n_options]: per-descriptor option values (see above); NULL = none */
+    int32_t n_options;
 } fgc_conv_desc;
 
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */

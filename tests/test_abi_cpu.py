@@ -80,3 +80,50 @@ def test_options_are_a_table_not_the_environment(monkeypatch):
     assert L.fgc_set_option(b"NO_SUCH_OPTION", 1) == -22 and b"NO_SUCH_OPTION" in L.fgc_last_error()
     n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(REPO, "facet_graph_convolution_amd", "csrc", "*.h*")))
     assert n_getenv == 1, n_getenv
+
+
+def test_a_descriptor_can_carry_its_own_option_values():
+    """fgc_conv_desc.options (round 6; the round-5 review's 'process-level options are global mutable state'): a list of
+    fgc_option_override in a descriptor holds for the calls made WITH that descriptor, on the calling thread, and leaves the
+    process-level table alone - two descriptors in one process answer fgc_conv_uses_pairs differently at the same time, also
+    from two threads at once."""
+    import ctypes as C
+    import threading
+    L = _lib.lib()
+    assert L.fgc_struct_size(0) == C.sizeof(_lib.ConvDesc)
+
+    def pair_desc():
+        d = _lib.ConvDesc()
+        fake = 4096                                   # (never dereferenced by the host-side test of the shape)
+        d.n, d.nnz, d.rowptr, d.col, d.x0 = 64, 256, fake, fake, fake
+        d.c0, d.c1, d.shift, d.cout = 64, 0, 2, 32
+        d.W0 = d.b = d.u = d.c = d.v = fake
+        d.pair_rowptr = d.pair_col = d.pair_mul = d.hc = fake
+        d.n_pairs, d.max_pair_deg, d.max_pair_in_deg, d.max_deg = 100, 8, 8, 13
+        return d
+
+    plain, fine = pair_desc(), pair_desc()
+    over = _lib.option_overrides(NO_PAIRS=1)
+    fine.options, fine.n_options = C.addressof(over), len(over)
+    old = _lib.get_option("NO_PAIRS")
+    assert old == 0
+    assert L.fgc_conv_uses_pairs(C.byref(plain)) == 1 and L.fgc_conv_uses_pairs(C.byref(fine)) == 0
+    assert _lib.get_option("NO_PAIRS") == old            # nothing global was written
+    # ... and the process-level switch still rules a descriptor without a list
+    with _lib.options(NO_PAIRS=1):
+        assert L.fgc_conv_uses_pairs(C.byref(plain)) == 0
+        back = _lib.option_overrides(NO_PAIRS=0)
+        on = pair_desc()
+        on.options, on.n_options = C.addressof(back), 1
+        assert L.fgc_conv_uses_pairs(C.byref(on)) == 1
+    # two threads, two descriptors, at the same time: the scope is per thread
+    out = {}
+
+    def ask(name, d):
+        out[name] = [L.fgc_conv_uses_pairs(C.byref(d)) for _ in range(20000)]
+    ts = [threading.Thread(target=ask, args=("plain", plain)), threading.Thread(target=ask, args=("fine", fine))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert set(out["plain"]) == {1} and set(out["fine"]) == {0}
+    with pytest.raises(ValueError):
+        _lib.option_overrides(NO_SUCH_OPTION=1)

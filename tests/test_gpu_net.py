@@ -450,6 +450,43 @@ def test_grouped_weight_gradient_launches_equal_the_per_layer_launches(dtype, mo
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
 
 
+def test_two_networks_in_one_process_run_different_kernel_forms():
+    """FacetDenoiser(options=...): per-network library options travel in every layer's descriptor (fgc_conv_desc.options), the
+    process-level table stays untouched.  One network in the pair form and one in the fine form of the up-convolutions, and
+    one with the 32-node conv kernels, side by side and interleaved step by step: each keeps its own form, all agree."""
+    from facet_graph_convolution_amd import _lib
+    from facet_graph_convolution_amd.net import FacetDenoiser
+    from facet_graph_convolution_amd.dataClasses import TrainingSet
+    from facet_graph_convolution_amd.meshgen import icosphere, add_noise
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    V, F = icosphere(4)
+    ds = TrainingSet()
+    ds.addMeshWithGT(add_noise(V, F), F, V, seed=0)
+    x, adjs, gt = ds.in_list[0], ds.adj_list[0], ds.gt_list[0]
+    samp = np.random.RandomState(2).randint(x.shape[1], size=4000)
+    Rm = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    before = {n: _lib.get_option(n) for n in ("NO_PAIRS", "W8_NT16")}
+    nets = [FacetDenoiser("cuda:0", seed=0).bind_mesh(x, adjs, gt=gt),
+            FacetDenoiser("cuda:0", seed=0, options={"NO_PAIRS": 1}).bind_mesh(x, adjs, gt=gt),
+            FacetDenoiser("cuda:0", seed=0, options={"W8_NT16": 0}).bind_mesh(x, adjs, gt=gt)]
+    assert set(nets[0].pair_dims()) == {"upconv1", "upconv2"} and nets[1].pair_dims() == {} and len(nets[2].pair_dims()) == 2
+    for n in nets:
+        n.set_samples(samp)
+        n.set_rotation(Rm)
+    for _ in range(2):                       # interleaved: no network's form leaks into another's calls
+        for n in nets:
+            n.forward_backward(rotate=True)
+    torch.cuda.synchronize()
+    assert {n: _lib.get_option(n) for n in before} == before
+    ref, names = nets[0], _lib.option_names()
+    for other in nets[1:]:
+        assert abs(other.buffers["loss"][0].item() - ref.buffers["loss"][0].item()) < 1e-5 * abs(ref.buffers["loss"][0].item())
+        label = "per-network options %s vs the default forms" % {names[o.index]: o.value for o in other.option_overrides}
+        check_gradients(ref.params.spec, other.params.grads, [g.clone() for g in ref.params.grads], 2e-5, label)
+    # the 32-node form really ran: bitwise it cannot equal the half-tile form's sums in every tensor
+    assert any(not torch.equal(a, b) for a, b in zip(nets[2].params.grads, ref.params.grads))
+
+
 def test_pool_gradient_folded_into_the_conv_backward_equals_the_separate_pass():
     """fgc_conv_bwd_io.pool_y / pool_dy: the gradient of the 4:1 max pooling behind conv1 and conv2 is added to dy inside
     stage 1 of those layers (the d-logits kernel's prologue for conv2, ds_db_kernel for the narrow first layer) instead of
