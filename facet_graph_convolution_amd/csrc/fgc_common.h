@@ -79,7 +79,8 @@ struct ProfScope {
     X(NO_MLP_BWD_SPLIT, 0)    /* 1: ... the backward only */                                                                     \
     X(NO_K1_SPLIT, 0)         /* 1: the dz GEMM of the fp32 d-logits kernel (half tiles, 32 outputs) on the fp32 MFMA */                \
     X(NO_BFM, 0)              /* 1: bf16 conv kernels aggregate on the vector ALU (conv_w8_kernel<BF>), not the matrix pipe */    \
-    X(K1_QS14, 0)             /* 1: fp32 half-tile d-logits kernel with a 14-slot table where degrees allow (5 workgroups / CU) */
+    X(K1_QS14, 0)             /* 1: fp32 half-tile d-logits kernel with a 14-slot table where degrees allow (5 workgroups / CU) */  \
+    X(W8_HALF2, 0)            /* 1: fp32 half-tile forward conv with the aggregate tile in two halves (6 workgroups / CU) */
 enum Opt {
 #define FGC_OPT_ENUM(name, def) OPT_##name,
     FGC_OPTION_LIST(FGC_OPT_ENUM)

@@ -118,14 +118,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 // resident per CU at the same 16 waves, and twice the packed-weight traffic per node).  NT = 16 needs npad <= 64.
 // EROW (data gradient of the pair form, fgc_conv_pair.hip): the gathered operand has one row per EDGE of the forward graph
 // (the per-pair dt rows), so the row of slot k is the edge id p.eid[e], not the neighbour col[e] >> shift.
-template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32, bool EROW = false>
-__global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+// H2 (forward, fp32, half tiles; option W8_HALF2): the aggregate tile is written and consumed in TWO halves of the assignment
+// index - assignments 0-4 (160 k), then 5-8 (128 k) - so it needs 10.75 KB instead of 18.9: 23.4 KB per workgroup, a SIXTH
+// resident workgroup per CU if the registers stay at 80 (the launch bound asks for six waves per SIMD), for two more
+// barriers per pass.  Round-3 candidate "resident workgroups are the currency"; measured in DESIGN.md section 10.
+template <bool DATA, bool FAST, int QS, bool BF = false, int NT = 32, bool EROW = false, bool H2 = false>
+__global__ __launch_bounds__(NT * 16, H2 ? 6 : 4) void conv_w8_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+    static_assert(!H2 || (!DATA && !BF && NT == 16), "two-half aggregate tile: the fp32 forward kernel on half tiles");
+    constexpr int ZS = H2 ? 168 : ZSTRIDE;             // floats per node of the (half) aggregate tile: == 8 mod 16
     static_assert(!BF || FAST, "the bf16 form exists for the fast shapes only");
     static_assert(!EROW || (DATA && FAST), "rows by edge id: the data-gradient kernel's fast shapes");
     static_assert(NT == 32 || (NT == 16 && FAST && QS == 16), "half tiles: the pipelined 16-slot form only");
     constexpr int TILE = NT, RT = NT / 16, NW = NT / 4, LW = NT == 32 ? 3 : 2, W8_THREADS = NT * 16;   // (shadow the 32-node constants)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZSTRIDE, QS, NT);
+    const Smem s = carve(smem_raw, BF ? ZSTRIDE_BF / 2 : ZS, QS, NT);
     constexpr int SPL = QS / 16 + (QS % 16 ? 1 : 0);   // slots per softmax lane: k = kl + 16 * t
     constexpr bool PIPE = FAST && QS == 16;            // rows requested one phase ahead (gather_rows / fma_rows)
     // DATA: the node's da | dg rows for the epilogue live in the two spare floats of the node's first nine edge slots
@@ -430,6 +436,76 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             }
             if (!want_gemm) return;
         }
+        // fp32: the k-groups [gl, gh) of this pass against the tile whose first column is k-group gz
+        auto gphase32 = [&](int gl, int gh, int gz) {
+        auto loadw = [&](int pass_, int u) {
+            const int uu = min(u, gh - 1);
+            if (FGC_KO & 512) return u32x4{(unsigned)uu, (unsigned)pass_, 0x3f800000u, 0x3f000000u};   // (no packed-weight loads)
+            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane, (unsigned)(pass_ * UPP + uu) * w_unit, 0));
+        };
+        // A fragments: one ds_read_b128 per row tile (4 k of a 16-deep group)
+        auto loada = [&](int g, f32x4 (&a)[RT]) {
+            const int gg = min(g, gh - 1) - gz;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * ZS + gg * 16 + lq * 4);
+        };
+        auto mm = [&](const f32x4 (&a)[RT], const u32x4& bw) {
+            const f32x4 b = __builtin_bit_cast(f32x4, bw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (FGC_KO & 1) asm volatile("" ::"v"(a[r][t]), "v"(b[t]));
+                    else acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r], 0, 0, 0);
+                }
+        };
+            int g = gl;
+            u32x4 b0 = loadw(pass, g), b1 = loadw(pass, g + 1), b2 = loadw(pass, g + 2), b3 = loadw(pass, g + 3);
+            f32x4 a0[RT], a1[RT];
+            loada(g, a0);
+            for (; g + 4 <= gh; g += 4) {
+                loada(g + 1, a1);
+                mm(a0, b0);
+                b0 = loadw(pass, g + 4);
+                loada(g + 2, a0);
+                mm(a1, b1);
+                b1 = loadw(pass, g + 5);
+                loada(g + 3, a1);
+                mm(a0, b2);
+                b2 = loadw(pass, g + 6);
+                loada(g + 4, a0);
+                mm(a1, b3);
+                b3 = loadw(pass, g + 7);
+            }
+            if (g < gh) {
+                loada(g + 1, a1);
+                mm(a0, b0);
+            }
+            if (g + 1 < gh) {
+                loada(g + 2, a0);
+                mm(a1, b1);
+            }
+            if (g + 2 < gh) mm(a0, b2);
+        };
+        if constexpr (H2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                constexpr int M0[2] = {0, 5}, NM[2] = {5, 4};
+                if (pass > 0 || h > 0) __syncthreads();  // the previous half's MFMA reads of the tile are done
+                float* zr = s.ztile + (size_t)node * ZS + 2 * cl;
+#pragma unroll
+                for (int m = 0; m < NM[h]; ++m) *reinterpret_cast<f32x2*>(zr + m * KC) = z[M0[h] + m];
+                __syncthreads();
+                if (FGC_KO & 8) continue;
+                // this half's k-groups (10, then 8), split over the k-parts like a whole pass
+                const int gb = M0[h] * 2, ng = NM[h] * 2;
+                const int gl = __builtin_amdgcn_readfirstlane(gb + ((ng * kpart) >> (LW - nsh)));
+                const int gh = __builtin_amdgcn_readfirstlane(gb + ((ng * (kpart + 1)) >> (LW - nsh)));
+                gphase32(gl, gh, gb);
+            }
+            return;
+        }
         if (pass > 0) __syncthreads();  // previous pass' MFMA reads of ztile are done
         if constexpr (BF) {
             unsigned* zr = reinterpret_cast<unsigned*>(s.ztile) + (size_t)node * (ZSTRIDE_BF / 2) + cl;
@@ -443,23 +519,6 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
         __syncthreads();
         // ---------------- phase G: acc[32 x 16] += ztile[32 x k-part] * Wp[k-part x 16]
         if (FGC_KO & 8) return;
-        // A fragments: one ds_read_b128 per row tile (fp32: 4 k of a 16-deep group, bf16: 8 k of a 32-deep step)
-        auto loada = [&](int g, f32x4 (&a)[RT]) {
-            const int gg = min(g, u1 - 1);
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-                a[r] = *reinterpret_cast<const f32x4*>(s.ztile + (size_t)(r * 16 + lr) * ZSTRIDE + gg * 16 + lq * 4);
-        };
-        auto mm = [&](const f32x4 (&a)[RT], const u32x4& bw) {
-            const f32x4 b = __builtin_bit_cast(f32x4, bw);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    if (FGC_KO & 1) asm volatile("" ::"v"(a[r][t]), "v"(b[t]));
-                    else acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[t], acc[r], 0, 0, 0);
-                }
-        };
         const char* zb = reinterpret_cast<const char*>(s.ztile);
         auto mmb = [&](int ks, const u32x4& b) {
 #pragma unroll
@@ -481,33 +540,7 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_w8_kernel(CoreParams p, FwdEp
             }
             if (ks < u1) mmb(ks, b0);
         } else {
-            int g = u0;
-            u32x4 b0 = loadw(pass, g), b1 = loadw(pass, g + 1), b2 = loadw(pass, g + 2), b3 = loadw(pass, g + 3);
-            f32x4 a0[RT], a1[RT];
-            loada(g, a0);
-            for (; g + 4 <= u1; g += 4) {
-                loada(g + 1, a1);
-                mm(a0, b0);
-                b0 = loadw(pass, g + 4);
-                loada(g + 2, a0);
-                mm(a1, b1);
-                b1 = loadw(pass, g + 5);
-                loada(g + 3, a1);
-                mm(a0, b2);
-                b2 = loadw(pass, g + 6);
-                loada(g + 4, a0);
-                mm(a1, b3);
-                b3 = loadw(pass, g + 7);
-            }
-            if (g < u1) {
-                loada(g + 1, a1);
-                mm(a0, b0);
-            }
-            if (g + 1 < u1) {
-                loada(g + 2, a0);
-                mm(a1, b1);
-            }
-            if (g + 2 < u1) mm(a0, b2);
+            gphase32(u0, u1, 0);
         }
     };
     for (int pass = 0; pass < p.passes; ++pass) do_pass(pass);
@@ -646,6 +679,15 @@ static int launch_w8f(const CoreParams& p, const FwdEpilogue& fe, const DataEpil
             const size_t zrow = BF ? (size_t)ZSTRIDE_BF * 2 : (size_t)ZSTRIDE * 4;
             size_t smem16 = NT * zrow + (size_t)NT * qnode_stride(16) * 4 + (2 * NT + 4) * 4 + 64;
             if (DATA) smem16 += (size_t)opt(OPT_W8_DATA_SMEM_PAD);   // (developer knob: fewer resident workgroups)
+            if constexpr (!DATA && !BF && !EROW) {
+                if (opt(OPT_W8_HALF2) == 1) {   // aggregate tile in two halves: 23.4 KB, six workgroups per CU
+                    const size_t smem_h2 = smem16 - (size_t)NT * (ZSTRIDE - 168) * 4;
+                    FGC_LAUNCH("conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT, EROW, true>), dim3(2 * core_grid(p)),
+                               dim3(NT * 16), smem_h2, p, fe, de);
+                    FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles, two-half aggregate tile)");
+                    return FGC_OK;
+                }
+            }
             FGC_LAUNCH(DATA ? "conv_w8_kernel<data>" : "conv_w8_kernel<fwd>", st, (conv_w8_kernel<DATA, FAST, QS, BF, NT, EROW>),
                        dim3(2 * core_grid(p)), dim3(NT * 16), smem16, p, fe, de);
             FGC_CHECK_LAUNCH("conv_w8_kernel (half tiles)");
