@@ -29,30 +29,36 @@ def main():
 
     lines = []
     roof = prof["roofline"]
-    lines.append("Reported family of bench.py (largest summed time per step): %s; reported through its launch with the most "
-                 "algorithmic work: %s" % (roof["family"], roof["kernel"]))
+    lines.append("Launch bench.py's `roofline` reports (%s): %s; best launch of its family: %s" % (
+        roof.get("selected_by", "largest summed time per step of its family"), roof["kernel"],
+        (roof.get("family_best") or {}).get("kernel")))
     lines.append("command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps %d --warmup %d --repeats 5   "
                  "(profiles/%s_rocprofv3_kernel_stats.csv, profiles/%s_bench_under_rocprofv3.json)"
                  % (prof["steps"], prof["warmup"], tag, tag))
-    # the forward conv launches of level 0: the fp32 forward instantiation (<DATA = false, FAST, QS = 16, BF = false, ...>; the
-    # bf16 networks of the line's `also` object launch the BF = true one on the same grid) on its largest grid = dconv1 (upconv1
-    # runs in the pair form since round 4)
-    fwd = [r for r in rows if "conv_w8_kernel<false, true, 16, false" in r["Kernel_Name"].replace("(bool)0", "false").replace("(bool)1", "true")]
-    if not fwd:
-        fwd = [r for r in named("conv_w8_kernel<false")]
-    if fwd:
-        gmax = max(int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]) for r in fwd)
-        big = [r for r in fwd if (int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"])) == gmax]
-        d1 = [r["_d"] for r in big]
-        u1 = []
+    # the trace rows of the reported launch: the kernel's instantiation(s) by name, on the largest grid they run on (= the
+    # level-0 layer; the only level-0 layer in the fine form is dconv1 since round 4).  fp32 instantiations only: the bf16
+    # networks of the line's `also` object launch other kernels.
+    norm = lambda k: k.replace("(bool)0", "false").replace("(bool)1", "true")
+    kname = roof["kernel"].split("/", 1)[1]
+    pick = {"conv_bwd_logits_deep_kernel": lambda k: "conv_bwd_logits_deep_kernel" in k,
+            "conv_w8_kernel<fwd>": lambda k: "conv_w8_kernel<false, true, 16, false" in norm(k),
+            "conv_w8_kernel<data>": lambda k: "conv_w8_kernel<true, true, 16, false" in norm(k),
+            "mlp_bwd_kernel<w>": lambda k: "mlp_bwd_w_split_kernel" in k,
+            "mlp_bwd_kernel<dx>": lambda k: "mlp_bwd_dx_split_kernel" in k,
+            "mlp_fwd_kernel": lambda k: "mlp_fwd_split_kernel" in k}.get(kname, lambda k: kname.split("<")[0] in k)
+    sel = [r for r in rows if pick(r["Kernel_Name"])]
+    grid = lambda r: int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"])
+    if sel:
+        gmax = max(grid(r) for r in sel)
+        d1 = [r["_d"] for r in sel if grid(r) == gmax]
         lines.append("  hipEvents inside bench.py (fgc_profile_*, %d steps), rocprofv3 attached      avg %.2f us"
                      % (prof["steps"], roof["avg_kernel_us"]))
-        lines.append("  rocprofv3 --kernel-trace, same command, the %d dconv1 forward launches     avg %.2f us (min %.2f, max %.2f)"
+        lines.append("  rocprofv3 --kernel-trace, same command, the %d launches of that kernel on its largest grid   avg %.2f us (min %.2f, max %.2f)"
                      % (len(d1), avg(d1), min(d1), max(d1)))
-        if u1:
-            lines.append("  (upconv1 forward, same grid: avg %.2f us over %d)" % (avg(u1), len(u1)))
         lines.append("  hipEvents, no profiler, default arguments (profiles/%s_bench.json)        avg %.2f us"
                      % (tag, dflt["roofline"]["avg_kernel_us"]))
+    else:
+        lines.append("  (no trace rows matched %s)" % kname)
     kern = prof.get("kernels", {})
     other = []
     for sub, label, key in (("mlp_bwd_kernel", "mlp_bwd_kernel", "bwd:mlp/mlp_bwd_kernel"),

@@ -29,6 +29,11 @@ def short(k):
     return k.split("(")[0]
 
 
+def is_fwd_conv(s):
+    # (conv_bfm_kernel: the bf16 kernels with the aggregation on the matrix pipe; same role, same profile key)
+    return s.startswith("conv_w8_kernel<false") or s.startswith("conv_bfm_kernel<false")
+
+
 def label(names):
     """tag/kernel key (as bench.py prints them) for every dispatch of ONE step.  The schedule is fixed: a forward layer
     starts with its logit-table launch (proj_mfma_kernel, or pair_transform_kernel for a layer in the pair form), a backward
@@ -48,12 +53,12 @@ def label(names):
             if base in ("proj_mfma_kernel", "proj_narrow_kernel", "pair_transform_kernel", "pair_transform_bf16_kernel"):
                 fi += 1
                 started = True
-            elif s.startswith("conv_w8_kernel<false") or base in ("pair_fwd_kernel", "conv_narrow_fwd_mma_kernel", "conv_narrow_fwd_kernel"):
+            elif is_fwd_conv(s) or base in ("pair_fwd_kernel", "conv_narrow_fwd_mma_kernel", "conv_narrow_fwd_kernel"):
                 if not started:      # (the first layer's table can come with the step's housekeeping launch)
                     fi += 1
                 started = False
             lay = FWD[min(max(fi, 0), 7)]
-            if s.startswith("conv_w8_kernel<false"):
+            if is_fwd_conv(s):
                 key = "fwd:%s/conv_w8_kernel<fwd>" % lay
             elif base.startswith("pair_transform"):
                 key = "fwd:%s/pair_transform_kernel" % lay
@@ -65,7 +70,7 @@ def label(names):
             if base.startswith("conv_bwd_logits") or base == "pair_bwd_logits_kernel" or base.startswith("conv_narrow_bwd"):
                 bi += 1
             lay = BWD[min(max(bi, 0), 7)]
-            if s.startswith("conv_w8_kernel<true"):
+            if s.startswith("conv_w8_kernel<true") or s.startswith("conv_bfm_kernel<true"):
                 key = "bwd:%s/conv_w8_kernel<data>" % lay
             elif base.startswith("conv_bwd_logits"):
                 key = "bwd:%s/%s" % (lay, base)
