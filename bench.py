@@ -759,11 +759,14 @@ def main(argv=None):
             if layer == "reduce" and "gemm_tn" in kern:
                 # the weight-gradient GEMMs of all layers, grouped into one launch per kernel form at the end of the backward
                 # pass (FGC_CONV_DEFER_DW): the work of all of them over these launches; pair layers with what they execute
+                # (fp32 groups only the layers whose r is small - net.grouped_dw_layers -, bf16 all of them)
+                in_group = getattr(net_, "grouped_dw_layers", None) or set(dims)
                 dw = {name: (pair_kernel_flops("gemm_tn", pdims[name][0], pdims[name][1], dims[name][2], dims[name][3])
-                             if name in pdims else kernel_flops("bwd_weight", *dims[name])) for name in dims}
+                             if name in pdims else kernel_flops("bwd_weight", *dims[name])) for name in dims if name in in_group}
                 fl = sum(dw.values()) / max(cnt / steps_, 1.0)
                 for name in pdims:
-                    pair_form[name]["executed_gflop"] += dw[name] / 1e9
+                    if name in dw:
+                        pair_form[name]["executed_gflop"] += dw[name] / 1e9
             if layer in pdims:      # pair form: the FLOPs the launch executes, not the fine-form convention
                 fl = pair_kernel_flops(kern, pdims[layer][0], pdims[layer][1], dims[layer][2], dims[layer][3])
                 by = None
