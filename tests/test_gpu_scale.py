@@ -9,7 +9,13 @@ import torch
 from parity_report import FP32_GRAD_TOL, FP32_NORMAL_TOL, check_gradients, check_normals
 
 FP32_TOL = (FP32_NORMAL_TOL, 1e-4, FP32_GRAD_TOL)
-MS_GRAD_TOL = 2e-3   # three-head step at 100k facets: see the test
+# The three-head step at 100k facets keeps 2e-3: its level-2 head (7 639 rows x 1 024 hidden units) has, on this mesh and
+# seed, ONE hidden unit whose float64 pre-activation is 4e-9 - fp32 puts it on another branch of the leaky ReLU, which moves
+# that head's W1 / b1 (and, through its input gradient, dconv3's parameters) by 1e-3 of their largest entries; every other
+# tensor sits at 2e-5.  Plain torch fp32 against torch float64 does the same; the MLP kernels are held
+# to float64 at 5e-6 at these sizes, kink-ambiguous units aside, by tests/test_gpu_ops.py::
+# test_mlp_backward_at_a_coarse_head_size_is_exact_up_to_the_sign_of_zero_preactivations.
+MS_GRAD_TOL = 2e-3
 
 pytestmark = pytest.mark.gpu
 
@@ -199,7 +205,8 @@ def test_100k_facet_multi_scale_train_step_matches_the_float64_oracle():
     """The three-head network (BASELINE config 5's architecture; model.py:894-899, 915-920) at the headline size: the heads
     over 25k x 64 and 6k x 128 rows run the wide forms of the MLP kernels, the coarse heads' input gradients are added to
     the up-convolutions'.  Outputs of the three heads, the three losses and all 52 gradients against the float64 closed
-    form (oracle/model_csr_ref.train_loss_ms), tolerances of the single-head test."""
+    form (oracle/model_csr_ref.train_loss_ms): normals and losses at the single-head bounds, gradients at MS_GRAD_TOL (above:
+    one leaky-ReLU unit of the level-2 head on the other side of its kink; the per-tensor table is printed)."""
     from facet_graph_convolution_amd.net import FacetDenoiser
     from facet_graph_convolution_amd.utils import rand_rotation_matrix
     from oracle import model_csr_ref as C
