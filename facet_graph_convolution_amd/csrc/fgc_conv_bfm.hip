@@ -19,7 +19,7 @@
 // Everything around it (soft assignment in fp32 from the logit tables, epilogues, packed-weight layout, XCD tile map) is
 // the 16-slot pipelined form of fgc_conv_w8.hip; shapes: FAST (whole 32-channel passes from one source), degrees <= 16.
 // Rows in flight live in LDS (1 KB per node, wave-private: no workgroup barrier between a gather and its use), so a lane
-// holds no row registers and no z accumulators: 16 + 18 registers less than the vector form.
+// holds no row registers and no z accumulators: 16 + 18 registers less than the vector form (76 in the forward half-tile kernel).
 #include <stdlib.h>
 
 #include "fgc_conv_w8.h"
@@ -32,6 +32,16 @@
 #endif
 #ifndef BFM_RING
 #define BFM_RING 4
+#endif
+// Nodes per sweep of the aggregation phase.  2 (two sweeps of two nodes per pass): half the fragment registers of a four-node
+// sweep - the forward half-tile kernel 89 -> 76 registers, i.e. SIX workgroups per CU by registers as by LDS (five with 4):
+// level-0 forward 48.7 -> 45.1 us, step 1.025 -> 1.020 ms in alternating same-box runs; the data-gradient kernels (five by LDS
+// either way) unchanged.  Forcing 80 registers on the four-node sweep instead (BFM_LB_FWD16 = 6: 9 spilled) lost: 55 us.
+#ifndef BFM_AH
+#define BFM_AH 2
+#endif
+#ifndef BFM_LB_FWD16
+#define BFM_LB_FWD16 4
 #endif
 #ifndef BFM_SEPARATE_QT
 #define BFM_SEPARATE_QT 0
@@ -112,7 +122,7 @@ __device__ __forceinline__ lds_ptr_t to_lds(const void* p) {
 // NT nodes per workgroup (16: four waves, 32: eight waves); a wave owns four nodes in the soft-assignment and aggregation
 // phases and one column tile x k-part of the tile product.  DATA / EROW as in conv_w8_kernel.
 template <bool DATA, int NT, bool EROW>
-__global__ __launch_bounds__(NT * 16, 4) void conv_bfm_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
+__global__ __launch_bounds__(NT * 16, (!DATA && NT == 16) ? BFM_LB_FWD16 : 4) void conv_bfm_kernel(CoreParams p, FwdEpilogue fe, DataEpilogue de) {
     constexpr int TILE = NT, RT = NT / 16, NW = NT / 4, LW = NT == 32 ? 3 : 2, THREADS = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const BfmSmem s = bfm_carve(smem_raw, NT);
@@ -312,52 +322,57 @@ __global__ __launch_bounds__(NT * 16, 4) void conv_bfm_kernel(CoreParams p, FwdE
         // ---------------- phase A: z^T[32 x 9] = X^T[32 x 16] q[16 x 9] per node on the matrix pipe
         wait_vm0();                                         // this pass' rows have landed in LDS
         if (pass > 0) lds_barrier();                        // previous pass' reads of the aggregate tile are done
-        // (all sixteen transposed reads of the wave's four nodes first, then the eight independent MFMAs back to back, then
-        //  the conversions and stores: written as three loops so that the reads and the MFMA latencies overlap)
-        f32x4 zt[4][2];
-        if (!(BFM_KO & 2)) {
-        s16x8 xt[4][2];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const char* xb = s.xs + (size_t)(wave * 4 + a) * XS_NODE;
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const char* ta = xb + (tr_off ^ (unsigned)(c2 * 32));
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)to_lds(ta));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)to_lds(ta + 256));
-                xt[a][c2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-                zt[a][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xt[a][c2]), __builtin_bit_cast(bf16x8, qf[a]),
-                                                                   f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-        // the next pass' rows travel under this pass' matrix phase: the transposed reads have returned (their MFMAs were
-        // issued), the wave's row image is free
-        if (pass + 1 < p.passes) {
-            wait_lgkm0();
-            issue(pass + 1);
-        }
+        // (BFM_AH nodes at a time - 4: all sixteen transposed reads of the wave's four nodes first, then the eight independent
+        //  MFMAs back to back, then the conversions and stores; 2: the same in two halves, with half the fragment registers)
         if (!(BFM_KO & 2)) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int nd = wave * 4 + a;
+            for (int hh = 0; hh < 4 / BFM_AH; ++hh) {
+                s16x8 xt[BFM_AH][2];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                // lane (m = lr, lq): channels 16 c2 + 4 lq .. + 3 of assignment m
-                const u32x2 zp = f4_to_bf4(zt[a][c2]);
-                if (lr < FGC_M) {
-                    // (the 16-byte pieces of an assignment's 64 bytes sit at piece ^ ((m >> 1) & 3): assignments m and m + 2
-                    //  are 128 bytes = 32 banks apart, unswizzled the nine lanes of a store group hit two banks five-fold -
-                    //  17 us of a 52 us level-0 launch by knock-out; the tile product reads with the same XOR)
-                    *reinterpret_cast<u32x2*>(s.ztile + (size_t)nd * ZROW + lr * (KC * 2) +
-                                              (((c2 * 2 + (lq >> 1)) ^ ((lr >> 1) & 3)) * 16) + (lq & 1) * 8) = zp;
+                for (int a = 0; a < BFM_AH; ++a) {
+                    const char* xb = s.xs + (size_t)(wave * 4 + BFM_AH * hh + a) * XS_NODE;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const char* ta = xb + (tr_off ^ (unsigned)(c2 * 32));
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)to_lds(ta));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)to_lds(ta + 256));
+                        xt[a][c2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                f32x4 zt[BFM_AH][2];
+#pragma unroll
+                for (int a = 0; a < BFM_AH; ++a)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+                        zt[a][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xt[a][c2]),
+                                                                           __builtin_bit_cast(bf16x8, qf[BFM_AH * hh + a]),
+                                                                           f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                // the next pass' rows travel under this pass' matrix phase: once the LAST transposed reads have returned (their
+                // MFMAs were issued) the wave's row image is free
+                if (hh == 4 / BFM_AH - 1 && pass + 1 < p.passes) {
+                    wait_lgkm0();
+                    issue(pass + 1);
+                }
+#pragma unroll
+                for (int a = 0; a < BFM_AH; ++a) {
+                    const int nd = wave * 4 + BFM_AH * hh + a;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        // lane (m = lr, lq): channels 16 c2 + 4 lq .. + 3 of assignment m
+                        const u32x2 zp = f4_to_bf4(zt[a][c2]);
+                        if (lr < FGC_M) {
+                            // (the 16-byte pieces of an assignment's 64 bytes sit at piece ^ ((m >> 1) & 3): assignments m and
+                            //  m + 2 are 128 bytes = 32 banks apart, unswizzled the nine lanes of a store group hit two banks
+                            //  five-fold - 17 us of a 52 us level-0 launch by knock-out; the tile product reads with the same XOR)
+                            *reinterpret_cast<u32x2*>(s.ztile + (size_t)nd * ZROW + lr * (KC * 2) +
+                                                      (((c2 * 2 + (lq >> 1)) ^ ((lr >> 1) & 3)) * 16) + (lq & 1) * 8) = zp;
+                        }
+                    }
                 }
             }
-        }
+        } else if (pass + 1 < p.passes) {
+            wait_lgkm0();
+            issue(pass + 1);
         }
         lds_barrier();
         if constexpr (DATA) {
