@@ -5,7 +5,7 @@ Runs oracle/model_csr_ref.train_loss_ms on the headline mesh twice - float64 and
 HIP path - and prints (a) per tensor the float32-vs-float64 gradient error, i.e. what ANY fp32 evaluation of this objective
 gets, (b) per head the samples with the largest |d loss / d cos| = 1 / sqrt(1 - cos^2): a sampled row whose prediction is
 within 1e-6 of (anti)parallel to its target carries a gradient ~1000x a typical row's and its fp32 cosine is uncertain by
-6e-8 / (1 - cos^2).  usage: python tools/ms_conditioning_probe.py [nu nv]"""
+6e-8 / (1 - cos^2).  usage: python tests/ms_conditioning_probe.py [nu nv]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
