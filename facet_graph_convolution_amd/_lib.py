@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the dlopen below)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FGC_LIB", os.path.join(_HERE, "csrc", "libfgc.so"))  # FGC_LIB: developer A/B builds
 
-ABI_VERSION = 103   # FGC_ABI_VERSION of the include/fgc.h this binding was written against
+ABI_VERSION = 104   # FGC_ABI_VERSION of the include/fgc.h this binding was written against
 FGC_M = 9
 AG_LD = 24
 DL_LD = 12
@@ -36,7 +36,9 @@ class ConvDesc(C.Structure):
         ("n_pairs", C.c_int32), ("max_pair_deg", C.c_int32), ("max_pair_in_deg", C.c_int32),
         ("hc", C.c_void_p),
         # per-descriptor option overrides (include/fgc.h: fgc_option_override); HOST pointer
-        ("options", C.c_void_p), ("n_options", C.c_int32),
+        ("options", C.c_void_p), ("n_options", C.c_int32), ("reserved1", C.c_int32),
+        # fgc_conv_layout_id as it read when the workspaces were packed (0 = the FGC_CONV_PACKED calls do not check)
+        ("packed_layout", C.c_uint64),
     ]
 
 
@@ -71,6 +73,8 @@ class ConvBwdIO(C.Structure):
         ("data_tile_list", C.c_void_p), ("n_data_tiles", C.c_int32), ("flags", C.c_int32),
         ("z_saved", C.c_void_p), ("pool_y", C.c_void_p), ("pool_dy", C.c_void_p),
         ("tpair_rowptr", C.c_void_p), ("tpair_col", C.c_void_p), ("tpair_edge", C.c_void_p), ("dt", C.c_void_p),
+        # row stride of r, stated with the buffer (0: each call derives it from its flags / CONV_R_PAD)
+        ("r_ld", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -92,6 +96,11 @@ CONV_DEFER_DW = 16
 CONV_SAVE_Z = 4
 CONV_BF16 = 8
 CONV_R_PAD = 32
+
+
+def mlp_layout(layout_id):
+    """FGC_MLP_LAYOUT(id): the flag bits of an FGC_MLP_PACKED call that name the layout the workspace was packed in."""
+    return int(layout_id) << 8
 
 
 _SIGS = {
@@ -144,6 +153,8 @@ _SIGS = {
     "fgc_conv_r_ld": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "fgc_conv_uses_pairs": (C.c_int, [C.POINTER(ConvDesc)]),
     "fgc_conv_pairs_allowed": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "fgc_conv_layout_id": (C.c_uint64, [C.POINTER(ConvDesc)]),
+    "fgc_mlp_layout_id": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "fgc_conv_bwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvBwdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fgc_conv_pack": (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.POINTER(C.POINTER(ConvBwdIO)), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.c_int32, C.POINTER(PackExtra), C.c_void_p]),

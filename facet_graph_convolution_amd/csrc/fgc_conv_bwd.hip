@@ -1923,6 +1923,12 @@ static bool k1_split(const fgc_conv_desc* d) {
     if (opt(OPT_NO_K1_SPLIT) == 1 || (d->flags & FGC_CONV_BF16)) return false;
     return k1_nodes(d) == 16 && d->cout == 32 && !pairs_ok(d);
 }
+// Everything fgc_conv_pack branches on when it chooses what to write into a layer's workspaces, as one number: a caller keeps
+// it with the packed operands (fgc_conv_desc.packed_layout) and the FGC_CONV_PACKED calls compare.
+uint64_t conv_layout_id(const fgc_conv_desc* d) {
+    const uint64_t bf16 = (d->flags & FGC_CONV_BF16) ? 1 : 0;
+    return 1ull | (uint64_t)narrow_supported(d) << 1 | (uint64_t)pairs_ok(d) << 2 | (uint64_t)k1_split(d) << 3 | bf16 << 4;
+}
 // (room for either layout wherever the shape allows the split one: the workspace a caller sized before changing NO_K1_SPLIT
 //  stays large enough; the operand itself must be packed again after such a change, like every packed operand)
 static size_t k1_wq_floats(const fgc_conv_desc* d) {
@@ -2068,13 +2074,13 @@ static TnPlan layer_tn_plan(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, c
     if (pairs_ok(d)) {      // K = the n / 4 coarse rows, one source
         const int nc = d->n >> 2;
         return tn_plan_of(bf16, true, true, io->r, PL, d->x0, nullptr, d->c0, 0, 0, nc, tn_rows_per_slab(nc, w.splitW), w.slab,
-                          conv_r_ld(cout, io->flags, bf16));
+                          io_r_ld(io, cout, bf16));
     }
     const bool v4 = conv_vec4_ok(d) && (cout % 4 == 0) && ((uintptr_t)io->r % 16 == 0);
     const bool stream_ok = v4 && !(opt(OPT_NO_TNSTREAM) == 1);
     (void)cin;
     return tn_plan_of(bf16, v4, stream_ok, io->r, PL, d->x0, d->x1, d->c0, d->c1, d->shift, d->n, tn_rows_per_slab(d->n, w.splitW),
-                      w.slab, conv_r_ld(cout, io->flags, bf16));
+                      w.slab, io_r_ld(io, cout, bf16));
 }
 
 // the five fixed-order sums behind a layer's parameter gradients (slabs of the weight-gradient GEMM, db and dc partials)
@@ -2100,6 +2106,11 @@ extern "C" size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d) {
     FGC_OPT_SCOPE(d);
     if (!d) return 0;
     return plan_bwd(d, nullptr).bytes;
+}
+
+extern "C" uint64_t fgc_conv_layout_id(const fgc_conv_desc* d) {
+    FGC_OPT_SCOPE(d);
+    return d ? conv_layout_id(d) : 1;
 }
 
 extern "C" int32_t fgc_conv_r_ld(int32_t cout, int32_t padded, int32_t bf16) {
@@ -2154,6 +2165,13 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
     FGC_CHECK_ARG(!d->act || io->y, "fgc_conv_bwd: y required when an activation was applied");
     FGC_CHECK_ARG(io->dW0 && io->db && io->du && io->dc && io->dv, "fgc_conv_bwd: null parameter-gradient pointer");
     FGC_CHECK_ARG(io->dx0 != nullptr || io->dx1 == nullptr, "fgc_conv_bwd: dx1 without dx0");
+    FGC_CHECK_ARG(io_r_ld_ok(io, d->cout, (d->flags & FGC_CONV_BF16) != 0),
+                  "fgc_conv_bwd: r_ld = %d is not a row stride of r for cout = %d (0, or >= %d and congruent to it modulo %d)",
+                  io->r_ld, d->cout, FGC_M * d->cout + 24, (d->flags & FGC_CONV_BF16) ? 8 : 4);
+    FGC_CHECK_ARG(!(io->flags & FGC_CONV_PACKED) || d->packed_layout == 0 || d->packed_layout == conv_layout_id(d),
+                  "fgc_conv_bwd: FGC_CONV_PACKED, but the operands were packed in layout %llu and the options now select %llu "
+                  "(an option changed between fgc_conv_pack and this call)", (unsigned long long)d->packed_layout,
+                  (unsigned long long)conv_layout_id(d));
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_conv_bwd_workspace_bytes(d) && (uintptr_t)workspace % 16 == 0,
                   "fgc_conv_bwd: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
                   fgc_conv_bwd_workspace_bytes(d));
@@ -2199,7 +2217,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             CoreParams p;
             fill_core_params(p, g2, nc, io->tpair_rowptr, io->tpair_col, io->tpair_edge, io->dt, nullptr, cout, 0, 0, cin, io->ag,
                              0, 12, 0, w.Wpt);
-            DataEpilogue ep{io->dl, io->dag, io->r, conv_r_ld(cout, io->flags, bf16), d->u, d->v, cin, d->c0, 0, 0,
+            DataEpilogue ep{io->dl, io->dag, io->r, io_r_ld(io, cout, bf16), d->u, d->v, cin, d->c0, 0, 0,
                             io->dx0, nullptr, io->accumulate0, 0};
             const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
             FGC_CHECK_ARG(w8_erow_supported(p, d->max_pair_in_deg) && (!bf16 || w8_bf16_supported(p, d->max_pair_in_deg)),
@@ -2450,7 +2468,7 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
                          d->shift, 12, 0, w.Wpt);
         p.tile_list = io->data_tile_list;
         p.n_tiles = io->n_data_tiles;
-        DataEpilogue ep{io->dl, io->dag, io->r, conv_r_ld(cout, io->flags, bf16), d->u, d->v, cin, d->c0, d->c1, d->shift,
+        DataEpilogue ep{io->dl, io->dag, io->r, io_r_ld(io, cout, bf16), d->u, d->v, cin, d->c0, d->c1, d->shift,
                         io->dx0, io->dx1, io->accumulate0, io->accumulate1};
         const size_t smem = conv_smem_bytes(g2, (size_t)TILE * 24 * 4);
         const bool vec4 = (cout % 4 == 0) && ((uintptr_t)io->ds % 16 == 0) && ((uintptr_t)io->r % 16 == 0);
@@ -2615,6 +2633,8 @@ extern "C" int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_
                 pl = tn_plan_of(false, true, true, A, zld, io->ds, nullptr, d->cout, 0, 0, d->n, rps, slab);
             } else {
                 FGC_CHECK_ARG(io->r, "fgc_conv_bwd_reduce: layer %d: FGC_CONV_DEFER_DW without r", i);
+                FGC_CHECK_ARG(io_r_ld_ok(io, d->cout, (d->flags & FGC_CONV_BF16) != 0),
+                              "fgc_conv_bwd_reduce: layer %d: r_ld = %d is not a row stride of r for cout = %d", i, io->r_ld, d->cout);
                 pl = layer_tn_plan(d, io, w);
             }
             if (!tn_groupable(pl.variant)) {

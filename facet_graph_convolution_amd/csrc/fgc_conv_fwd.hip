@@ -353,6 +353,10 @@ extern "C" int fgc_conv_fwd(const fgc_conv_desc* d, float* ag, float* y, float* 
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_conv_workspace_bytes(d),
                   "fgc_conv_fwd: workspace too small (%zu < %zu)", workspace_bytes, fgc_conv_workspace_bytes(d));
     FGC_CHECK_ARG((uintptr_t)workspace % 16 == 0 && (uintptr_t)ag % 16 == 0, "fgc_conv_fwd: workspace/ag need 16-byte alignment");
+    FGC_CHECK_ARG(!(d->flags & FGC_CONV_PACKED) || d->packed_layout == 0 || d->packed_layout == conv_layout_id(d),
+                  "fgc_conv_fwd: FGC_CONV_PACKED, but the operands were packed in layout %llu and the options now select %llu "
+                  "(an option changed between fgc_conv_pack and this call)", (unsigned long long)d->packed_layout,
+                  (unsigned long long)conv_layout_id(d));
     hipStream_t st = (hipStream_t)stream;
     float* Wp = (float*)workspace;
     const int rows = d->src_rows > 0 ? d->src_rows : (d->n >> d->shift);

@@ -34,6 +34,19 @@ static inline int conv_r_ld(int cout, int io_flags, bool bf16) {
     const int pl = FGC_M * cout + 24, q = bf16 ? 64 : 32;
     return (io_flags & FGC_CONV_R_PAD) ? (pl + q - 1) / q * q : pl;
 }
+// ... of THIS io: the stride the caller stated with the buffer (fgc_conv_bwd_io.r_ld, checked by io_r_ld_ok), else the one the
+// call's flags imply.  The writer (stage 4) and the readers (stage 8, fgc_conv_bwd_reduce) all come through here.
+static inline int io_r_ld(const fgc_conv_bwd_io* io, int cout, bool bf16) {
+    return io->r_ld > 0 ? io->r_ld : conv_r_ld(cout, io->flags, bf16);
+}
+static inline bool io_r_ld_ok(const fgc_conv_bwd_io* io, int cout, bool bf16) {
+    const int pl = FGC_M * cout + 24;
+    return io->r_ld == 0 || (io->r_ld >= pl && (io->r_ld - pl) % (bf16 ? 8 : 4) == 0);
+}
+
+// which packed-operand layouts the option values in force select for the descriptor (include/fgc.h: fgc_conv_layout_id);
+// defined beside the pack code in fgc_conv_bwd.hip
+uint64_t conv_layout_id(const fgc_conv_desc* d);
 
 bool w8_supported(const CoreParams& p, int max_deg);
 // max_deg: the largest degree of the gathered graph (<= KMAX); <= 16 selects the 16-slot form of the fast kernel

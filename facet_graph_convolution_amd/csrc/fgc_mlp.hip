@@ -530,6 +530,23 @@ int mlp_pack_jobs_f32(const fgc_pack_extra* e, PackJob* jobs, size_t* totals) {
 }
 }  // namespace fgc
 
+namespace fgc {
+int mlp_layout_id(int cin, int hidden, int cout, bool bf16) {
+    if (bf16) return 1 | 8;     // (the bf16-storage kernels have one operand form)
+    return 1 | (mlp_fwd_split_ok(nullptr, cin, hidden, cout) ? 2 : 0) | (mlp_bwd_split_ok(nullptr, nullptr, cin, hidden, cout) ? 4 : 0);
+}
+}  // namespace fgc
+
+extern "C" int32_t fgc_mlp_layout_id(int32_t cin, int32_t hidden, int32_t cout, int32_t bf16) {
+    return mlp_layout_id(cin, hidden, cout, bf16 != 0);
+}
+
+// an FGC_MLP_PACKED call whose flags carry the layout the workspace was packed in (FGC_MLP_LAYOUT): refuse if the options moved
+#define FGC_MLP_CHECK_LAYOUT(who, bf16)                                                                                        \
+    FGC_CHECK_ARG(!(flags & FGC_MLP_PACKED) || (flags >> 8) == 0 || (flags >> 8) == mlp_layout_id(cin, hidden, cout, bf16),        \
+                  who ": FGC_MLP_PACKED, but the operands were packed in layout %d and the options now select %d (an option "  \
+                  "changed between fgc_conv_pack and this call)", flags >> 8, mlp_layout_id(cin, hidden, cout, bf16))
+
 extern "C" int32_t fgc_mlp_num_partials(int32_t n) { return cdiv(n, MLP_T); }
 
 extern "C" size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout) {
@@ -565,6 +582,7 @@ extern "C" int fgc_mlp_fwd(const float* x, int32_t n, int32_t cin, int32_t hidde
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_workspace_bytes(cin, hidden, cout),
                   "fgc_mlp_fwd: workspace too small");
     FGC_CHECK_ARG(alpha >= 0.f && alpha <= 1.f, "fgc_mlp_fwd: alpha=%g outside [0,1] (the reference uses 0.1, model.py:846)", alpha);
+    FGC_MLP_CHECK_LAYOUT("fgc_mlp_fwd", false);
     hipStream_t st = (hipStream_t)stream;
     // the two 1024-wide products on the bf16 matrix pipe with three-term operand splits (fgc_mlp_bf16.hip) where the shape
     // allows: fp32-equivalent results, the matrix time a sixth of the fp32 MFMA's
@@ -606,6 +624,7 @@ extern "C" int fgc_mlp_bwd(const float* x, const float* dy, int32_t n, int32_t c
     FGC_CHECK_ARG(hidden > 0 && hidden % 256 == 0, "fgc_mlp_bwd: hidden=%d must be a multiple of 256", hidden);
     FGC_CHECK_ARG(cout > 0 && cout <= MLP_COUT_MAX, "fgc_mlp_bwd: cout=%d outside [1,%d]", cout, MLP_COUT_MAX);
     FGC_CHECK_ARG(alpha >= 0.f && alpha <= 1.f, "fgc_mlp_bwd: alpha=%g outside [0,1] (the reference uses 0.1, model.py:846)", alpha);
+    FGC_MLP_CHECK_LAYOUT("fgc_mlp_bwd", false);
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout),
                   "fgc_mlp_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                   fgc_mlp_bwd_workspace_bytes(n, cin, hidden, cout));

@@ -1227,6 +1227,9 @@ extern "C" int fgc_mlp_fwd_bf16(const void* x, int32_t n, int32_t cin, int32_t h
     if (rc) return rc;
     if ((rc = mlp_bf16_alpha("fgc_mlp_fwd_bf16", alpha))) return rc;
     FGC_CHECK_ARG(W1 && b1 && W2 && b2 && y, "fgc_mlp_fwd_bf16: null pointer");
+    FGC_CHECK_ARG(!(flags & FGC_MLP_PACKED) || (flags >> 8) == 0 || (flags >> 8) == mlp_layout_id(cin, hidden, cout, true),
+                  "fgc_mlp_fwd_bf16: FGC_MLP_PACKED, but the operands were packed in layout %d, not %d", flags >> 8,
+                  mlp_layout_id(cin, hidden, cout, true));
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bf16_workspace_bytes(cin, hidden, cout) && (uintptr_t)workspace % 16 == 0,
                   "fgc_mlp_fwd_bf16: workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;
@@ -1261,6 +1264,9 @@ extern "C" int fgc_mlp_bwd_bf16(const void* x, const float* dy, int32_t n, int32
     if (rc) return rc;
     if ((rc = mlp_bf16_alpha("fgc_mlp_bwd_bf16", alpha))) return rc;
     FGC_CHECK_ARG(dy && W1 && b1 && W2 && dx && dW1 && db1 && dW2 && db2, "fgc_mlp_bwd_bf16: null pointer");
+    FGC_CHECK_ARG(!(flags & FGC_MLP_PACKED) || (flags >> 8) == 0 || (flags >> 8) == mlp_layout_id(cin, hidden, cout, true),
+                  "fgc_mlp_bwd_bf16: FGC_MLP_PACKED, but the operands were packed in layout %d, not %d", flags >> 8,
+                  mlp_layout_id(cin, hidden, cout, true));
     FGC_CHECK_ARG((cin == 32 || cin == 64) && cout <= 3, "fgc_mlp_bwd_bf16: cin=%d cout=%d (cin 32 or 64, cout <= 3)", cin, cout);
     FGC_CHECK_ARG(workspace && workspace_bytes >= fgc_mlp_bwd_bf16_workspace_bytes(n, cin, hidden, cout) &&
                       (uintptr_t)workspace % 16 == 0,

@@ -7,6 +7,9 @@
 
 namespace fgc {
 bool mlp_split_enabled();
+// which operand layouts the options in force select for the shape (include/fgc.h: fgc_mlp_layout_id), 1 ... 255; and whether an
+// FGC_MLP_PACKED call's flags name another one (FGC_MLP_LAYOUT)
+int mlp_layout_id(int cin, int hidden, int cout, bool bf16);
 size_t mlp_split_pack_bytes(int cin, int hidden);
 bool mlp_fwd_split_ok(const float* x, int cin, int hidden, int cout);   // x == NULL: the shape alone
 int launch_mlp_fwd_split(const float* x, int n, int cin, int hidden, int cout, const float* W1, const float* b1, const float* W2,

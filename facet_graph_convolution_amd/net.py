@@ -435,6 +435,8 @@ class FacetDenoiser:
             io.ds, io.dl, io.dag, io.r = (B[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
             if ("r_" + lay.name) in B:
                 io.r = B["r_" + lay.name].data_ptr()
+            # the stride of r belongs to the buffer: stated once here, not re-derived from every staged call's flags
+            io.r_ld = rld(lay)
             gW0, gb, gu, gc, gv = grads[lay.pidx:lay.pidx + 5]
             io.dW0, io.db, io.du, io.dc, io.dv = (t.data_ptr() for t in (gW0, gb, gu, gc, gv))
             if pg is not None:
@@ -649,6 +651,13 @@ class FacetDenoiser:
             _lib.check(L.fgc_conv_pack(A["descs"], A["ios"], A["wsf"], A["wsb"], A["count"],
                                        C.byref(ex) if ex is not None else None, st), "pack")
             packed = _lib.CONV_PACKED
+            # the operands carry the identity of their layout: a library option that moves between this launch and a layer's
+            # FGC_CONV_PACKED / FGC_MLP_PACKED calls is then an error, not a product with the wrong operand
+            for dd in M["descs"].values():
+                dd.packed_layout = L.fgc_conv_layout_id(C.byref(dd))
+            if mlp_packed:
+                mlp_packed = M["mlp_packed"] = _lib.MLP_PACKED | _lib.mlp_layout(
+                    L.fgc_mlp_layout_id(32, HIDDEN, 3, 1 if self.dtype == "bf16" else 0))
         for lay in self.layers:
             d = M["descs"][lay.name]
             lws = B["wsf_" + lay.name]
@@ -851,7 +860,8 @@ class FacetDenoiser:
                                  _p(vals[s + 2]), LRELU_ALPHA, _p(B["g_d1"]), _p(grads[s]), _p(grads[s + 1]),
                                  _p(grads[s + 2]), _p(grads[s + 3]), M.get("mlp_packed", 0), _p(ws), ws.numel(), st),
                    "head0 bwd")
-        rp = self.r_pad      # (FGC_CONV_R_PAD: rows of r padded to whole 128-byte lines)
+        # (the stride of r - padded to whole 128-byte lines unless FGC_NO_R_PAD=1 - is stated in every io's r_ld at bind time:
+        #  the staged calls below may reset io.flags freely)
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
             self._tag("bwd:" + name)
             # (g_h2 += d pool2 and g_h1 += d pool1 are folded into stage 1 of conv2 / conv1: fgc_conv_bwd_io.pool_y / pool_dy;
@@ -864,7 +874,7 @@ class FacetDenoiser:
                            "pool1 bwd")
             d, io = M["descs"][name], M["ios"][name]
             lws = B["wsb_" + name]
-            base = ((_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0) | rp
+            base = (_lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE) if self.batched else 0
             if self.batched and name in self.grouped_dw_layers:
                 base |= _lib.CONV_DEFER_DW
             if not self.sharded:
@@ -896,7 +906,7 @@ class FacetDenoiser:
                 yield ("xchg", [("pedges", lay.level, dtb), ("pedges", lay.level, dlb)], None)
                 io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("pair data")
-                io.flags = rp
+                io.flags = 0
                 continue
             # s = dy * lrelu'(y) / deg on owned rows and the d-logits of owned edges, in one call (the deep d-logits kernel
             # computes s in its prologue; packs the operands of stages 2 and 4 when the network did not)
@@ -917,16 +927,16 @@ class FacetDenoiser:
                 io.stages = 4 | 8
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_bnd"][0].data_ptr(), g.tiles["ttiles_bnd"][1]
                 call("data/boundary")
-                io.data_tile_list, io.n_data_tiles, io.flags = None, 0, rp
+                io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
             else:
                 yield ("xchg", items, None)
                 io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("data")
-                io.flags = rp
+                io.flags = 0
         if self.batched:
             A = M["arrays"]
             for lname in self.grouped_dw_layers:      # (the staged calls of a sharded step leave other flags behind)
-                M["ios"][lname].flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW | rp
+                M["ios"][lname].flags = _lib.CONV_PACKED | _lib.CONV_DEFER_REDUCE | _lib.CONV_DEFER_DW
             self._tag("bwd:reduce")
             _lib.check(L.fgc_conv_bwd_reduce(A["descs"], A["ios"], A["wsb"], A["count"], st), "reduce")
         if self.sharded:

@@ -43,8 +43,10 @@ extern "C" {
 /* ABI version of this header.  fgc_version() returns the value the LIBRARY was built with: a binding compares the two
  * (and the struct sizes below) before its first call.  102: fgc_set_option / fgc_get_option; fgc_conv_pack(extra),
  * flags of fgc_mlp_fwd / fgc_mlp_bwd and their _bf16 forms, larger fgc_conv_desc / fgc_conv_bwd_io (all since 101).
- * 103: fgc_conv_pairs_allowed; options NO_BFM, K1_QS14; fgc_conv_desc.options / n_options (per-descriptor option overrides). */
-#define FGC_ABI_VERSION 103
+ * 103: fgc_conv_pairs_allowed; options NO_BFM, K1_QS14; fgc_conv_desc.options / n_options (per-descriptor option overrides).
+ * 104: fgc_conv_bwd_io.r_ld (the stride of r stated with the buffer); fgc_conv_desc.packed_layout + fgc_conv_layout_id,
+ * fgc_mlp_layout_id / FGC_MLP_LAYOUT (packed operands carry the identity of their layout). */
+#define FGC_ABI_VERSION 104
 
 const char* fgc_last_error(void);
 int fgc_version(void);
@@ -241,6 +243,10 @@ typedef struct fgc_conv_desc {
                                     facet-sharded caller: owned rows while the halo parents travel, then the rest) */
     const fgc_option_override* options;  /* HOST pointer, [n_options]: per-descriptor option values (see above); NULL = none */
     int32_t n_options;
+    int32_t reserved1;
+    uint64_t packed_layout;      /* 0, or fgc_conv_layout_id(this descriptor) as it read when the operands in the workspaces
+                                    were packed: a call told FGC_CONV_PACKED then returns FGC_EINVAL if the option values of
+                                    the moment select another operand layout, instead of multiplying by the wrong one */
 } fgc_conv_desc;
 
 /* the workspace still holds the packed operands of the previous call with this descriptor: skip the packing */
@@ -253,7 +259,9 @@ typedef struct fgc_conv_desc {
                                    * then stay untouched until that call: a caller that shares r between layers cannot use it */
 #define FGC_CONV_R_PAD 32         /* fgc_conv_bwd_io.flags: the rows of r are padded to whole 128-byte lines - row stride
                                      fgc_conv_r_ld(cout, 1, bf16) elements instead of M*cout + 24 (columns unchanged: M*cout
-                                     aggregate columns, then da | dg; the pad columns are never read) */
+                                     aggregate columns, then da | dg; the pad columns are never read).  Read only when
+                                     fgc_conv_bwd_io.r_ld == 0; a caller that sets r_ld states the stride once, with the
+                                     buffer, and need not repeat the flag in every staged call */
 #define FGC_CONV_SAVE_Z 4         /* fgc_conv_desc.flags, first layer over a narrow input (cin <= 8): the forward pass
                                   * leaves the aggregates z [n, roundup4(9*cin)] in its workspace (sized for it by
                                   * fgc_conv_workspace_bytes when the flag is set) so that the backward pass, given
@@ -333,6 +341,12 @@ typedef struct fgc_conv_bwd_io {
     float* dt;                   /* [n_pairs (+ incoming cross-shard pairs), cout], 16-byte aligned (bf16 with
                                     FGC_CONV_BF16): stage 1|2 writes the rows of the owned pairs, stage 4 gathers the rows the
                                     transposed pair graph names (tpair_edge), like dl */
+    int32_t r_ld;                /* row stride of r in elements (fp32 floats / bf16 halves), a property of the BUFFER: stage 4
+                                    writes with it, stage 8 and fgc_conv_bwd_reduce read with it, whatever `flags` holds in
+                                    each of those calls.  0 = derive it from flags (FGC_CONV_R_PAD set or not) in every call,
+                                    as ABI 103 did.  Otherwise >= M*cout + 24 and congruent to it modulo 4 (bf16: modulo 8) -
+                                    fgc_conv_r_ld() returns the two strides the kernels are tuned for. */
+    int32_t reserved0;
 } fgc_conv_bwd_io;
 
 size_t fgc_conv_bwd_workspace_bytes(const fgc_conv_desc* d);
@@ -366,6 +380,12 @@ int fgc_conv_uses_pairs(const fgc_conv_desc* d);
  * them on the GLOBAL pair graph so that every rank decides alike (fgc_conv_uses_pairs applies the same function to the
  * descriptor's own counts).  rows: coarse source rows; 1 = allowed. */
 int fgc_conv_pairs_allowed(int64_t rows, int64_t n_pairs, int32_t max_pair_in_deg, int32_t cout);
+/* Which packed-operand layouts the option values of THIS moment (process options, then the descriptor's own overrides)
+ * select for the descriptor - first-layer path or not, pair form or not, d-logits operand as fp32 or as bf16 split planes,
+ * storage type.  Never 0.  Operands packed ahead of their use (fgc_conv_pack, or an earlier call) are only valid while this
+ * value stays what it was: store it in fgc_conv_desc.packed_layout and the FGC_CONV_PACKED calls check it (packed_layout is
+ * not part of the value). */
+uint64_t fgc_conv_layout_id(const fgc_conv_desc* d);
 int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, void* workspace, size_t workspace_bytes,
                  void* stream);
 
@@ -432,6 +452,12 @@ int fgc_conv_bwd_reduce(const fgc_conv_desc* const* descs, const fgc_conv_bwd_io
  * fgc_pack_extra naming it, same W1 / W2 / shape, nothing written to it since): the call skips its own pack launch.
  * ---------------------------------------------------------------------------------- */
 #define FGC_MLP_PACKED 1
+/* The MLP's counterpart of fgc_conv_layout_id: which operand layouts the option values of this moment select for the shape
+ * (1 ... 255; bf16 != 0: the _bf16 entry points).  OR FGC_MLP_LAYOUT(id as it read when the workspace was packed) into the
+ * flags of an FGC_MLP_PACKED call and the call returns FGC_EINVAL if the options moved in between; without it nothing is
+ * checked. */
+#define FGC_MLP_LAYOUT(id) ((int32_t)(id) << 8)
+int32_t fgc_mlp_layout_id(int32_t cin, int32_t hidden, int32_t cout, int32_t bf16);
 int32_t fgc_mlp_num_partials(int32_t n);
 size_t fgc_mlp_workspace_bytes(int32_t cin, int32_t hidden, int32_t cout);
 size_t fgc_mlp_bwd_workspace_bytes(int32_t n, int32_t cin, int32_t hidden, int32_t cout);

@@ -127,3 +127,54 @@ def test_a_descriptor_can_carry_its_own_option_values():
     assert set(out["plain"]) == {1} and set(out["fine"]) == {0}
     with pytest.raises(ValueError):
         _lib.option_overrides(NO_SUCH_OPTION=1)
+
+
+def test_packed_operands_carry_the_identity_of_their_layout():
+    """fgc_conv_layout_id / fgc_mlp_layout_id (ABI 104; the round-5 advisor's 'setting an option between fgc_conv_pack and the
+    launch computes garbage silently'): the number changes with every option that changes what fgc_conv_pack writes - pair form
+    or not, the d-logits operand as split planes or fp32, the first-layer path, the MLP's split forms - follows a
+    descriptor's own overrides, and does not depend on the stored packed_layout.  (That an FGC_CONV_PACKED call refuses a stale
+    value is a launch-path check: tests/test_gpu_conv.py.)"""
+    L = _lib.lib()
+    fake = 4096
+
+    def desc(cin, cout, shift=0, pairs=False, n=640, max_deg=12):
+        d = _lib.ConvDesc()
+        d.n, d.nnz, d.rowptr, d.col, d.x0 = n, 12 * n, fake, fake, fake
+        d.c0, d.c1, d.shift, d.cout, d.max_deg = cin, 0, shift, cout, max_deg
+        d.W0 = d.b = d.u = d.c = d.v = fake
+        if pairs:
+            d.pair_rowptr = d.pair_col = d.pair_mul = d.hc = fake
+            d.n_pairs, d.max_pair_deg, d.max_pair_in_deg = 100, 8, 8
+        return d
+
+    ident = lambda d: L.fgc_conv_layout_id(C.byref(d))
+    up, deep, first = desc(64, 32, shift=2, pairs=True), desc(32, 32), desc(6, 32)
+    base = [ident(d) for d in (up, deep, first)]
+    assert all(b != 0 for b in base) and len(set(base)) == 3
+    with _lib.options(NO_PAIRS=1):
+        assert ident(up) != base[0] and ident(deep) == base[1]
+    with _lib.options(NO_K1_SPLIT=1):
+        assert ident(deep) != base[1] and ident(first) == base[2]
+    with _lib.options(NO_NARROW=1):
+        assert ident(first) != base[2]
+    assert [ident(d) for d in (up, deep, first)] == base
+    over = _lib.option_overrides(NO_PAIRS=1)
+    up.options, up.n_options = C.addressof(over), 1
+    assert ident(up) != base[0]
+    up.options, up.n_options = None, 0
+    up.packed_layout = 12345
+    assert ident(up) == base[0]
+    bf = desc(32, 32)
+    bf.flags = _lib.CONV_BF16
+    assert ident(bf) != base[1]
+    # the MLP's: 1 ... 255, moves with the two split switches, one form for bf16 storage
+    m = L.fgc_mlp_layout_id(32, 1024, 3, 0)
+    assert 0 < m < 256 and 0 < L.fgc_mlp_layout_id(32, 1024, 3, 1) < 256
+    with _lib.options(NO_MLP_BWD_SPLIT=1):
+        m1 = L.fgc_mlp_layout_id(32, 1024, 3, 0)
+    with _lib.options(NO_MLP_SPLIT=1):
+        m2 = L.fgc_mlp_layout_id(32, 1024, 3, 0)
+        assert L.fgc_mlp_layout_id(32, 1024, 3, 1) == L.fgc_mlp_layout_id(32, 1024, 3, 1)
+    assert len({m, m1, m2}) == 3
+    assert _lib.mlp_layout(m) == m << 8

@@ -279,3 +279,99 @@ def test_first_layer_backward_without_input_gradient(golden_dir, case):
     assert torch.allclose(y2, ref, atol=1e-7)
     if yp is not None:
         assert torch.equal(yp, y2.view(-1, 4, y2.shape[1]).amax(1))
+
+
+def test_the_stride_of_r_and_the_layout_of_packed_operands_are_stated_not_implied(golden_dir):
+    """ABI 104.  (1) fgc_conv_bwd_io.r_ld: the row stride of r is a property of the buffer - a staged backward whose calls never
+    carry FGC_CONV_R_PAD but whose io states the padded stride is bit-identical to the single call (the writer, stage 4, and the
+    reader, stage 8, used to re-derive the stride from each call's own flags: one forgotten bit gave silently wrong weight
+    gradients); a stride that cannot be one is refused.  (2) fgc_conv_desc.packed_layout: an FGC_CONV_PACKED call made after
+    an option moved the operand layout returns FGC_EINVAL instead of multiplying by the stale operand."""
+    import ctypes as C
+    from facet_graph_convolution_amd import ops, _lib
+    from facet_graph_convolution_amd.graph import FacetGraph
+    from facet_graph_convolution_amd.ops import make_conv_desc, ptr, stream_ptr
+    z = np.load(os.path.join(golden_dir, "conv_c1_coarsened.npz"))
+    dev = torch.device("cuda:0")
+    g = FacetGraph(z["adj"], dev)
+    n, cin, cout = g.n, 32, 32
+    x = torch.tensor(np.random.RandomState(0).normal(size=(n, cin)).astype(np.float32), device=dev)
+    params = _params(cin, cout, 5, dev)
+    L = _lib.lib()
+    y_ref, _, ag_ref = ops.conv_fwd(g, x, None, 0, params, act=1)
+    dy = torch.tensor(np.random.RandomState(3).normal(size=(n, cout)).astype(np.float32), device=dev)
+    dx_ref, _, grads_ref = ops.conv_bwd(g, x, None, 0, params, ag_ref, y_ref, dy, act=1)
+
+    d = make_conv_desc(g, x, None, 0, params, True, 1, 0.1)
+    ws = torch.empty(L.fgc_conv_bwd_workspace_bytes(C.byref(d)) + 256, dtype=torch.uint8, device=dev)
+    trow, tcol, tedge = g.transposed()
+    f32 = dict(dtype=torch.float32, device=dev)
+    rld = L.fgc_conv_r_ld(cout, 1, 0)
+    assert rld % 32 == 0 and rld > 9 * cout + 24
+    io = _lib.ConvBwdIO()
+    io.trowptr, io.tcol, io.tedge, io.max_in_deg = trow.data_ptr(), tcol.data_ptr(), tedge.data_ptr(), g.max_in_deg
+    bufs = dict(ds=torch.empty(n, cout, **f32), dl=torch.empty(g.nnz, 12, **f32), dag=torch.empty(n, 24, **f32),
+                r=torch.full((n, rld), float("nan"), **f32), dx=torch.full((n, cin), float("nan"), **f32))
+    grads = [torch.empty_like(p) for p in params]
+    io.ag, io.y, io.dy = ag_ref.data_ptr(), y_ref.data_ptr(), dy.data_ptr()
+    io.ds, io.dl, io.dag, io.r = (bufs[k].data_ptr() for k in ("ds", "dl", "dag", "r"))
+    io.dx0 = bufs["dx"].data_ptr()
+    io.dW0, io.db, io.du, io.dc, io.dv = [t.data_ptr() for t in grads]
+    io.r_ld = rld
+    for stages, fl in [(1 | 2, 0), (4, _lib.CONV_PACKED), (8, _lib.CONV_PACKED)]:      # (no call carries CONV_R_PAD)
+        io.stages, io.flags = stages, fl
+        _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "staged bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(bufs["dx"], dx_ref)
+    for a, b in zip(grads, grads_ref):
+        assert torch.equal(a, b)
+    r = bufs["r"]
+    assert torch.isfinite(r[:, :9 * cout + 24]).all() and torch.isnan(r[:, 9 * cout + 24:]).all()   # pad columns untouched
+    # ... and the flag still works for a caller that sets no r_ld (ABI 103 behaviour)
+    io.r_ld = 0
+    grads2 = [torch.empty_like(p) for p in params]
+    io.dW0, io.db, io.du, io.dc, io.dv = [t.data_ptr() for t in grads2]
+    io.stages, io.flags = 0, _lib.CONV_R_PAD
+    _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "bwd, flag form")
+    torch.cuda.synchronize()
+    for a, b in zip(grads2, grads_ref):
+        assert torch.equal(a, b)
+    for bad in (9 * cout + 23, 9 * cout + 25, 9 * cout + 26):      # too short / not congruent to 9 cout + 24 modulo 4
+        io.r_ld = bad
+        assert L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()) == -22
+        assert b"r_ld" in L.fgc_last_error()
+    io.r_ld = 0
+
+    # (2) the operands in ws were packed with the split d-logits operand (the default for a 32-wide layer on this graph)
+    ident = L.fgc_conv_layout_id(C.byref(d))
+    with _lib.options(NO_K1_SPLIT=1):
+        other = L.fgc_conv_layout_id(C.byref(d))
+    if other == ident:
+        pytest.skip("this shape has one d-logits operand form on this graph")
+    d.packed_layout = ident
+    io.stages, io.flags = 0, _lib.CONV_PACKED | _lib.CONV_R_PAD
+    _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "packed bwd, same options")
+    with _lib.options(NO_K1_SPLIT=1):
+        assert L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()) == -22
+        assert b"packed in layout" in L.fgc_last_error()
+        io.flags = _lib.CONV_R_PAD           # not told PACKED: the call packs for itself and runs
+        _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), ptr(ws), ws.numel(), stream_ptr()), "bwd packs again")
+    torch.cuda.synchronize()
+    for a, b in zip(grads2, grads_ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)      # (the fp32-MFMA form of the d-logits GEMM: not bit-identical)
+    # the MLP's flags carry theirs
+    from facet_graph_convolution_amd.net import HIDDEN
+    m = L.fgc_mlp_layout_id(32, HIDDEN, 3, 0)
+    xs = torch.tensor(np.random.RandomState(1).normal(size=(512, 32)).astype(np.float32), device=dev)
+    W1 = torch.randn(32, HIDDEN, device=dev) * 0.1
+    b1, W2, b2 = torch.zeros(HIDDEN, device=dev), torch.randn(HIDDEN, 3, device=dev) * 0.1, torch.zeros(3, device=dev)
+    wsm = torch.empty(L.fgc_mlp_workspace_bytes(32, HIDDEN, 3) + 256, dtype=torch.uint8, device=dev)
+    ym = torch.empty(512, 3, device=dev)
+    call = lambda flags: L.fgc_mlp_fwd(ptr(xs), 512, 32, HIDDEN, 3, ptr(W1), ptr(b1), ptr(W2), ptr(b2), 0.1, ptr(ym), None, flags,
+                                       ptr(wsm), wsm.numel(), stream_ptr())
+    assert call(0) == 0
+    y0 = ym.clone()
+    assert call(_lib.MLP_PACKED | _lib.mlp_layout(m)) == 0 and torch.equal(ym, y0)
+    with _lib.options(NO_MLP_SPLIT=1):
+        assert call(_lib.MLP_PACKED | _lib.mlp_layout(m)) == -22 and b"packed in layout" in L.fgc_last_error()
+    torch.cuda.synchronize()
