@@ -622,6 +622,40 @@ def main(argv=None):
     import gc
     gc.collect()
     gc.freeze()
+    # Facet-sharded: WHICH layers run as interior | exchange | boundary launches is a latency question.  A layer below
+    # net.split_min_tiles interior tiles waits for its halo rows and runs as one launch; above it the exchange travels under
+    # the interior tiles at the price of a second, half-empty launch.  The default (1024: level 0 of a 100k-facet shard only)
+    # was set where an "exchange" is a 5 us device copy (two shards in one process, tools/shard_step_probe.py); on xGMI the
+    # collective of a coarse level is latency the one-GPU probes never saw.  So the job measures it on ITS OWN collectives,
+    # before the warm-up: a few steps per candidate threshold, max over ranks through an all-reduce (every rank reads the same
+    # numbers and takes the same decision), the default kept unless a candidate is 2 % faster.  FGC_SPLIT_MIN_TILES set: no tuning.
+    split_tune = None
+    if shard and train and not graph_mode[0] and "FGC_SPLIT_MIN_TILES" not in os.environ and getattr(net, "overlap", False):
+        default_thr = net.split_min_tiles
+        try:
+            ntune = max(3, min(8, args.steps))
+            res = {}
+            for thr in sorted({default_thr, 256, 64}, reverse=True):
+                net.split_min_tiles = thr
+                step()
+                step()
+                sync_barrier()
+                t0 = time.perf_counter()
+                for _ in range(ntune):
+                    step()
+                sync_barrier()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                res[thr] = tt.item() / ntune * 1e3
+            best = min(res, key=res.get)
+            chosen = best if res[best] < 0.98 * res[default_thr] else default_thr
+            net.split_min_tiles = chosen
+            split_tune = {"ms_per_step": {str(k): round(v, 4) for k, v in res.items()}, "steps_each": ntune, "chosen": chosen,
+                          "default": default_thr}
+        except Exception as e:               # noqa: BLE001 - an optimisation: its failure leaves the default schedule
+            net.split_min_tiles = default_thr
+            split_tune = {"error": "%s: %s" % (type(e).__name__, str(e)[:200]), "chosen": default_thr, "default": default_thr}
+            print("bench: split-threshold tuning failed (%s), default kept" % split_tune["error"], file=sys.stderr)
     w_done = 0
     graph_note = None
     if args.graph and world == 1 and train:
@@ -980,7 +1014,8 @@ def main(argv=None):
                                            "RCCL" if backend == "nccl" else backend, dist.get_world_size()))},
             "loss_deg": loss,
             # what the process ran, in order (round 6: the hipEvent pass moved in front; the timed region is W + K steps as ever)
-            "timeline": ("%sW = %d untimed warm-up steps -> K = %d timed steps between barriers -> untimed extras" % (
+            "timeline": ("%s%sW = %d untimed warm-up steps -> K = %d timed steps between barriers -> untimed extras" % (
+                "split-threshold tuning (`split_tune`) -> " if split_tune is not None else "",
                 "per-kernel hipEvent pass (%d eager steps; also warms the clocks) -> " % args.steps if prof is not None else "",
                 args.warmup, args.steps)),
             "startup_s": {k: round(v, 2) for k, v in startup.items()},
@@ -990,6 +1025,7 @@ def main(argv=None):
             "ms_per_step_median": float(np.median(rep_ms)),
             "hipgraph_replay": hipgraph,
             "retry_note": os.environ.get("FGC_BENCH_RETRY_NOTE") or graph_note,
+            "split_tune": split_tune,
             "forward_only_ms": fwd_ms,
             "forward_only_facets_per_s": F_total / (fwd_ms * 1e-3),
             "hbm_roofline_frac_whole_step": step_bytes / (ms_step * 1e-3) / (PEAK_HBM_GBS * 1e9),

@@ -440,7 +440,44 @@ def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0, dtype="f32", mult
     return nets
 
 
-def sim_run(nets, make_gen, poison=True):
+class SimLatency:
+    """Probe infrastructure for sim_run (tools/shard_latency_probe.py): gives the stand-in exchanges the LATENCY of a real
+    collective, which one process on one GPU otherwise never shows.  A blocking exchange or all-reduce stalls the compute
+    stream for `us` microseconds (a spin kernel of one wave); an overlapped exchange spins on a side stream of its shard from
+    the moment the shard resumes computing, and the shard's ("wait", key) makes the compute stream wait for it - so the
+    interior tiles hide as much of it as they last, like on a rank of its own.  All shards share the one compute stream, in
+    order: a stall of one shard is not filled by another's kernels."""
+
+    def __init__(self, us, n_shards):
+        self.us = float(us)
+        self.side = [torch.cuda.Stream() for _ in range(n_shards)]
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        a.record()
+        torch.cuda._sleep(4_000_000)
+        b.record()
+        torch.cuda.synchronize()
+        self.cycles_per_us = 4_000_000 / (a.elapsed_time(b) * 1e3)
+        self.cycles = int(self.us * self.cycles_per_us)
+
+    def stall(self):
+        if self.cycles > 0:
+            torch.cuda._sleep(self.cycles)
+
+    def start(self, i):
+        """The clock of shard i's overlapped exchange starts now (the shard resumes); returns the event its wait needs."""
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side[i]):
+            self.side[i].wait_event(ev)
+            self.stall()
+            done = torch.cuda.Event()
+            done.record()
+        return done
+
+
+def sim_run(nets, make_gen, poison=True, latency=None):
     """Advance the schedules of all shards; every yielded exchange / all-reduce request is served among them.
 
     Exchanges and sums are COLLECTIVE: all shards must arrive at them in the same order.  A ("wait", key) is
@@ -451,8 +488,13 @@ def sim_run(nets, make_gen, poison=True):
     lets a halo row reach a result fails the parity tests instead of reading last step's values."""
     gens = [make_gen(n) for n in nets]
     pending = [dict() for _ in nets]
+    clocks = [dict() for _ in nets]      # (latency is not None: key -> the event an overlapped exchange completes with)
 
     def advance(i):
+        if latency is not None:
+            for key in pending[i]:
+                if key not in clocks[i]:
+                    clocks[i][key] = latency.start(i)
         while True:
             try:
                 r = next(gens[i])
@@ -461,6 +503,8 @@ def sim_run(nets, make_gen, poison=True):
                 return None
             if r[0] == "wait":
                 px = pending[i].pop(r[1])
+                if latency is not None:
+                    torch.cuda.current_stream().wait_event(clocks[i].pop(r[1]))
                 if getattr(px, "_sim_late", None) is not None:
                     px.recv_buf.copy_(px._sim_late)
                     px._sim_late = None
@@ -484,6 +528,8 @@ def sim_run(nets, make_gen, poison=True):
                 tot += r[1]
             for r in reqs:
                 r[1].copy_(tot)
+                if latency is not None:
+                    latency.stall()      # (an all-reduce blocks every rank: one stall per shard on the shared stream)
             continue
         pxs = [n._packed(r) for n, r in zip(nets, reqs)]
         for px in pxs:
@@ -503,6 +549,8 @@ def sim_run(nets, make_gen, poison=True):
             pd._sim_late = target if late else None
         for i, (px, r) in enumerate(zip(pxs, reqs)):
             if r[2] is None:
+                if latency is not None:
+                    latency.stall()
                 px.unpack()
             else:
                 assert r[2] not in pending[i], "two exchanges in flight under one key"
@@ -511,16 +559,16 @@ def sim_run(nets, make_gen, poison=True):
                     px.poison_tails()
 
 
-def sim_forward_backward(nets, rotate=True):
-    sim_run(nets, lambda n: n._forward_gen(rotate, n._fused_loss_now()))
-    sim_run(nets, lambda n: n._loss_backward_gen(rotate))
+def sim_forward_backward(nets, rotate=True, latency=None):
+    sim_run(nets, lambda n: n._forward_gen(rotate, n._fused_loss_now()), latency=latency)
+    sim_run(nets, lambda n: n._loss_backward_gen(rotate), latency=latency)
 
 
 def sim_forward_multi_scale(nets, rotate=False):
     sim_run(nets, lambda n: n._forward_ms_gen(rotate))
 
 
-def sim_forward_backward_captured(nets, rotate=True):
+def sim_forward_backward_captured(nets, rotate=True, latency=None):
     """The step of sim_forward_backward with every shard's launches replayed from its hipGraph segments (one graph per
     stretch between two exchanges, net._capture_segments), the requests served between the replays - what
     `forward_backward(capture=True)` does on a sharded rank, with the simulated exchange in place of the communicator.
@@ -538,6 +586,6 @@ def sim_forward_backward_captured(nets, rotate=True):
             if req is not None:
                 yield req
 
-    sim_run(nets, lambda n: replay(n._graph_fb[0][0]))
-    sim_run(nets, lambda n: replay(n._graph_fb[0][1]))
+    sim_run(nets, lambda n: replay(n._graph_fb[0][0]), latency=latency)
+    sim_run(nets, lambda n: replay(n._graph_fb[0][1]), latency=latency)
 

@@ -77,11 +77,19 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert set(j["startup_s"]) == {"preprocess_s", "shard_plan_s", "bind_s"}
     # the default of N > 1 is eager launches (bench.py: graph_mode); no retry happened
     assert "eager launches" in j["config"]["parallelism"] and j["hipgraph_replay"] is None and j["retry_note"] is None
+    # which layers split around their exchange was measured on the job's own collectives before the warm-up (every rank reads
+    # the same all-reduced times, so every rank chose alike); a pinned threshold or hipGraph segments: no tuning
+    tune = j["split_tune"]
+    assert set(tune["ms_per_step"]) == {"1024", "256", "64"} and all(v > 0 for v in tune["ms_per_step"].values())
+    assert tune["default"] == 1024 and tune["chosen"] in (1024, 256, 64) and "split-threshold tuning" in j["timeline"]
+    if tune["chosen"] != 1024:
+        assert tune["ms_per_step"][str(tune["chosen"])] < 0.98 * tune["ms_per_step"]["1024"]
     # --graph 1: the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
     # (stretches WITH launches only: two requests back to back leave no graph; this small mesh splits no layer)
     e = _bench(["--gpus", "2", "--graph", "1"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
     assert e["hipgraph_replay"]["graphs_per_step"] >= 12 and e["hipgraph_replay"]["eager_ms_per_step"] > 0
     assert e["hipgraph_replay"]["timed_region"] == "hipgraph" and "hipGraph segments" in e["config"]["parallelism"]
+    assert e["split_tune"] is None
     # weak scaling: the mesh has twice the facets of the single-GPU run
     assert "%d facets" % (2 * 48 * 40 * 2) in j["config"]["workload"]
     # ... and the same ranks report the OTHER reading of the metric beside it: the ONE single-GPU-sized mesh sharded over
