@@ -2191,7 +2191,11 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
         // convolution over the n / 4 coarse rows whose gathered operand is dt (one row per pair)
         FGC_CHECK_ARG(io->tpair_rowptr && io->tpair_col && io->tpair_edge && io->dt && d->max_pair_in_deg > 0,
                       "fgc_conv_bwd: the pair form needs the transposed pair graph, dt and max_pair_in_deg");
-        FGC_CHECK_ARG(!io->pool_dy && io->data_tile_list == nullptr, "fgc_conv_bwd: the pair form has no pooled output / tile list");
+        FGC_CHECK_ARG(!io->pool_dy, "fgc_conv_bwd: the pair form has no pooled output");
+        // (a tile list names 32-row tiles of the n / 4 COARSE rows the data kernel runs over: a facet-sharded caller computes the
+        //  tiles whose in-pairs are all its own while the dt / d-logit rows of the others travel)
+        FGC_CHECK_ARG(io->data_tile_list == nullptr || (io->n_data_tiles >= 0 && io->n_data_tiles <= cdiv(d->n >> 2, TILE)),
+                      "fgc_conv_bwd: pair form: n_data_tiles=%d outside [0, %d]", io->n_data_tiles, cdiv(d->n >> 2, TILE));
         FGC_CHECK_ARG(((uintptr_t)io->dt | (uintptr_t)io->dy | (uintptr_t)io->dl | (uintptr_t)io->dag | (uintptr_t)io->r) % 16 == 0,
                       "fgc_conv_bwd: the pair form needs 16-byte aligned buffers");
         const int nc = d->n >> 2;
@@ -2223,8 +2227,12 @@ extern "C" int fgc_conv_bwd(const fgc_conv_desc* d, const fgc_conv_bwd_io* io, v
             FGC_CHECK_ARG(w8_erow_supported(p, d->max_pair_in_deg) && (!bf16 || w8_bf16_supported(p, d->max_pair_in_deg)),
                           "fgc_conv_bwd: pair form: unsupported shape (cin=%d cout=%d max_pair_in_deg=%d)", cin, cout,
                           d->max_pair_in_deg);
-            rc = launch_data_w8_erow(p, ep, smem, d->max_pair_in_deg, st, bf16);
-            if (rc) return rc;
+            p.tile_list = io->data_tile_list;
+            p.n_tiles = io->n_data_tiles;
+            if (!p.tile_list || p.n_tiles > 0) {
+                rc = launch_data_w8_erow(p, ep, smem, d->max_pair_in_deg, st, bf16);
+                if (rc) return rc;
+            }
         }
         if (stages & 8) {
             if (!(io->flags & FGC_CONV_DEFER_DW)) {

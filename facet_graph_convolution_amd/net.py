@@ -562,6 +562,15 @@ class FacetDenoiser:
     # behind it: conv1 -> {h1, p1}, conv2 -> {h2, p2}), 7 backward (a layer's s rows and cross-edge d-logits together),
     # two scalar all-reduces for normalizeTensor and its gradient, one all-reduce of gradient + loss sum: 17.
     # ------------------------------------------------------------------------------------------
+    @property
+    def pair_split_min_tiles(self):
+        """The split threshold of a pair-form layer's backward exchange, in 32-row tiles of its COARSE rows: the same NUMBER as
+        `split_min_tiles`, i.e. four times stricter in rows.  Its boundary launch - a handful of workgroups of the data kernel -
+        costs that kernel's single-workgroup latency (~20 us at level 0 of a 100k-facet shard, measured: tools/
+        shard_latency_probe.py), so the split pays only where a collective's latency is well above that; at the default
+        threshold no pair layer of a 100k-facet shard splits (782 coarse tiles), at bench.py's tuning candidates 256 / 64 they do."""
+        return self.split_min_tiles
+
     def _option(self, name):
         """The value a library option has for THIS network: its own override (options=...) or the process-level value."""
         if self.option_overrides is not None:
@@ -903,7 +912,22 @@ class FacetDenoiser:
                 call("pair logits")
                 dtb = B["dt"][:npl * cout].view(npl, cout)
                 dlb = B["dl"][:npl * DL_LD].view(npl, DL_LD)
-                yield ("xchg", [("pedges", lay.level, dtb), ("pedges", lay.level, dlb)], None)
+                items = [("pedges", lay.level, dtb), ("pedges", lay.level, dlb)]
+                if self.overlap and pg.tiles["ttiles_int"][1] >= self.pair_split_min_tiles:
+                    # ... it travels under the data kernel of the coarse-row tiles whose in-pairs all have owned parents; the
+                    # tiles with an incoming cross-shard pair and the weight gradients follow (round 6: the pair layers'
+                    # backward exchange used to block - tools/shard_latency_probe.py)
+                    yield ("xchg", items, "bwd")
+                    io.stages, io.flags = 4, base | _lib.CONV_PACKED
+                    io.data_tile_list, io.n_data_tiles = pg.tiles["ttiles_int"][0].data_ptr(), pg.tiles["ttiles_int"][1]
+                    call("pair data/interior")
+                    yield ("wait", "bwd")
+                    io.stages = 4 | 8
+                    io.data_tile_list, io.n_data_tiles = pg.tiles["ttiles_bnd"][0].data_ptr(), pg.tiles["ttiles_bnd"][1]
+                    call("pair data/boundary")
+                    io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
+                    continue
+                yield ("xchg", items, None)
                 io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
                 call("pair data")
                 io.flags = 0

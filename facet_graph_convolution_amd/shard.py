@@ -20,6 +20,8 @@ scalar all-reduces for normalizeTensor and its gradient, one all-reduce of the f
 tail.  A grouped exchange is one RCCL group of point-to-point sends / receives: over xGMI every peer pair has its own
 link, so it is one hop, never a ring.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -223,6 +225,9 @@ class LocalPairGraph:
         self.send_counts, self.recv_counts = list(PP.send_counts), list(PP.recv_counts)
         self.send_edges = up(np.concatenate(PP.send_edges).astype(np.int32))
         self.cross_send_counts, self.cross_recv_counts = list(PP.cross_send_counts), list(PP.cross_recv_counts)
+        # 32-row tiles of the COARSE rows whose in-pairs all have owned parents / that have an incoming cross-shard pair: the
+        # backward data kernel of the pair form runs the first kind while the dt / d-logit rows of the others travel
+        self.tiles = {k: (up(getattr(PP, k)), len(getattr(PP, k))) for k in ("ttiles_int", "ttiles_bnd")}
 
 
 class LocalGraph:
@@ -448,9 +453,10 @@ class SimLatency:
     interior tiles hide as much of it as they last, like on a rank of its own.  All shards share the one compute stream, in
     order: a stall of one shard is not filled by another's kernels."""
 
+    _streams = None      # side streams that were SEEN to run beside the compute stream (found once per process)
+
     def __init__(self, us, n_shards):
         self.us = float(us)
-        self.side = [torch.cuda.Stream() for _ in range(n_shards)]
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
@@ -460,6 +466,32 @@ class SimLatency:
         torch.cuda.synchronize()
         self.cycles_per_us = 4_000_000 / (a.elapsed_time(b) * 1e3)
         self.cycles = int(self.us * self.cycles_per_us)
+        if SimLatency._streams is None:
+            # HIP streams share a few hardware queues, and two streams on one queue run one after the other: a side stream that
+            # happens to share the compute stream's queue would show every overlapped exchange as exposed.  Keep the streams on
+            # which a spin demonstrably overlaps a spin on the compute stream (both take ~200 us: together ~200, not ~400).
+            good, c = [], int(2000 * self.cycles_per_us)
+            self.overlap_test_ms = []
+            for _ in range(12):
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(1000)          # (the first launch on a stream sets its queue up)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                torch.cuda._sleep(c)
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(c)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3
+                self.overlap_test_ms.append(round(ms, 2))
+                if ms < 3.0:                         # (two 2 ms spins: ~2 ms together, ~4 ms one after the other)
+                    good.append(st)
+            SimLatency._streams = good
+        if not SimLatency._streams:
+            raise RuntimeError("SimLatency: no side stream runs beside the compute stream on this device (two 2 ms spins took %s ms)"
+                               % getattr(self, "overlap_test_ms", "?"))
+        self.side = [SimLatency._streams[i % len(SimLatency._streams)] for i in range(n_shards)]
+        self.n_concurrent_streams = len(SimLatency._streams)
 
     def stall(self):
         if self.cycles > 0:

@@ -23,7 +23,7 @@ print("%d facets in %d shards on one GPU; shard 0: interior tiles per level fwd 
       % (F, world, [g[l].tiles["tiles_int"][1] for l in range(3)], [g[l].tiles["ttiles_int"][1] for l in range(3)]))
 lats = (0, 10, 20, 40)
 cal = SimLatency(10, world)
-print("spin kernel: %.1f cycles per us" % cal.cycles_per_us)
+print("spin kernel: %.1f cycles per us; %d of 12 side streams run beside the compute stream" % (cal.cycles_per_us, cal.n_concurrent_streams))
 for thr in (1 << 30, 1024, 256, 64):
     for n in nets:
         n.split_min_tiles = thr
