@@ -186,6 +186,8 @@ class FacetDenoiser:
         # ... only where the interior is big enough to hide an exchange and to fill the GPU on its own: a layer of a
         # coarse level has a few hundred tiles in all, splitting it costs more than the exchange it would cover
         self.split_min_tiles = int(os.environ.get("FGC_SPLIT_MIN_TILES", "1024"))
+        # ... and a layer's weight-gradient stage runs inside the NEXT layer's backward exchange window (_loss_backward_gen)
+        self.dw_in_window = os.environ.get("FGC_NO_DW_IN_WINDOW", "0") != "1"
         # one launch packs the weight operands of all layers, one pair sums all parameter gradients (each small launch
         # costs ~5 us on an idle MI355X, and there were 37 of them per step); FGC_NO_BATCHED=1 = per-layer housekeeping
         self.batched = os.environ.get("FGC_NO_BATCHED", "0") != "1"
@@ -335,7 +337,12 @@ class FacetDenoiser:
         grouped = []
         if self.grouped_dw_mode != "0" and gt is not None:
             grouped.append(self.layers[0].name)   # (no r to keep apart: its GEMM can always wait for the grouped launch)
-            for lay in self.layers[1:]:        # (the first layer has no r: its GEMM reads the saved aggregates and ds)
+            # Facet-sharded: a layer's weight-gradient GEMM is what the NEXT layer's backward exchange hides behind
+            # (_loss_backward_gen: dw_in_window), worth a collective's latency per layer - more than the ramp and tail a grouped
+            # launch saves; only the first layer, which has no exchange, still waits for the grouped launch.  (An explicit
+            # FGC_GROUPED_DW decides otherwise.)
+            windowed = plan is not None and self.dw_in_window and "FGC_GROUPED_DW" not in os.environ
+            for lay in ([] if windowed else self.layers[1:]):   # (the first layer has no r: its GEMM reads the saved aggregates and ds)
                 cnt = ns[lay.level] * rld(lay)
                 # (a layer over a 4x-upsampled tensor runs on its n / 4 coarse rows - the pair form - unless refused)
                 used = cnt // 4 if (lay.shift == 2 and self.pairs) else cnt
@@ -871,6 +878,30 @@ class FacetDenoiser:
                    "head0 bwd")
         # (the stride of r - padded to whole 128-byte lines unless FGC_NO_R_PAD=1 - is stated in every io's r_ld at bind time:
         #  the staged calls below may reset io.flags freely)
+        # Facet-sharded: a layer's weight-gradient stage (8: the GEMM over its r rows and inputs, the partial sums) depends on
+        # nothing that follows it, and r stays intact until the NEXT layer's data kernel writes it.  So it is launched inside
+        # the next layer's exchange window - between the begin of that layer's exchange (s + d-logit rows, or dt + d-logit
+        # rows) and its wait - where it hides 20 - 55 us of a collective's latency that nothing else in a strictly sequential
+        # backward pass can hide (tools/shard_latency_probe.py; FGC_NO_DW_IN_WINDOW=1: right behind its own data kernel).
+        # Same launches, same arithmetic, another order.
+        pending_dw = [None]
+
+        def flush_dw():
+            if pending_dw[0] is not None:
+                pending_dw[0]()
+                pending_dw[0] = None
+
+        def defer_dw(name, d, io, lws, flags):
+            def run():
+                self._tag("bwd:" + name)
+                io.stages, io.flags = 8, flags
+                io.data_tile_list, io.n_data_tiles = None, 0
+                _lib.check(L.fgc_conv_bwd(C.byref(d), C.byref(io), _p(lws), lws.numel(), st), name + " bwd/weights")
+                io.flags = 0
+            pending_dw[0] = run
+            if not self.dw_in_window:
+                flush_dw()
+
         for name in ["dconv1", "upconv1", "dconv2", "upconv2", "dconv3", "conv3", "conv2", "conv1"]:
             self._tag("bwd:" + name)
             # (g_h2 += d pool2 and g_h1 += d pool1 are folded into stage 1 of conv2 / conv1: fgc_conv_bwd_io.pool_y / pool_dy;
@@ -900,6 +931,8 @@ class FacetDenoiser:
             if not L.fgc_conv_bwd_needs_exchange(C.byref(d), C.byref(io)):
                 # first layer over a narrow input: its parameter gradients are sums over owned nodes, nothing to
                 # exchange (the flat-gradient all-reduce adds the ranks)
+                flush_dw()
+                self._tag("bwd:" + name)
                 io.stages = 1 | 2 | 8
                 call("params")
                 continue
@@ -918,19 +951,25 @@ class FacetDenoiser:
                     # tiles with an incoming cross-shard pair and the weight gradients follow (round 6: the pair layers'
                     # backward exchange used to block - tools/shard_latency_probe.py)
                     yield ("xchg", items, "bwd")
+                    flush_dw()
+                    self._tag("bwd:" + name)
                     io.stages, io.flags = 4, base | _lib.CONV_PACKED
                     io.data_tile_list, io.n_data_tiles = pg.tiles["ttiles_int"][0].data_ptr(), pg.tiles["ttiles_int"][1]
                     call("pair data/interior")
                     yield ("wait", "bwd")
-                    io.stages = 4 | 8
                     io.data_tile_list, io.n_data_tiles = pg.tiles["ttiles_bnd"][0].data_ptr(), pg.tiles["ttiles_bnd"][1]
                     call("pair data/boundary")
                     io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
+                    defer_dw(name, d, io, lws, base | _lib.CONV_PACKED)
                     continue
-                yield ("xchg", items, None)
-                io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
+                yield ("xchg", items, "bwd")
+                flush_dw()
+                yield ("wait", "bwd")
+                self._tag("bwd:" + name)
+                io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 call("pair data")
                 io.flags = 0
+                defer_dw(name, d, io, lws, base | _lib.CONV_PACKED)
                 continue
             # s = dy * lrelu'(y) / deg on owned rows and the d-logits of owned edges, in one call (the deep d-logits kernel
             # computes s in its prologue; packs the operands of stages 2 and 4 when the network did not)
@@ -944,19 +983,25 @@ class FacetDenoiser:
                 # ... it travels under the data kernel of the interior tiles (all in-edges from owned rows); boundary
                 # tiles and the weight gradients follow
                 yield ("xchg", items, "bwd")
+                flush_dw()
+                self._tag("bwd:" + name)
                 io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_int"][0].data_ptr(), g.tiles["ttiles_int"][1]
                 call("data/interior")
                 yield ("wait", "bwd")
-                io.stages = 4 | 8
                 io.data_tile_list, io.n_data_tiles = g.tiles["ttiles_bnd"][0].data_ptr(), g.tiles["ttiles_bnd"][1]
                 call("data/boundary")
                 io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
             else:
-                yield ("xchg", items, None)
-                io.stages, io.flags = 4 | 8, base | _lib.CONV_PACKED
+                yield ("xchg", items, "bwd")
+                flush_dw()
+                yield ("wait", "bwd")
+                self._tag("bwd:" + name)
+                io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 call("data")
                 io.flags = 0
+            defer_dw(name, d, io, lws, base | _lib.CONV_PACKED)
+        flush_dw()
         if self.batched:
             A = M["arrays"]
             for lname in self.grouped_dw_layers:      # (the staged calls of a sharded step leave other flags behind)

@@ -447,10 +447,11 @@ def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0, dtype="f32", mult
 
 class SimLatency:
     """Probe infrastructure for sim_run (tools/shard_latency_probe.py): gives the stand-in exchanges the LATENCY of a real
-    collective, which one process on one GPU otherwise never shows.  A blocking exchange or all-reduce stalls the compute
-    stream for `us` microseconds (a spin kernel of one wave); an overlapped exchange spins on a side stream of its shard from
-    the moment the shard resumes computing, and the shard's ("wait", key) makes the compute stream wait for it - so the
-    interior tiles hide as much of it as they last, like on a rank of its own.  All shards share the one compute stream, in
+    collective, which one process on one GPU otherwise never shows.  Every collective is a spin kernel of one wave, `us`
+    microseconds long, on a side stream of its shard that waits for the compute stream (as RCCL's stream does); a blocking
+    exchange or all-reduce makes the compute stream wait for it at once, an overlapped exchange spins from the moment the shard
+    resumes computing and the shard's ("wait", key) makes the compute stream wait - so the launches in between hide as much
+    of it as they last, like on a rank of its own.  All shards share the one compute stream, in
     order: a stall of one shard is not filled by another's kernels."""
 
     _streams = None      # side streams that were SEEN to run beside the compute stream (found once per process)
@@ -493,20 +494,23 @@ class SimLatency:
         self.side = [SimLatency._streams[i % len(SimLatency._streams)] for i in range(n_shards)]
         self.n_concurrent_streams = len(SimLatency._streams)
 
-    def stall(self):
-        if self.cycles > 0:
-            torch.cuda._sleep(self.cycles)
-
     def start(self, i):
         """The clock of shard i's overlapped exchange starts now (the shard resumes); returns the event its wait needs."""
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.side[i]):
             self.side[i].wait_event(ev)
-            self.stall()
+            if self.cycles > 0:
+                torch.cuda._sleep(self.cycles)
             done = torch.cuda.Event()
             done.record()
         return done
+
+    def stall(self, i=0):
+        """A blocking collective of shard i: like every collective of a real rank it runs on ANOTHER stream (RCCL's), which
+        waits for the compute stream and which the compute stream then waits for - the same two cross-stream dependencies as an
+        overlapped exchange whose wait follows at once."""
+        torch.cuda.current_stream().wait_event(self.start(i))
 
 
 def sim_run(nets, make_gen, poison=True, latency=None):
@@ -558,10 +562,10 @@ def sim_run(nets, make_gen, poison=True, latency=None):
             tot = reqs[0][1].clone()
             for r in reqs[1:]:
                 tot += r[1]
-            for r in reqs:
+            for i, r in enumerate(reqs):
                 r[1].copy_(tot)
                 if latency is not None:
-                    latency.stall()      # (an all-reduce blocks every rank: one stall per shard on the shared stream)
+                    latency.stall(i)     # (an all-reduce blocks every rank: one stall per shard on the shared stream)
             continue
         pxs = [n._packed(r) for n, r in zip(nets, reqs)]
         for px in pxs:
@@ -582,7 +586,7 @@ def sim_run(nets, make_gen, poison=True, latency=None):
         for i, (px, r) in enumerate(zip(pxs, reqs)):
             if r[2] is None:
                 if latency is not None:
-                    latency.stall()
+                    latency.stall(i)
                 px.unpack()
             else:
                 assert r[2] not in pending[i], "two exchanges in flight under one key"

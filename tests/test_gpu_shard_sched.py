@@ -314,3 +314,40 @@ def test_capture_is_not_interrupted_by_the_garbage_collector():
     with _no_gc_while_capturing():
         assert not gc.isenabled()
     assert gc.isenabled()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_weight_gradients_inside_the_next_layers_exchange_window(dtype, monkeypatch):
+    """Round 6: a layer's weight-gradient stage (GEMM over its r rows + partial sums) is launched between the BEGIN of the next
+    layer's backward exchange and its wait - the only independent work a sequential backward pass has to put under a
+    collective's latency (tools/shard_latency_probe.py).  Same launches in another order: the gradients equal those of the
+    old order (FGC_NO_DW_IN_WINDOW=1, GEMM right behind its own data kernel) and the unsharded network's within the usual
+    bound; every backward exchange of a layer that follows another is overlapped (begun under a key, awaited later), with
+    launches in between; and r is never overwritten before its reader ran - the halo tails and the r buffer hold NaN until
+    written (sim_run poisons the tails), so a GEMM that ran too late would read the next layer's rows."""
+    from facet_graph_convolution_amd.shard import sim_forward_backward, sim_run
+    x, adjs, gt = _mesh(64, 48, seed=0)
+    samp = np.random.RandomState(4).randint(x.shape[1], size=4000)
+    from facet_graph_convolution_amd.utils import rand_rotation_matrix
+    R = rand_rotation_matrix(randnums=np.random.RandomState(3).uniform(size=3))
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("FGC_NO_DW_IN_WINDOW", off)
+        ref, nets = _step_pair(x, adjs, gt, 2, dtype, samp, R)
+        assert nets[0].dw_in_window == (off == "0")
+        # (windowed: only the first layer, which has no exchange, keeps its GEMM for the grouped launch)
+        assert (len(nets[0].grouped_dw_layers) == 1) == (off == "0")
+        sim_forward_backward(nets, rotate=True)
+        _compare(ref, nets, *TOL[dtype])
+        out[off] = [n.params.grad.clone() for n in nets]
+        if off == "0":
+            _eager_then_segments(ref, nets, dtype)
+            # the schedule itself: every backward exchange is begun under a key and awaited later
+            reqs = [r for r in nets[0]._loss_backward_gen(True)]
+            torch.cuda.synchronize()
+            x_ = [r for r in reqs if r[0] == "xchg"]
+            assert len(x_) == 7 and all(r[2] == "bwd" for r in x_) and sum(1 for r in reqs if r[0] == "wait") == 7
+    for a, b in zip(out["1"], out["0"]):
+        # (the two runs group different layers' GEMMs - one launch per kernel form or one per layer: the same sums in the same
+        #  order, tests/test_gpu_net.py::test_grouped_weight_gradient_launches_equal_the_per_layer_launches)
+        assert torch.equal(a, b), "the windowed order changed a gradient: max diff %.3e" % (a - b).abs().max().item()
