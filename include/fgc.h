@@ -320,7 +320,9 @@ typedef struct fgc_conv_bwd_io {
     float* dc;
     float* dv;
     const int32_t* data_tile_list; /* device, [n_data_tiles]: 32-row tiles stage 4 computes; NULL = all.  Tiles whose
-                                      in-edges all come from owned rows need neither halo rows of ds nor remote dl */
+                                      in-edges all come from owned rows need neither halo rows of ds nor remote dl.  Pair
+                                      form: tiles of the n / 4 COARSE rows the data kernel runs over (those whose in-pairs
+                                      all have owned parents need no incoming dt / dl row) */
     int32_t n_data_tiles;
     int32_t flags;                 /* FGC_CONV_PACKED: the operands are already packed (an earlier stage call, or
                                     * fgc_conv_pack); FGC_CONV_DEFER_REDUCE: see fgc_conv_bwd_reduce */
