@@ -83,7 +83,7 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert set(tune["ms_per_step"]) == {"1024", "256", "64"} and all(v > 0 for v in tune["ms_per_step"].values())
     assert tune["default"] == 1024 and tune["chosen"] in (1024, 256, 64) and "split-threshold tuning" in j["timeline"]
     if tune["chosen"] != 1024:
-        assert tune["ms_per_step"][str(tune["chosen"])] < 0.98 * tune["ms_per_step"]["1024"]
+        assert tune["ms_per_step"][str(tune["chosen"])] < 0.97 * tune["ms_per_step"]["1024"]
     # --graph 1: the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
     # (stretches WITH launches only: two requests back to back leave no graph; this small mesh splits no layer)
     e = _bench(["--gpus", "2", "--graph", "1"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})
