@@ -622,22 +622,29 @@ def main(argv=None):
     import gc
     gc.collect()
     gc.freeze()
-    # Facet-sharded: WHICH layers run as interior | exchange | boundary launches is a latency question.  A layer below
-    # net.split_min_tiles interior tiles waits for its halo rows and runs as one launch; above it the exchange travels under
-    # the interior tiles at the price of a second, half-empty launch.  The default (1024: level 0 of a 100k-facet shard only)
-    # was set where an "exchange" is a 5 us device copy (two shards in one process, tools/shard_step_probe.py); on xGMI the
-    # collective of a coarse level is latency the one-GPU probes never saw.  So the job measures it on ITS OWN collectives,
-    # before the warm-up: a few steps per candidate threshold, max over ranks through an all-reduce (every rank reads the same
-    # numbers and takes the same decision), the default kept unless a candidate is 3 % faster.  FGC_SPLIT_MIN_TILES set: no tuning.
+    # Facet-sharded: HOW MUCH of the schedule overlaps its exchanges is a latency question.  An exchange that nothing overlaps is
+    # one blocking call - a synchronous collective on the compute stream; an overlapped one is asynchronous, i.e. on RCCL's own
+    # stream behind two cross-stream dependencies that cost ~20 us by themselves (tools/rccl_call_cost_probe.py), which pays
+    # only if the collective lasts longer than that.  Three things overlap: the interior tiles of a layer with at least
+    # net.split_min_tiles of them (at the price of a second, half-empty launch), and - net.dw_in_window - the previous layer's
+    # weight-gradient stage inside a layer's backward exchange window.  The defaults (1024, window) were set on an EMULATED
+    # latency (two shards in one process, tools/shard_latency_probe.py: they win above ~30 us per collective, lose 2 - 3 % below);
+    # what a grouped all-to-all costs on xGMI is not known here.  So the job measures on ITS OWN collectives, before the
+    # warm-up: a few steps per candidate, two interleaved passes, max over ranks through an all-reduce (every rank reads the same
+    # numbers and takes the same decision); the default is kept unless a candidate is 3 % faster.  FGC_SPLIT_MIN_TILES or
+    # FGC_NO_DW_IN_WINDOW set: no tuning.
     split_tune = None
-    if shard and train and not graph_mode[0] and "FGC_SPLIT_MIN_TILES" not in os.environ and getattr(net, "overlap", False):
-        default_thr = net.split_min_tiles
+    if shard and train and not graph_mode[0] and "FGC_SPLIT_MIN_TILES" not in os.environ and "FGC_NO_DW_IN_WINDOW" not in os.environ \
+            and getattr(net, "overlap", False):
+        default = (net.split_min_tiles, net.dw_in_window)
+        cands = [default, (default[0], False), (1 << 30, False), (256, True), (64, True)]
+        label = lambda c: "%s/%s" % ("none" if c[0] >= 1 << 30 else c[0], "window" if c[1] else "behind")
         try:
             ntune = max(3, min(8, args.steps))
             res = {}
             for _pass in range(2):           # (two interleaved passes, the minimum per candidate: one slow block must not decide)
-                for thr in sorted({default_thr, 256, 64}, reverse=True):
-                    net.split_min_tiles = thr
+                for c in cands:
+                    net.split_min_tiles, net.dw_in_window = c
                     step()
                     step()
                     sync_barrier()
@@ -647,16 +654,18 @@ def main(argv=None):
                     sync_barrier()
                     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    res[thr] = min(res.get(thr, 1e30), tt.item() / ntune * 1e3)
+                    res[c] = min(res.get(c, 1e30), tt.item() / ntune * 1e3)
             best = min(res, key=res.get)
-            chosen = best if res[best] < 0.97 * res[default_thr] else default_thr
-            net.split_min_tiles = chosen
-            split_tune = {"ms_per_step": {str(k): round(v, 4) for k, v in res.items()}, "steps_each": ntune, "passes": 2,
-                          "chosen": chosen, "default": default_thr, "rule": "a candidate replaces the default if it is 3 % faster"}
+            chosen = best if res[best] < 0.97 * res[default] else default
+            net.split_min_tiles, net.dw_in_window = chosen
+            split_tune = {"ms_per_step": {label(c): round(v, 4) for c, v in res.items()}, "steps_each": ntune, "passes": 2,
+                          "chosen": label(chosen), "default": label(default),
+                          "candidates": "split threshold (interior tiles) / weight-gradient stage in the next layer's exchange window or behind its data kernel",
+                          "rule": "a candidate replaces the default if it is 3 % faster"}
         except Exception as e:               # noqa: BLE001 - an optimisation: its failure leaves the default schedule
-            net.split_min_tiles = default_thr
-            split_tune = {"error": "%s: %s" % (type(e).__name__, str(e)[:200]), "chosen": default_thr, "default": default_thr}
-            print("bench: split-threshold tuning failed (%s), default kept" % split_tune["error"], file=sys.stderr)
+            net.split_min_tiles, net.dw_in_window = default
+            split_tune = {"error": "%s: %s" % (type(e).__name__, str(e)[:200]), "chosen": label(default), "default": label(default)}
+            print("bench: schedule tuning failed (%s), default kept" % split_tune["error"], file=sys.stderr)
     w_done = 0
     graph_note = None
     if args.graph and world == 1 and train:
@@ -1016,7 +1025,7 @@ def main(argv=None):
             "loss_deg": loss,
             # what the process ran, in order (round 6: the hipEvent pass moved in front; the timed region is W + K steps as ever)
             "timeline": ("%s%sW = %d untimed warm-up steps -> K = %d timed steps between barriers -> untimed extras" % (
-                "split-threshold tuning (`split_tune`) -> " if split_tune is not None else "",
+                "schedule tuning (`split_tune`) -> " if split_tune is not None else "",
                 "per-kernel hipEvent pass (%d eager steps; also warms the clocks) -> " % args.steps if prof is not None else "",
                 args.warmup, args.steps)),
             "startup_s": {k: round(v, 2) for k, v in startup.items()},

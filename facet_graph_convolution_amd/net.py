@@ -639,6 +639,19 @@ class FacetDenoiser:
         wait_before = {"conv2": "conv1", "conv3": "conv2", "dconv3": "conv3", "upconv2": "dconv3", "dconv2": "upconv2",
                        "upconv1": "dconv2", "dconv1": "upconv1"}
         split = self.sharded and self.overlap
+        # A layer's output exchange is begun under a key only if its consumer launches something before it waits (interior
+        # tiles, the transform of the owned coarse rows, a multi-scale head); otherwise it is served as ONE blocking call - a
+        # synchronous collective runs on the compute stream itself, without the two cross-stream dependencies of an
+        # asynchronous one (20 - 25 us per call on this platform: tools/rccl_call_cost_probe.py)
+        in_flight = set()
+
+        def consumer_overlaps(nxt):
+            if nxt is None or not split:
+                return False
+            dn = M["descs"][nxt.name]
+            if L.fgc_conv_uses_pairs(C.byref(dn)):
+                return True
+            return M["graphs"][nxt.level].tiles["tiles_int"][1] >= self.split_min_tiles
         packed = 0
         table_done = False      # the first layer's logit table came with the housekeeping launch
         if self.batched:
@@ -674,7 +687,7 @@ class FacetDenoiser:
             if mlp_packed:
                 mlp_packed = M["mlp_packed"] = _lib.MLP_PACKED | _lib.mlp_layout(
                     L.fgc_mlp_layout_id(32, HIDDEN, 3, 1 if self.dtype == "bf16" else 0))
-        for lay in self.layers:
+        for li, lay in enumerate(self.layers):
             d = M["descs"][lay.name]
             lws = B["wsf_" + lay.name]
             lflags = M["layer_flags"][lay.name]
@@ -682,13 +695,15 @@ class FacetDenoiser:
             args = (C.byref(d), _p(B["ag_" + lay.name]), _p(B[lay.y]), _p(B[lay.pool]) if lay.pool else None, _p(lws),
                     lws.numel(), st)
             need = wait_before.get(lay.name) if self.sharded else None
+            if need is not None and need not in in_flight:
+                need = None          # (its producer's exchange was a blocking call: the halo rows are there)
             if self.sharded and need and L.fgc_conv_uses_pairs(C.byref(d)):
                 # pair form: the owned coarse rows are transformed while the halo parents travel; then the tail rows and
                 # every block (include/fgc.h: partial forward calls)
                 g = M["graphs"][lay.level]
                 own_src = d.n >> 2
                 self._tag("fwd:" + lay.name)
-                if split:
+                if split and need:
                     d.tile_list, d.n_tiles = g.tiles["tiles_int"][0].data_ptr(), 0
                     d.proj_row0, d.proj_rows = 0, own_src
                     _lib.check(L.fgc_conv_fwd(*args), lay.name)
@@ -699,7 +714,8 @@ class FacetDenoiser:
                     _lib.check(L.fgc_conv_fwd(*args), lay.name)
                     d.proj_row0, d.proj_rows, d.flags = 0, 0, packed | lflags
                 else:
-                    yield ("wait", need)
+                    if need:
+                        yield ("wait", need)
                     _lib.check(L.fgc_conv_fwd(*args), lay.name)
             elif split and need and M["graphs"][lay.level].tiles["tiles_int"][1] >= self.split_min_tiles:
                 # interior tiles (they gather owned rows only) run while the halo rows travel; then the rest
@@ -726,7 +742,12 @@ class FacetDenoiser:
                     d.proj_rows = 0
             if self.sharded and lay.name in send_after:
                 items = [(k, lv, B[t], par) for k, lv, t, par in send_after[lay.name]]
-                yield ("xchg", items, lay.name)
+                nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
+                if consumer_overlaps(nxt) or (self.multi_scale and lay.name in ("dconv3", "dconv2")):
+                    in_flight.add(lay.name)
+                    yield ("xchg", items, lay.name)
+                else:
+                    yield ("xchg", items, None)
             if self.multi_scale and lay.name in ("dconv3", "dconv2"):
                 head, out = ("head2", "y2") if lay.name == "dconv3" else ("head1", "y1")
                 W1, b1, W2, b2 = vals[self.slot[head]:self.slot[head] + 4]
@@ -962,9 +983,13 @@ class FacetDenoiser:
                     io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
                     defer_dw(name, d, io, lws, base | _lib.CONV_PACKED)
                     continue
-                yield ("xchg", items, "bwd")
+                # (nothing to put under it - no weight-gradient stage pending -: ONE blocking call, a synchronous collective on
+                #  the compute stream, without the cross-stream dependencies of an asynchronous one)
+                key = "bwd" if pending_dw[0] is not None else None
+                yield ("xchg", items, key)
                 flush_dw()
-                yield ("wait", "bwd")
+                if key:
+                    yield ("wait", key)
                 self._tag("bwd:" + name)
                 io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 call("pair data")
@@ -993,9 +1018,11 @@ class FacetDenoiser:
                 call("data/boundary")
                 io.data_tile_list, io.n_data_tiles, io.flags = None, 0, 0
             else:
-                yield ("xchg", items, "bwd")
+                key = "bwd" if pending_dw[0] is not None else None
+                yield ("xchg", items, key)
                 flush_dw()
-                yield ("wait", "bwd")
+                if key:
+                    yield ("wait", key)
                 self._tag("bwd:" + name)
                 io.stages, io.flags = 4, base | _lib.CONV_PACKED
                 call("data")

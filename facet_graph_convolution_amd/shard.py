@@ -384,7 +384,14 @@ class DistComm:
         return (work, px)
 
     def exchange(self, px):
-        self.finish(self.exchange_begin(px))
+        """The exchange `px` as ONE blocking call, for a schedule that has nothing to launch before it needs the rows: pack,
+        a SYNCHRONOUS collective, unpack.  torch (>= 2.7) runs a synchronous RCCL op on the current stream - no event for
+        RCCL's own stream to wait for, none for the compute stream to wait for afterwards: 19 us per call instead of 40 on the
+        compute stream's clock, 26 instead of 50 us of host time (world size 1, tools/rccl_call_cost_probe.py,
+        profiles/r6_rccl_call_cost_probe.txt).  The host does not block either way."""
+        px.pack()
+        self.all_to_all_flat(px.send_buf, px.send_splits, px.recv_buf, px.recv_splits, async_op=False)
+        px.unpack()
 
     def finish(self, handle):
         if handle is not None:
@@ -448,16 +455,18 @@ def make_sim_shards(x, adjs, gt, world, device="cuda", seed=0, dtype="f32", mult
 class SimLatency:
     """Probe infrastructure for sim_run (tools/shard_latency_probe.py): gives the stand-in exchanges the LATENCY of a real
     collective, which one process on one GPU otherwise never shows.  Every collective is a spin kernel of one wave, `us`
-    microseconds long, on a side stream of its shard that waits for the compute stream (as RCCL's stream does); a blocking
-    exchange or all-reduce makes the compute stream wait for it at once, an overlapped exchange spins from the moment the shard
-    resumes computing and the shard's ("wait", key) makes the compute stream wait - so the launches in between hide as much
-    of it as they last, like on a rank of its own.  All shards share the one compute stream, in
+    microseconds long.  A blocking exchange or all-reduce spins in the compute stream itself (a synchronous RCCL op runs on the
+    current stream); an overlapped exchange spins on a side stream of its shard that waits for the compute stream (as RCCL's
+    own stream does for an asynchronous op) from the moment the shard resumes computing, and the shard's ("wait", key) makes
+    the compute stream wait for it - so the launches in between hide as much of it as they last, like on a rank of its own,
+    at the price of the two cross-stream dependencies.  All shards share the one compute stream, in
     order: a stall of one shard is not filled by another's kernels."""
 
     _streams = None      # side streams that were SEEN to run beside the compute stream (found once per process)
 
-    def __init__(self, us, n_shards):
+    def __init__(self, us, n_shards, sync_on_side_stream=False):
         self.us = float(us)
+        self.sync_on_side_stream = bool(sync_on_side_stream)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
@@ -507,10 +516,14 @@ class SimLatency:
         return done
 
     def stall(self, i=0):
-        """A blocking collective of shard i: like every collective of a real rank it runs on ANOTHER stream (RCCL's), which
-        waits for the compute stream and which the compute stream then waits for - the same two cross-stream dependencies as an
-        overlapped exchange whose wait follows at once."""
-        torch.cuda.current_stream().wait_event(self.start(i))
+        """A blocking collective of shard i (an exchange served as one blocking call, an all-reduce): torch runs a synchronous
+        RCCL op on the CURRENT stream, so it is a spin kernel in the compute stream itself - no cross-stream dependency.
+        (`sync_on_side_stream`: the pre-2.7 behaviour and what shard.DistComm did until round 6 - the op on another stream,
+        which waits for the compute stream and which the compute stream then waits for.)"""
+        if self.sync_on_side_stream:
+            torch.cuda.current_stream().wait_event(self.start(i))
+        elif self.cycles > 0:
+            torch.cuda._sleep(self.cycles)
 
 
 def sim_run(nets, make_gen, poison=True, latency=None):

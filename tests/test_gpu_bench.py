@@ -77,13 +77,14 @@ def test_two_ranks_from_a_plain_shell_over_gloo():
     assert set(j["startup_s"]) == {"preprocess_s", "shard_plan_s", "bind_s"}
     # the default of N > 1 is eager launches (bench.py: graph_mode); no retry happened
     assert "eager launches" in j["config"]["parallelism"] and j["hipgraph_replay"] is None and j["retry_note"] is None
-    # which layers split around their exchange was measured on the job's own collectives before the warm-up (every rank reads
-    # the same all-reduced times, so every rank chose alike); a pinned threshold or hipGraph segments: no tuning
+    # how much of the schedule overlaps its exchanges was measured on the job's own collectives before the warm-up (every rank
+    # reads the same all-reduced times, so every rank chose alike); a pinned threshold or hipGraph segments: no tuning
     tune = j["split_tune"]
-    assert set(tune["ms_per_step"]) == {"1024", "256", "64"} and all(v > 0 for v in tune["ms_per_step"].values())
-    assert tune["default"] == 1024 and tune["chosen"] in (1024, 256, 64) and "split-threshold tuning" in j["timeline"]
-    if tune["chosen"] != 1024:
-        assert tune["ms_per_step"][str(tune["chosen"])] < 0.97 * tune["ms_per_step"]["1024"]
+    assert set(tune["ms_per_step"]) == {"1024/window", "1024/behind", "none/behind", "256/window", "64/window"}
+    assert all(v > 0 for v in tune["ms_per_step"].values()) and tune["default"] == "1024/window" and tune["passes"] == 2
+    assert tune["chosen"] in tune["ms_per_step"] and "schedule tuning" in j["timeline"]
+    if tune["chosen"] != tune["default"]:
+        assert tune["ms_per_step"][tune["chosen"]] < 0.97 * tune["ms_per_step"][tune["default"]]
     # --graph 1: the same schedule replayed from hipGraphs, one per stretch of launches between two exchanges
     # (stretches WITH launches only: two requests back to back leave no graph; this small mesh splits no layer)
     e = _bench(["--gpus", "2", "--graph", "1"] + SMALL, env={"FGC_BENCH_BACKEND": "gloo"})

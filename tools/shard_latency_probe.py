@@ -30,31 +30,40 @@ lats = (0, 10, 20, 40)
 cal = SimLatency(10, world)
 print("spin kernel: %.1f cycles per us; %d of 12 side streams run beside the compute stream" % (cal.cycles_per_us, cal.n_concurrent_streams))
 thrs = (1 << 30, 1024, 256, 64)
-modes = (("segments", sim_forward_backward_captured), ("eager", sim_forward_backward))
+modes = (("eager", sim_forward_backward), ("segments", sim_forward_backward_captured))
+# (weight-gradient stage, blocking collectives on a side stream?) - the last one is what shard.DistComm did until round 6:
+# every exchange an asynchronous op awaited at once
+variants = (("window", False), ("behind", False), ("behind", True))
 best = {}
 for rep in range(3):
-    for window, nets in sets.items():
+    for window, side in variants:
+        nets = sets[window]
         for thr in thrs:
             for n in nets:
                 n.split_min_tiles = thr
                 n._graph_fb = None
             for mode, fn in modes:
+                if mode == "segments" and thr not in (1024,):
+                    continue
                 for X in lats:
-                    lat = SimLatency(X, world) if X else None
+                    lat = SimLatency(X, world, sync_on_side_stream=side) if (X or side) else None
                     for _ in range(3):
                         fn(nets, rotate=True, latency=lat)
                     torch.cuda.synchronize(); t = time.perf_counter()
                     for _ in range(steps):
                         fn(nets, rotate=True, latency=lat)
                     torch.cuda.synchronize()
-                    k = (window, mode, thr, X)
+                    k = (window, side, mode, thr, X)
                     best[k] = min(best.get(k, 1e9), (time.perf_counter() - t) / steps / world * 1e3)
 print("ms per shard and step at X = %s us   | exposed collectives of 17 (slope between %d and %d us)" % ("/".join(str(v) for v in lats), lats[1], lats[-1]))
 for mode, _ in modes:
     for thr in thrs:
-        for window in sets:
-            row = [best[(window, mode, thr, X)] for X in lats]
+        for window, side in variants:
+            if (window, side, mode, thr, lats[0]) not in best:
+                continue
+            row = [best[(window, side, mode, thr, X)] for X in lats]
             slope = (row[-1] - row[1]) / (lats[-1] - lats[1]) * 1e3
-            print("%-8s threshold %-10s dW %-6s  %s   | %.1f" % (mode, "none" if thr == 1 << 30 else thr, window,
-                                                               "  ".join("%.3f" % v for v in row), slope))
-print("loss %.4f / %.4f" % tuple(s[0].buffers["loss"][0].item() for s in sets.values()))
+            print("%-8s threshold %-6s dW %-6s blocking collectives %-22s %s   | %.1f"
+                  % (mode, "none" if thr == 1 << 30 else thr, window, "on a side stream" if side else "in the compute stream",
+                     "  ".join("%.3f" % v for v in row), slope))
+print("loss %.4f / %.4f" % tuple(s_[0].buffers["loss"][0].item() for s_ in sets.values()))
